@@ -1,0 +1,398 @@
+"""ORACLE (test infrastructure, not product code) for the `c_lqp_solve` hot path.
+
+A CPU restatement of what the reference does for one convex sub-problem
+(PMPC.jl/src/main.jl:115-171 `lqp_solve`):
+
+  1. assemble the joint sparse QP  (P,q), (A,b), (G,l,u)  exactly as
+     PMPC.jl/src/lqp_utils.jl:2-393 does            -> oracle/lqp_assemble.c (ctypes)
+  2. hand it to OSQP: `[A;G] z in [[b;l],[b;u]]`    (PMPC.jl/src/osqp_solver.jl:20-72)
+  3. scatter z back into X,U (lqp_utils.jl:395-423) -> split_lqp_vars
+
+The numeric solver of step 2 is a third-party dependency that is NOT in
+/root/reference: OSQP.jl 0.8.0 -> OSQP_jll 0.600.200 (OSQP C 0.6.2, ADMM + QDLDL;
+PMPC.jl/Manifest.toml:294-304).  Its published algorithm (Stellato et al., "OSQP: an
+operator splitting solver for quadratic programs", Alg. 1 + the rho_eq = 1e3*rho rule
++ adaptive rho + polish) is restated in `osqp_admm` below with scipy's SuperLU in
+place of QDLDL.  Because OSQP at its default eps=1e-3 only reaches z* to ~1e-3, the
+oracle's answer is the UNIQUE optimum z* of the strictly convex QP: `solve_qp_exact`
+refines the ADMM guess by an active-set KKT solve and returns a KKT certificate
+(stationarity, primal feasibility, multiplier signs, complementarity).
+
+OSQP.jl keeps only the upper triangle of P (`P = triu(P)` in its `setup!`), so the
+effective Hessian is triu(P) + triu(P,1)'.  `effective_P` applies that; for the
+symmetric Q,R every reference problem uses it is the identity.
+
+PARITY UNPINNED: the reference's own tests hold no numeric golden vector for this
+path (PMPC.jl/test/runtests.jl:33-41 only asserts !isnan; tests/pmpcjl_test.py has no
+asserts) and neither Julia nor OSQP can run in the build container.  The oracle is
+pinned by (a) its KKT certificate on every solve, (b) the reference's own Python SCP
+loop (pmpc/scp_mpc.py:205-442) run over it to make tests/golden/*.npz.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+Layouts.  "py" layout = the reference's Python-side arrays (pmpc/scp_mpc.py:297-321):
+x0 (M,x), f (M,N,x), fx (M,N,x,x) with fx[i,j,r,t] = dF_r/dx_t, fu (M,N,x,u),
+Q (M,N,x,x), R (M,N,u,u), vectors (M,N,d).  "abi" layout = the C-ABI buffers
+(PMPC.jl/src/c_interface.jl:28-46): the same vectors, and matrices with their last two
+axes swapped (column-major blocks) — pmpc/julia_utils.py:69-77 + asfortranarray.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+import subprocess
+import time
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+_HERE = Path(__file__).resolve().parent
+_SO = _HERE / "liblqp_oracle.so"
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    """gcc-compile the C restatement (recipe also in oracle/Makefile)."""
+    src = _HERE / "lqp_assemble.c"
+    if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-o", str(_SO), str(src)])
+    return _SO
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(_SO))
+        _lib.lqp_repr_Pq.restype = ctypes.c_longlong
+        _lib.lqp_repr_Ab.restype = ctypes.c_longlong
+        _lib.lqp_repr_Gla.restype = ctypes.c_longlong
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def to_abi_mat(A):
+    """py (..., row, col) -> abi memory (..., col, row)."""
+    return np.ascontiguousarray(np.swapaxes(np.asarray(A, dtype=np.float64), -1, -2))
+
+
+# -------------------------------------------------------------------------------------------------
+# sentinels: PMPC.jl/src/c_interface.jl:56-70
+# -------------------------------------------------------------------------------------------------
+def unwrap_sentinels(M, udim, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1):
+    has_xb = not (np.any(np.isnan(lx)) or np.any(np.isnan(ux)))
+    has_ub = not (np.any(np.isnan(lu)) or np.any(np.isnan(uu)))
+    # absent slew_reg -> make_probs default 0.0 (main.jl:23-25)
+    sr = np.zeros(M) if np.any(np.isnan(slew_reg)) else _f64(slew_reg).reshape(M)
+    if np.any(np.isnan(slew_reg0)) or np.any(np.isnan(slew_um1)):
+        sr0, um1 = np.zeros(M), np.zeros((M, udim))  # main.jl:23-27 defaults
+    else:
+        sr0, um1 = _f64(slew_reg0).reshape(M), _f64(slew_um1).reshape(M, udim)
+    return has_xb, has_ub, sr, sr0, um1
+
+
+# -------------------------------------------------------------------------------------------------
+# assembly (ctypes into lqp_assemble.c)
+# -------------------------------------------------------------------------------------------------
+class JointQP:
+    __slots__ = ("P", "q", "A", "b", "G", "l", "u", "dims", "Nc", "t_assemble")
+
+
+def assemble_abi(
+    xdim, udim, N, M, Nc, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
+    slew_reg, slew_reg0, slew_um1,
+) -> JointQP:
+    """All array arguments are float64 buffers in ABI layout (any shape, C-contiguous memory)."""
+    lib = _load()
+    t0 = time.perf_counter()
+    f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = map(_f64, (f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref))
+    lx, ux, lu, uu = map(_f64, (lx, ux, lu, uu))
+    has_xb, has_ub, sr, sr0, um1 = unwrap_sentinels(M, udim, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1)
+    sr, sr0, um1 = map(_f64, (sr, sr0, um1))
+    ll = ctypes.c_longlong
+    n, m_eq, m_in, nnzP, nnzA = ll(), ll(), ll(), ll(), ll()
+    sz = ctypes.c_size_t
+    dims = (sz(xdim), sz(udim), sz(N), sz(M), ll(Nc))
+    lib.lqp_sizes(*dims, ctypes.c_int(has_ub), ctypes.c_int(has_xb), *(ctypes.byref(v) for v in (n, m_eq, m_in, nnzP, nnzA)))
+    n, m_eq, m_in, nnzP, nnzA = (v.value for v in (n, m_eq, m_in, nnzP, nnzA))
+
+    Pp, Pi, Px, q = np.zeros(n + 1, np.int64), np.zeros(nnzP, np.int64), np.zeros(nnzP), np.zeros(n)
+    k = lib.lqp_repr_Pq(*dims, _p(X_prev), _p(U_prev), _p(Q), _p(R), _p(X_ref), _p(U_ref),
+                        ctypes.c_double(reg_x), ctypes.c_double(reg_u), _p(sr), _p(sr0), _p(um1),
+                        _p(Pp), _p(Pi), _p(Px), _p(q))
+    assert 0 <= k <= nnzP
+    P = sp.csc_matrix((Px[:k], Pi[:k], Pp), shape=(n, n))
+
+    Ap, Ai, Ax, b = np.zeros(n + 1, np.int64), np.zeros(nnzA, np.int64), np.zeros(nnzA), np.zeros(m_eq)
+    k = lib.lqp_repr_Ab(*dims, _p(f), _p(fx), _p(fu), _p(X_prev), _p(U_prev), _p(Ap), _p(Ai), _p(Ax), _p(b))
+    assert k == nnzA
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(m_eq, n))
+
+    Gp, Gi, Gx = np.zeros(n + 1, np.int64), np.zeros(m_in, np.int64), np.zeros(m_in)
+    l, u = np.zeros(m_in), np.zeros(m_in)
+    k = lib.lqp_repr_Gla(*dims, ctypes.c_int(has_ub), ctypes.c_int(has_xb), _p(lx), _p(ux), _p(lu), _p(uu),
+                         _p(Gp), _p(Gi), _p(Gx), _p(l), _p(u))
+    assert k == m_in
+    G = sp.csc_matrix((Gx, Gi, Gp), shape=(m_in, n))
+
+    qp = JointQP()
+    qp.P, qp.q, qp.A, qp.b, qp.G, qp.l, qp.u = P, q, A, b, G, l, u
+    qp.dims, qp.Nc = (xdim, udim, N, M), (Nc if Nc >= 0 else N)
+    qp.t_assemble = time.perf_counter() - t0
+    return qp
+
+
+def split_vars(qp: JointQP, z):
+    """split_lqp_vars (lqp_utils.jl:395-423) -> X (M,N,x), U (M,N,u) (== ABI (x,N,M), (u,N,M) memory)."""
+    lib = _load()
+    xdim, udim, N, M = qp.dims
+    z = _f64(z)
+    X, U = np.zeros((M, N, xdim)), np.zeros((M, N, udim))
+    sz, ll = ctypes.c_size_t, ctypes.c_longlong
+    lib.split_lqp_vars(sz(xdim), sz(udim), sz(N), sz(M), ll(qp.Nc), _p(z), _p(X), _p(U))
+    return X, U
+
+
+def effective_P(P):
+    """OSQP.jl `setup!` keeps triu(P); the Hessian OSQP minimises is triu(P) + triu(P,1)'."""
+    Pu = sp.triu(P, format="csc")
+    return (Pu + sp.triu(P, k=1, format="csc").T).tocsc()
+
+
+# -------------------------------------------------------------------------------------------------
+# restated OSQP (ADMM) — the reference's numeric solver (osqp_solver.jl:34-72 -> OSQP C 0.6.2)
+# -------------------------------------------------------------------------------------------------
+def osqp_admm(P, q, Aa, la, ua, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, rho=0.1, sigma=1e-6, alpha=1.6,
+              adaptive_rho=True, check_every=25, x0=None, y0=None):
+    """OSQP Algorithm 1 with the published defaults (rho=0.1, sigma=1e-6, alpha=1.6, rho_eq=1e3*rho,
+    eps_abs=eps_rel=1e-3, max_iter=4000, adaptive rho).  Problem scaling (Ruiz) is not restated: it
+    changes the iteration path, not the fixed point.  Returns x, y, info."""
+    n, m = P.shape[0], Aa.shape[0]
+    eq = (ua - la) <= 1e-12 * np.maximum(1.0, np.abs(la))
+    x = np.zeros(n) if x0 is None else x0.copy()
+    y = np.zeros(m) if y0 is None else y0.copy()
+    z = np.clip(Aa @ x, la, ua)
+    AaT = Aa.T.tocsc()
+    nfact = 0
+
+    def factor(rho_):
+        rho_vec = np.where(eq, 1e3 * rho_, rho_)
+        K = sp.bmat([[P + sigma * sp.identity(n), AaT], [Aa, -sp.diags(1.0 / rho_vec)]], format="csc")
+        return spla.splu(K), rho_vec
+
+    lu, rho_vec = factor(rho)
+    nfact += 1
+    it, status = 0, "max_iter"
+    for it in range(1, max_iter + 1):
+        rhs = np.concatenate([sigma * x - q, z - y / rho_vec])
+        sol = lu.solve(rhs)
+        xt, nu = sol[:n], sol[n:]
+        zt = z + (nu - y) / rho_vec
+        x = alpha * xt + (1 - alpha) * x
+        zr = alpha * zt + (1 - alpha) * z
+        z_new = np.clip(zr + y / rho_vec, la, ua)
+        y = y + rho_vec * (zr - z_new)
+        z = z_new
+        if it % check_every == 0 or it == max_iter:
+            Ax, Px, Aty = Aa @ x, P @ x, AaT @ y
+            rp, rd = np.linalg.norm(Ax - z, np.inf), np.linalg.norm(Px + q + Aty, np.inf)
+            ep = eps_abs + eps_rel * max(np.linalg.norm(Ax, np.inf), np.linalg.norm(z, np.inf))
+            ed = eps_abs + eps_rel * max(np.linalg.norm(Px, np.inf), np.linalg.norm(Aty, np.inf), np.linalg.norm(q, np.inf))
+            if rp <= ep and rd <= ed:
+                status = "solved"
+                break
+            if adaptive_rho:
+                num = rp / max(np.linalg.norm(Ax, np.inf), np.linalg.norm(z, np.inf), 1e-30)
+                den = rd / max(np.linalg.norm(Px, np.inf), np.linalg.norm(Aty, np.inf), np.linalg.norm(q, np.inf), 1e-30)
+                rho_new = float(np.clip(rho * math.sqrt(num / max(den, 1e-30)), 1e-6, 1e6))
+                if rho_new > 5 * rho or rho_new < rho / 5:
+                    rho = rho_new
+                    lu, rho_vec = factor(rho)
+                    nfact += 1
+    return x, y, dict(iters=it, status=status, rho=rho, factorizations=nfact)
+
+
+# -------------------------------------------------------------------------------------------------
+# exact optimum + KKT certificate
+# -------------------------------------------------------------------------------------------------
+def _kkt_solve(P, A, GW, rhs_z, rhs_eq, rhs_w, refine=3):
+    n, me, mw = P.shape[0], A.shape[0], GW.shape[0]
+    blocks = [[P, A.T, GW.T if mw else None], [A, None, None]]
+    if mw:
+        blocks.append([GW, None, None])
+    else:
+        blocks = [[P, A.T], [A, None]]
+    K = sp.bmat(blocks, format="csc")
+    rhs = np.concatenate([rhs_z, rhs_eq, rhs_w])
+    try:
+        lu = spla.splu(K)
+    except RuntimeError:
+        # degenerate active set (redundant active rows): regularise like OSQP's polish
+        # (delta = 1e-6) and recover the un-regularised solution by iterative refinement
+        delta = 1e-7
+        reg = sp.diags(np.concatenate([np.full(n, delta), np.full(me + mw, -delta)]))
+        lu = spla.splu((K + reg).tocsc())
+        refine = 30
+    sol = lu.solve(rhs)
+    for _ in range(refine):
+        sol += lu.solve(rhs - K @ sol)
+    return sol[:n], sol[n:n + me], sol[n + me:]
+
+
+def kkt_certificate(P, q, A, b, G, l, u, z, y, mu):
+    """mu > 0 pushes against the upper bound, mu < 0 against the lower one."""
+    Gz = G @ z if G.shape[0] else np.zeros(0)
+    r_stat = P @ z + q + A.T @ y + (G.T @ mu if G.shape[0] else 0.0)
+    r_eq = A @ z - b
+    viol = np.maximum(np.maximum(l - Gz, Gz - u), 0.0) if G.shape[0] else np.zeros(0)
+    comp = np.minimum(np.maximum(mu, 0.0), np.abs(u - Gz)) + np.minimum(np.maximum(-mu, 0.0), np.abs(Gz - l)) if G.shape[0] else np.zeros(0)
+    comp = np.where(np.isfinite(comp), comp, 0.0)
+    mx = lambda v: float(np.max(np.abs(v))) if np.size(v) else 0.0
+    return dict(stationarity=mx(r_stat), equality=mx(r_eq), bound_violation=mx(viol), complementarity=mx(comp))
+
+
+def solve_qp_exact(qp: JointQP, tol=1e-9, verbose=False):
+    """Unique optimum z* of the strictly convex joint QP + its KKT certificate."""
+    P, q, A, b, G, l, u = effective_P(qp.P), qp.q, qp.A, qp.b, qp.G, qp.l, qp.u
+    n, m_in = P.shape[0], G.shape[0]
+    if m_in == 0:
+        z, y, _ = _kkt_solve(P, A, sp.csc_matrix((0, n)), -q, b, np.zeros(0))
+        cert = kkt_certificate(P, q, A, b, G, l, u, z, y, np.zeros(0))
+        assert max(cert.values()) <= tol * max(1.0, float(np.max(np.abs(q)))), cert
+        return z, dict(cert=cert, admm=None, active_set_iters=0)
+
+    # 1) the reference's algorithm (ADMM) to a moderate tolerance -> active-set guess
+    Aa = sp.vstack([A, G], format="csc")  # augmented_A, osqp_solver.jl:20-32
+    la, ua = np.concatenate([b, l]), np.concatenate([b, u])
+    x_admm, y_admm, info = osqp_admm(P, q, Aa, la, ua, eps_abs=1e-6, eps_rel=1e-6, max_iter=20000)
+    mu = y_admm[A.shape[0]:]
+    Gz = G @ x_admm
+    scale = np.maximum(1.0, np.abs(Gz))
+    lower = (Gz - l < -mu) | (Gz < l + 1e-9 * scale)  # OSQP polish active-set rule
+    upper = (u - Gz < mu) | (Gz > u - 1e-9 * scale)
+    Gr = G.tocsr()
+
+    # 2) primal-dual active-set refinement on the sparse KKT system
+    z = y = None
+    mu_full = np.zeros(m_in)
+    seen = set()
+    for it in range(200):
+        both = lower & upper
+        W = np.flatnonzero(lower | upper)
+        v = np.where(upper[W] & ~lower[W], u[W], l[W])
+        z, y, muW = _kkt_solve(P, A, Gr[W].tocsc(), -q, b, v)
+        mu_full = np.zeros(m_in)
+        mu_full[W] = muW
+        Gz = G @ z
+        bad_lower = lower & ~both & (mu_full > 1e-12)   # lower-active needs mu <= 0
+        bad_upper = upper & ~both & (mu_full < -1e-12)  # upper-active needs mu >= 0
+        add_lower = ~lower & (Gz < l - 1e-11 * np.maximum(1.0, np.abs(l)))
+        add_upper = ~upper & (Gz > u + 1e-11 * np.maximum(1.0, np.abs(u)))
+        if not (bad_lower.any() or bad_upper.any() or add_lower.any() or add_upper.any()):
+            break
+        lower = (lower & ~bad_lower) | add_lower
+        upper = (upper & ~bad_upper) | add_upper
+        key = (lower.tobytes(), upper.tobytes())
+        if key in seen:  # cycling: restart the guess from a tighter ADMM run
+            x_admm, y_admm, info = osqp_admm(P, q, Aa, la, ua, eps_abs=1e-9, eps_rel=1e-9, max_iter=100000,
+                                             x0=x_admm, y0=y_admm)
+            mu = y_admm[A.shape[0]:]
+            Gz = G @ x_admm
+            lower, upper = (Gz - l < -mu), (u - Gz < mu)
+            seen.clear()
+        seen.add(key)
+    cert = kkt_certificate(P, q, A, b, G, l, u, z, y, mu_full)
+    if verbose:
+        print("oracle: admm", info, "active-set iters", it, cert)
+    assert max(cert.values()) <= tol * max(1.0, float(np.max(np.abs(q)))), cert
+    return z, dict(cert=cert, admm=info, active_set_iters=it)
+
+
+# -------------------------------------------------------------------------------------------------
+# entry points
+# -------------------------------------------------------------------------------------------------
+def lqp_solve_abi(xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
+                  reg_x, reg_u, slew_reg, slew_reg0, slew_um1, verbose=False, return_info=False):
+    """Same argument list as `c_lqp_solve` (PMPC.jl/src/c_interface.jl:77-141) minus the output
+    pointers; ABI-layout buffers in, X (M,N,x) / U (M,N,u) out (== the (x,N,M) / (u,N,M) the
+    reference copies into X_out / U_out, c_interface.jl:138-139).  x0 is accepted and ignored, as
+    in the reference (lqp_utils.jl:293-296)."""
+    qp = assemble_abi(xdim, udim, N, M, Nc, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
+                      reg_x, reg_u, slew_reg, slew_reg0, slew_um1)
+    z, info = solve_qp_exact(qp, verbose=verbose)
+    X, U = split_vars(qp, z)
+    return (X, U, info) if return_info else (X, U)
+
+
+def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, x_l=None, x_u=None,
+                 u_l=None, u_u=None, slew_reg=None, slew_reg0=None, slew_um1=None, return_info=False):
+    """py-layout convenience wrapper (batched: x0 (M,x), fx (M,N,x,x) ...)."""
+    f = _f64(f)
+    M, N, xdim = f.shape
+    udim = np.shape(fu)[-1]
+    nanx, nanu = np.full((M, N, xdim), np.nan), np.full((M, N, udim), np.nan)
+    bx = lambda z, d: d if z is None or np.size(z) == 0 else np.broadcast_to(_f64(z), d.shape).copy()
+    sr = np.full(M, np.nan) if slew_reg is None else np.broadcast_to(_f64(slew_reg), (M,)).copy()
+    sr0 = np.full(M, np.nan) if slew_reg0 is None else np.broadcast_to(_f64(slew_reg0), (M,)).copy()
+    um1 = np.full((M, udim), np.nan) if slew_um1 is None else np.broadcast_to(_f64(slew_um1), (M, udim)).copy()
+    return lqp_solve_abi(
+        xdim, udim, N, M, Nc, _f64(x0), f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev),
+        to_abi_mat(Q), to_abi_mat(R), _f64(X_ref), _f64(U_ref), bx(x_l, nanx), bx(x_u, nanx), bx(u_l, nanu),
+        bx(u_u, nanu), float(reg_x), float(reg_u), sr, sr0, um1, return_info=return_info)
+
+
+def aff_solve(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l,
+              u_u, solver_settings=None):
+    """Drop-in for `pmpc.scp_mpc.aff_solve` (pmpc/scp_mpc.py:78-167) / `static_backend.aff_solve`
+    (pmpc/static_backend.py:198-312) so that the REFERENCE's own SCP loop can run over the oracle
+    (QP path only).  Same sentinel rules as static_backend.py:257-272."""
+    solver_settings = dict(solver_settings or {})
+    f, fx, fu = np.asarray(f, float), np.asarray(fx, float), np.asarray(fu, float)
+    if f.ndim == 2:
+        f, fx, fu = f[None], fx[None], fu[None]
+    M, N, xdim = f.shape
+    udim = fu.shape[-1]
+    x0 = np.asarray(x0, float).reshape(M, xdim)
+    rs = lambda z, d: np.asarray(z, float).reshape((M, N) + d)
+    X_prev, X_ref, U_prev, U_ref = rs(X_prev, (xdim,)), rs(X_ref, (xdim,)), rs(U_prev, (udim,)), rs(U_ref, (udim,))
+    Q, R = rs(Q, (xdim, xdim)), rs(R, (udim, udim))
+    Nc = solver_settings.get("Nc", -1)
+    none_if_empty = lambda z: None if z is None or np.size(z) == 0 else z
+    X, U = lqp_solve_py(
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=reg_x, reg_u=reg_u, Nc=Nc,
+        x_l=none_if_empty(x_l), x_u=none_if_empty(x_u), u_l=none_if_empty(u_l), u_u=none_if_empty(u_u),
+        slew_reg=slew_rate,  # static_backend.py:262
+        slew_reg0=solver_settings.get("slew_reg", None),  # static_backend.py:263-267 (sic)
+        slew_um1=u_slew)
+    X_traj = np.concatenate([x0[:, None, :], X], -2)  # static_backend.py:311
+    return X_traj, U, dict()
+
+
+# -------------------------------------------------------------------------------------------------
+# CPU baseline leg (bench.py): the reference-shaped path, timed
+# -------------------------------------------------------------------------------------------------
+def reference_shaped_solve_abi(*abi_args, eps=1e-3):
+    """What the reference does per SCP iteration, on the CPU: single-threaded CSC assembly
+    (lqp_utils.jl) + a FRESH OSQP model (main.jl:145-150): KKT factorisation + ADMM to the OSQP
+    default tolerance.  Returns (X, U, timing dict)."""
+    t0 = time.perf_counter()
+    qp = assemble_abi(*abi_args)
+    P = effective_P(qp.P)
+    Aa = sp.vstack([qp.A, qp.G], format="csc")
+    la, ua = np.concatenate([qp.b, qp.l]), np.concatenate([qp.b, qp.u])
+    t1 = time.perf_counter()
+    z, _, info = osqp_admm(P, qp.q, Aa, la, ua, eps_abs=eps, eps_rel=eps)
+    t2 = time.perf_counter()
+    X, U = split_vars(qp, z)
+    return X, U, dict(assemble_s=t1 - t0, solve_s=t2 - t1, total_s=time.perf_counter() - t0, **info)
