@@ -1,0 +1,134 @@
+/*
+ * pmpc_abi.h — C ABI of libpmpc_hip.so, the MI355X-native replacement for the
+ * PMPC.jl back end of StanfordASL/pmpc.
+ *
+ * Part 1 is the DROP-IN boundary: the two symbols the reference's pybind11 module
+ * binds (PMPC.jl/pmpcjl/module.cpp:9-23) and the Julia library exports
+ * (PMPC.jl/src/c_interface.jl:77-141 `c_lqp_solve`, :146-214 `c_lcone_solve`),
+ * with the same argument order, layouts, sentinels and error behaviour.
+ *
+ * Part 2 is the device-resident extension (no reference counterpart): the same
+ * solve with every buffer already in HBM, a persistent workspace, an explicit HIP
+ * stream, particle sharding over RCCL and the on-device dynamics linearisation
+ * that replaces the user's f_fx_fu_fn callback (pmpc/scp_mpc.py:338-342) for the
+ * built-in models.
+ *
+ * Layouts (column-major, PMPC.jl/src/c_interface.jl:28-46):
+ *   x0 (xdim,M)   f, X_prev, X_ref, lx, ux (xdim,N,M)   U_prev, U_ref, lu, uu (udim,N,M)
+ *   fx, Q (xdim,xdim,N,M)   fu (xdim,udim,N,M)   R (udim,udim,N,M)
+ *   slew_reg (M)   slew_reg0 (M)   slew_um1 (udim,M)
+ *   X_out (xdim,N,M)  — steps 1..N, x0 is NOT included (c_interface.jl:138)
+ *   U_out (udim,N,M)
+ * i.e. particle-major, time-minor arrays of column-major blocks; equivalently the
+ * C-order numpy arrays (M,N,d) and (M,N,col,row).
+ *
+ * Sentinels (c_interface.jl:56-70): any NaN in lx|ux => no state bounds; any NaN in
+ * lu|uu => no control bounds; any NaN in slew_reg => 0; any NaN in slew_reg0 or
+ * slew_um1 => both ignored.  Nc < 0 => Nc = N (PMPC.jl/src/main.jl:127-128).
+ * +-inf entries of a bound array mean "unbounded on that side" (as for OSQP).
+ *
+ * Errors: void return; on failure X_out/U_out are filled with NaN
+ * (PMPC.jl/src/osqp_solver.jl:65-71) which the Python host turns into
+ * (None, None, None) (pmpc/scp_mpc.py:391-394).
+ *
+ * Threading: one caller thread at a time per process (as the reference, which holds
+ * the GIL for the whole call, module.cpp:28-72).  Blocking.
+ */
+#ifndef PMPC_ABI_H
+#define PMPC_ABI_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 1 — drop-in boundary (host pointers)
+ * ------------------------------------------------------------------------------------------- */
+
+/* replaces PMPC.jl/src/c_interface.jl:77-141 (prototype: PMPC.jl/pmpcjl/module.cpp:9-15) */
+void c_lqp_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
+                 double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
+                 double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
+                 double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                 long long verbose);
+
+/* replaces PMPC.jl/src/c_interface.jl:146-214 (prototype: module.cpp:17-23).
+ * smooth_alpha = NaN => hard constraints (PMPC.jl/src/main.jl:242-244).  `solver` is accepted
+ * for signature compatibility ("ecos" | "cosmo" | "mosek" | "gurobi"); see DESIGN.md for the
+ * documented deviation of this entry point from the reference's epsilon-anchored cone objective. */
+void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
+                   double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
+                   double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
+                   double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                   long long verbose, double smooth_alpha, char *solver);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 2 — device-resident extension
+ * ------------------------------------------------------------------------------------------- */
+
+/* flags for pmpc_problem.flags */
+#define PMPC_HAS_XBOUNDS 1u  /* lx/ux valid (no NaN sentinel) */
+#define PMPC_HAS_UBOUNDS 2u  /* lu/uu valid */
+#define PMPC_HAS_SLEW 4u     /* slew_reg valid (else treated as 0) */
+#define PMPC_HAS_SLEW0 8u    /* slew_reg0 and slew_um1 valid */
+#define PMPC_FORCE_GENERIC 16u /* debugging: never take the MFMA fast path */
+
+typedef struct pmpc_problem {
+  size_t xdim, udim, N, M; /* M = particles held by THIS rank */
+  long long Nc;
+  unsigned flags;
+  double reg_x, reg_u;
+  /* device pointers, ABI layouts above; unused ones may be NULL */
+  const double *x0, *f, *fx, *fu, *X_prev, *U_prev, *Q, *R, *X_ref, *U_ref;
+  const double *lx, *ux, *lu, *uu;
+  const double *slew_reg, *slew_reg0, *slew_um1;
+  double *X_out, *U_out; /* device, (xdim,N,M) / (udim,N,M) */
+} pmpc_problem;
+
+typedef struct pmpc_info {
+  int status;          /* 0 ok, 1 not converged (outputs NaN), 2 numerical failure (outputs NaN) */
+  int ipm_iters;       /* 0 = the equality-only optimum was feasible */
+  int structured_solves; /* Riccati factorisations performed */
+  int fast_path;       /* 1 = MFMA register-resident kernels were used */
+  double mu;           /* final complementarity */
+  double slack_res;    /* final slack residual (inf-norm) */
+  double max_violation;/* bound violation of the equality-only optimum */
+} pmpc_info;
+
+/* Opaque solver context: owns the HIP stream, the workspace cache keyed on
+ * (xdim,udim,N,M,Nc,flags) and the optional RCCL communicator. */
+typedef struct pmpc_ctx pmpc_ctx;
+
+int pmpc_create(pmpc_ctx **ctx, int device);          /* 0 on success */
+void pmpc_destroy(pmpc_ctx *ctx);
+void *pmpc_stream(pmpc_ctx *ctx);                     /* hipStream_t the solver launches on */
+void pmpc_sync(pmpc_ctx *ctx);                        /* hipStreamSynchronize(pmpc_stream) */
+
+/* Solve with all buffers in HBM.  Asynchronous on pmpc_stream() except for one small
+ * device->host read per IPM iteration.  Returns pmpc_info.status. */
+int pmpc_lqp_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, pmpc_info *info, int verbose);
+
+/* Particle sharding over RCCL (one process per GPU).  unique_id is the 128-byte ncclUniqueId
+ * produced by pmpc_comm_unique_id on rank 0 and distributed by the host (torch.distributed).
+ * With a communicator set, pmpc_lqp_solve_device treats `M` as the local shard and
+ * all-reduces the consensus Hessian/gradient and the IPM scalars. */
+int pmpc_comm_unique_id(void *unique_id_128);
+int pmpc_comm_init(pmpc_ctx *ctx, int rank, int world, const void *unique_id_128);
+int pmpc_comm_rank(pmpc_ctx *ctx);
+int pmpc_comm_world(pmpc_ctx *ctx);
+
+/* On-device dynamics linearisation (row a2 of SURVEY.md §8: the f_fx_fu_fn callback for the
+ * built-in models).  model: 0 = unicycle (reference tests/dubins_car.py:48-90, params (3,M)),
+ * 1 = synthetic quadrotor (params (4,M)).  X_prev/U_prev/x0 and outputs in ABI layout. */
+int pmpc_linearize_device(pmpc_ctx *ctx, int model, size_t N, size_t M, const double *x0, const double *X_prev,
+                          const double *U_prev, const double *params, double *f, double *fx, double *fu);
+
+/* version / build probe used by the loader and the tests */
+const char *pmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMPC_ABI_H */

@@ -1,0 +1,88 @@
+"""ctypes binding of libpmpc_hip.so (include/pmpc_abi.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C pmpc_amd/csrc`.  There is no
+CPU path: `load()` raises if the shared object is missing, and every solve raises if no HIP device
+is present (the product path must fail loudly rather than fall back)."""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libpmpc_hip.so"
+_lib = None
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+
+# flags of pmpc_problem.flags (include/pmpc_abi.h)
+HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC = 1, 2, 4, 8, 16
+
+ABI_SYMBOLS = [
+    "c_lqp_solve", "c_lcone_solve", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
+    "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
+    "pmpc_version",
+]
+
+
+class PmpcProblem(ctypes.Structure):
+    _fields_ = (
+        [(k, ctypes.c_size_t) for k in ("xdim", "udim", "N", "M")]
+        + [("Nc", ctypes.c_longlong), ("flags", ctypes.c_uint), ("reg_x", ctypes.c_double), ("reg_u", ctypes.c_double)]
+        + [(k, ctypes.c_void_p) for k in ("x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref",
+                                          "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out")]
+    )
+
+
+class PmpcInfo(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int), ("ipm_iters", ctypes.c_int), ("structured_solves", ctypes.c_int),
+                ("fast_path", ctypes.c_int), ("mu", ctypes.c_double), ("slack_res", ctypes.c_double),
+                ("max_violation", ctypes.c_double)]
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C pmpc_amd/csrc). pmpc_amd has no CPU fallback.")
+    lib = ctypes.CDLL(str(LIB_PATH), mode=ctypes.RTLD_GLOBAL)
+    sz, ll, dbl, vp = ctypes.c_size_t, ctypes.c_longlong, ctypes.c_double, ctypes.c_void_p
+    common = [c_dp, c_dp, sz, sz, sz, sz, ll] + [c_dp] * 14 + [dbl, dbl] + [c_dp] * 3 + [ll]
+    lib.c_lqp_solve.argtypes = common
+    lib.c_lqp_solve.restype = None
+    lib.c_lcone_solve.argtypes = common + [dbl, ctypes.c_char_p]
+    lib.c_lcone_solve.restype = None
+    lib.pmpc_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+    lib.pmpc_create.restype = ctypes.c_int
+    lib.pmpc_destroy.argtypes = [vp]
+    lib.pmpc_destroy.restype = None
+    lib.pmpc_stream.argtypes = [vp]
+    lib.pmpc_stream.restype = vp
+    lib.pmpc_sync.argtypes = [vp]
+    lib.pmpc_sync.restype = None
+    lib.pmpc_lqp_solve_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), ctypes.POINTER(PmpcInfo), ctypes.c_int]
+    lib.pmpc_lqp_solve_device.restype = ctypes.c_int
+    lib.pmpc_comm_unique_id.argtypes = [vp]
+    lib.pmpc_comm_unique_id.restype = ctypes.c_int
+    lib.pmpc_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.pmpc_comm_init.restype = ctypes.c_int
+    lib.pmpc_comm_rank.argtypes = [vp]
+    lib.pmpc_comm_rank.restype = ctypes.c_int
+    lib.pmpc_comm_world.argtypes = [vp]
+    lib.pmpc_comm_world.restype = ctypes.c_int
+    lib.pmpc_linearize_device.argtypes = [vp, ctypes.c_int, sz, sz] + [vp] * 7
+    lib.pmpc_linearize_device.restype = ctypes.c_int
+    lib.pmpc_version.argtypes = []
+    lib.pmpc_version.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_dp)

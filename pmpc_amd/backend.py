@@ -1,0 +1,148 @@
+"""Python side of the C ABI — the counterpart of the reference's pmpc/static_backend.py.
+
+Same function names, argument order, shape asserts, sentinel conventions and return layout:
+
+* `lqp_solve`  (pmpc/static_backend.py:24-104)   -> `c_lqp_solve`
+* `lcone_solve`(pmpc/static_backend.py:107-191)  -> `c_lcone_solve`
+* `aff_solve`  (pmpc/static_backend.py:198-312)  -> marshal one SCP sub-problem, prepend x0
+
+Arrays handed to `lqp_solve` / `lcone_solve` use the "Julia" shapes of the reference
+(x0 (xdim,M), f (xdim,N,M), fx (xdim,xdim,N,M) ...; pmpc/julia_utils.py:69-77 `py2jl`); they are
+made Fortran-contiguous, which yields exactly the column-major buffers the ABI expects
+(PMPC.jl/src/c_interface.jl:28-46).  The compute happens in libpmpc_hip.so on the GPU; there
+is no CPU path here.
+"""
+from __future__ import annotations
+
+import math
+from copy import copy
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .utils import atleast_nd, to_numpy_f64
+
+
+def is_precompiled_backend_available() -> bool:
+    """pmpc/static_backend.py:14-21 — here: does libpmpc_hip.so load."""
+    try:
+        _lib.load()
+        return True
+    except (ImportError, OSError):
+        return False
+
+
+# ---- layout conversion (pmpc/julia_utils.py:69-88) ---------------------------------------------------
+def py2jl(x, keep: int = 1):
+    n = x.ndim
+    return np.transpose(x, tuple(range(n - keep, n)) + tuple(range(n - keep - 1, -1, -1)))
+
+
+def jl2py(x, keep: int = 1):
+    n = x.ndim
+    return np.transpose(x, tuple(range(n - 1, keep - 1, -1)) + tuple(range(0, keep)))
+
+
+def _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1):
+    assert x0.ndim == 2
+    xdim, M = x0.shape
+    assert f.ndim == 3
+    N = f.shape[1]
+    assert fu.ndim == 4
+    udim = fu.shape[1]
+    assert f.shape == (xdim, N, M), f.shape
+    assert fx.shape == (xdim, xdim, N, M), fx.shape
+    assert fu.shape == (xdim, udim, N, M), fu.shape
+    assert X_prev.shape == (xdim, N, M) and U_prev.shape == (udim, N, M)
+    assert Q.shape == (xdim, xdim, N, M) and R.shape == (udim, udim, N, M)
+    assert X_ref.shape == (xdim, N, M) and U_ref.shape == (udim, N, M)
+    assert lx.shape == (xdim, N, M), lx.shape
+    assert ux.shape == (xdim, N, M), ux.shape
+    assert lu.shape == (udim, N, M), lu.shape
+    assert uu.shape == (udim, N, M), uu.shape
+    assert slew_um1.shape == (udim, M)
+    assert slew_reg.shape == (M,)
+    assert slew_reg0.shape == (M,), slew_reg0.shape
+    return xdim, udim, N, M
+
+
+def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
+          slew_um1, verbose, extra=()):
+    lib = _lib.load()
+    xdim, udim, N, M = _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg,
+                                     slew_reg0, slew_um1)
+    arrs = [np.asfortranarray(np.asarray(z, dtype=np.float64))
+            for z in (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1)]
+    X_out, U_out = np.empty(xdim * N * M), np.empty(udim * N * M)
+    ptr = lambda a: a.ctypes.data_as(_lib.c_dp)
+    getattr(lib, entry)(ptr(X_out), ptr(U_out), xdim, udim, N, M, int(Nc), *[ptr(a) for a in arrs[:14]], float(reg_x),
+                        float(reg_u), *[ptr(a) for a in arrs[14:]], int(verbose), *extra)
+    # pmpc/static_backend.py:103
+    return np.reshape(X_out, (M, N, xdim)), np.reshape(U_out, (M, N, udim))
+
+
+def lqp_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
+              slew_um1, verbose=False):
+    """pmpc/static_backend.py:24-104."""
+    return _call("c_lqp_solve", Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
+                 slew_reg, slew_reg0, slew_um1, verbose)
+
+
+def lcone_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
+                slew_um1, smooth_alpha=1e1, verbose=False, solver="ecos"):
+    """pmpc/static_backend.py:107-191."""
+    extra = (float(smooth_alpha), str(solver).encode())
+    return _call("c_lcone_solve", Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
+                 slew_reg, slew_reg0, slew_um1, verbose, extra)
+
+
+def aff_solve(
+    f: np.ndarray, fx: np.ndarray, fu: np.ndarray, x0: np.ndarray, X_prev: np.ndarray, U_prev: np.ndarray,
+    Q: np.ndarray, R: np.ndarray, X_ref: np.ndarray, U_ref: np.ndarray, reg_x: float, reg_u: float,
+    slew_rate: Optional[float], u_slew: Optional[np.ndarray], x_l: np.ndarray, x_u: np.ndarray, u_l: np.ndarray,
+    u_u: np.ndarray, solver_settings: Optional[Dict[str, Any]] = None,
+) -> Tuple[np.ndarray, np.ndarray, Any]:
+    """Solve a single instance of a linearized MPC problem (pmpc/static_backend.py:198-312)."""
+    solver_settings = copy(solver_settings) if solver_settings is not None else dict()
+    f = atleast_nd(to_numpy_f64(f), 3)
+    fx, fu = atleast_nd(to_numpy_f64(fx), 4), atleast_nd(to_numpy_f64(fu), 4)
+    x0 = atleast_nd(to_numpy_f64(x0), 2)
+    X_prev, U_prev = atleast_nd(to_numpy_f64(X_prev), 3), atleast_nd(to_numpy_f64(U_prev), 3)
+    Q, R = atleast_nd(to_numpy_f64(Q), 4), atleast_nd(to_numpy_f64(R), 4)
+    X_ref, U_ref = atleast_nd(to_numpy_f64(X_ref), 3), atleast_nd(to_numpy_f64(U_ref), 3)
+    x_l, x_u, u_l, u_u = [None if z is None else atleast_nd(to_numpy_f64(z), 3) for z in (x_l, x_u, u_l, u_u)]
+
+    x_l, x_u, u_l, u_u = [None if z is None else py2jl(z, 1) for z in (x_l, x_u, u_l, u_u)]
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = [
+        py2jl(z, d) for z, d in zip((x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref), (1, 1, 2, 2, 1, 1, 2, 2, 1, 1))]
+
+    solver_settings.setdefault("solver", "ecos")
+    solver = solver_settings["solver"].lower()
+    assert solver in ("ecos", "gurobi", "mosek", "cosmo", "osqp")
+    if solver in ("ecos", "gurobi", "mosek", "cosmo") or "smooth_cstr" in solver_settings or "smooth_alpha" in solver_settings:
+        method, smooth_alpha = "cone", solver_settings.get("smooth_alpha", math.nan)  # static_backend.py:244-250
+    else:
+        method, smooth_alpha = "qp", None
+
+    Nc = -1 if "Nc" not in solver_settings else solver_settings["Nc"]
+    nan_like = lambda z: np.nan * np.zeros_like(z)
+    x_l = nan_like(X_prev) if x_l is None or x_l.size == 0 else x_l
+    x_u = nan_like(X_prev) if x_u is None or x_u.size == 0 else x_u
+    u_l = nan_like(U_prev) if u_l is None or u_l.size == 0 else u_l
+    u_u = nan_like(U_prev) if u_u is None or u_u.size == 0 else u_u
+    M = x0.shape[-1]
+    slew_reg = (math.nan if slew_rate is None else slew_rate) * np.ones(M)
+    # the reference feeds solver_settings["slew_reg"] into slew_reg0 (static_backend.py:263-267)
+    slew_reg0 = np.nan * np.zeros(M) if "slew_reg" not in solver_settings else solver_settings["slew_reg"] * np.ones(M)
+    slew_um1 = nan_like(U_prev[:, 0, :]) if u_slew is None else py2jl(atleast_nd(to_numpy_f64(u_slew), 2), 1)
+
+    args = (Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, x_l, x_u, u_l, u_u, reg_x, reg_u, slew_reg, slew_reg0,
+            slew_um1)
+    verbose = solver_settings.get("verbose", False)
+    if method == "qp":
+        X, U = lqp_solve(*args, verbose=verbose)
+    else:
+        X, U = lcone_solve(*args, smooth_alpha, verbose=verbose, solver=solver_settings["solver"])
+    X_traj = np.concatenate([np.swapaxes(x0, -1, -2)[:, None, :], X], -2)  # static_backend.py:311
+    return X_traj, U, dict()

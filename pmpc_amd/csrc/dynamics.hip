@@ -1,0 +1,118 @@
+// dynamics.hip — on-device linearisation: the f_fx_fu_fn step of the SCP loop
+// (pmpc/scp_mpc.py:338-342) for the built-in models, writing f, fx, fu straight into the ABI
+// layout the Riccati kernels stream (no host round trip of the (M,N,x,x) Jacobian stacks).
+//
+//   X_ = [x0, X_prev[:-1]]  (scp_mpc.py:338);  f[j] = F(X_[j], U_prev[j]), fx[j] = dF/dx, fu[j] = dF/du
+//
+// model 0: unicycle of the reference's tests/dubins_car.py:48-90 (closed-form Jacobians; the
+//          reference uses torch.autograd, :11-30).  params (3,M) = [v_scale, w_scale, T].
+// model 1: synthetic quadrotor of SURVEY.md §8(d) (not in the reference). params (4,M) = [m,Jx,Jy,Jz].
+// Host (numpy) specifications: pmpc_amd/dynamics.py.  One thread per (particle, stage); stores are
+// 8-byte scattered within the thread's own 1152-byte block (HBM write-combining in L2).
+#include "pmpc_dev.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_lin_unicycle(int N, int M, const double *x0, const double *X_prev,
+                                                      const double *U_prev, const double *params, double *f, double *fx,
+                                                      double *fu) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int i = (int)(idx / N), j = (int)(idx % N);
+  const double *xs = j == 0 ? x0 + 4 * (size_t)i : X_prev + (idx - 1) * 4;
+  const double *us = U_prev + idx * 2, *p = params + 3 * (size_t)i;
+  const double vs = p[0], ws = p[1], T = p[2], eps = 1e-6;
+  double u1 = vs * us[0], u2 = -ws * us[1];
+  u1 += (u1 >= 0.0 ? eps : -eps);
+  u2 += (u2 >= 0.0 ? eps : -eps);
+  const double px = xs[0], py = xs[1], v0 = xs[2], th0 = xs[3];
+  const double a = T * u2 + th0;
+  double sa, ca, s0, c0;
+  sincos(a, &sa, &ca);
+  sincos(th0, &s0, &c0);
+  const double iu2 = 1.0 / u2, iu22 = iu2 * iu2;
+  const double n1 = u2 * sa * v0 + T * u1 * u2 * sa + u1 * ca - s0 * u2 * v0 - c0 * u1;
+  const double n2 = -(u2 * ca * v0 - u1 * sa + T * u1 * u2 * ca) + c0 * u2 * v0 - s0 * u1;
+  double *fo = f + idx * 4, *A = fx + idx * 16, *B = fu + idx * 8;
+  fo[0] = px + n1 * iu22; fo[1] = py + n2 * iu22; fo[2] = v0 + T * u1; fo[3] = a;
+  for (int k = 0; k < 16; k++) A[k] = 0.0;
+  for (int k = 0; k < 8; k++) B[k] = 0.0;
+  // column-major blocks: A[r + 4*t] = dF_r/dx_t
+  A[0 + 4 * 0] = 1.0; A[1 + 4 * 1] = 1.0; A[2 + 4 * 2] = 1.0; A[3 + 4 * 3] = 1.0;
+  A[0 + 4 * 2] = (u2 * sa - s0 * u2) * iu22;
+  A[0 + 4 * 3] = (u2 * ca * v0 + T * u1 * u2 * ca - u1 * sa - c0 * u2 * v0 + s0 * u1) * iu22;
+  A[1 + 4 * 2] = (-u2 * ca + c0 * u2) * iu22;
+  A[1 + 4 * 3] = (-(-u2 * sa * v0 - u1 * ca - T * u1 * u2 * sa) - s0 * u2 * v0 - c0 * u1) * iu22;
+  const double dn1_du1 = T * u2 * sa + ca - c0, dn2_du1 = sa - T * u2 * ca - s0;
+  const double dn1_du2 = sa * v0 + u2 * ca * T * v0 + T * u1 * sa + T * u1 * u2 * ca * T - u1 * sa * T - s0 * v0;
+  const double dn2_du2 = -(ca * v0 - u2 * sa * T * v0 - u1 * ca * T + T * u1 * ca - T * T * u1 * u2 * sa) + c0 * v0;
+  B[0 + 4 * 0] = dn1_du1 * iu22 * vs;
+  B[1 + 4 * 0] = dn2_du1 * iu22 * vs;
+  B[2 + 4 * 0] = T * vs;
+  B[0 + 4 * 1] = (dn1_du2 * iu22 - 2.0 * n1 * iu22 * iu2) * (-ws);
+  B[1 + 4 * 1] = (dn2_du2 * iu22 - 2.0 * n2 * iu22 * iu2) * (-ws);
+  B[3 + 4 * 1] = T * (-ws);
+}
+
+__global__ void __launch_bounds__(256) k_lin_quadrotor(int N, int M, const double *x0, const double *X_prev,
+                                                       const double *U_prev, const double *params, double *f, double *fx,
+                                                       double *fu) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int i = (int)(idx / N), j = (int)(idx % N);
+  const double *xs = j == 0 ? x0 + 12 * (size_t)i : X_prev + (idx - 1) * 12;
+  const double *us = U_prev + idx * 4, *p = params + 4 * (size_t)i;
+  const double m = p[0], Jx = p[1], Jy = p[2], Jz = p[3], dt = 0.05, g = 9.81;
+  const double ph = xs[6], th = xs[7], ps = xs[8], wx = xs[9], wy = xs[10], wz = xs[11];
+  const double T = us[0], tx = us[1], ty = us[2], tz = us[3];
+  double sph, cph, sth, cth, sps, cps;
+  sincos(ph, &sph, &cph);
+  sincos(th, &sth, &cth);
+  sincos(ps, &sps, &cps);
+  const double icth = 1.0 / cth, tth = sth * icth, sec2 = icth * icth;
+  const double bx = cps * sth * cph + sps * sph, by = sps * sth * cph - cps * sph, bz = cth * cph;
+  const double a = T / m;
+  double *fo = f + idx * 12, *A = fx + idx * 144, *B = fu + idx * 48;
+  fo[0] = xs[0] + dt * xs[3]; fo[1] = xs[1] + dt * xs[4]; fo[2] = xs[2] + dt * xs[5];
+  fo[3] = xs[3] + dt * a * bx; fo[4] = xs[4] + dt * a * by; fo[5] = xs[5] + dt * (a * bz - g);
+  fo[6] = ph + dt * (wx + sph * tth * wy + cph * tth * wz);
+  fo[7] = th + dt * (cph * wy - sph * wz);
+  fo[8] = ps + dt * (sph * icth * wy + cph * icth * wz);
+  fo[9] = wx + dt * (tx - (Jz - Jy) * wy * wz) / Jx;
+  fo[10] = wy + dt * (ty - (Jx - Jz) * wz * wx) / Jy;
+  fo[11] = wz + dt * (tz - (Jy - Jx) * wx * wy) / Jz;
+  for (int k = 0; k < 144; k++) A[k] = 0.0;
+  for (int k = 0; k < 48; k++) B[k] = 0.0;
+#define AE(r, t) A[(r) + 12 * (t)]
+#define BE(r, t) B[(r) + 12 * (t)]
+  for (int k = 0; k < 12; k++) AE(k, k) = 1.0;
+  for (int k = 0; k < 3; k++) AE(k, 3 + k) = dt;
+  AE(3, 6) = dt * a * (-cps * sth * sph + sps * cph); AE(3, 7) = dt * a * (cps * cth * cph); AE(3, 8) = dt * a * (-sps * sth * cph + cps * sph);
+  AE(4, 6) = dt * a * (-sps * sth * sph - cps * cph); AE(4, 7) = dt * a * (sps * cth * cph); AE(4, 8) = dt * a * (cps * sth * cph + sps * sph);
+  AE(5, 6) = dt * a * (-cth * sph); AE(5, 7) = dt * a * (-sth * cph);
+  AE(6, 6) += dt * (cph * tth * wy - sph * tth * wz);
+  AE(6, 7) = dt * (sph * sec2 * wy + cph * sec2 * wz);
+  AE(6, 9) = dt; AE(6, 10) = dt * sph * tth; AE(6, 11) = dt * cph * tth;
+  AE(7, 6) = dt * (-sph * wy - cph * wz);
+  AE(7, 10) = dt * cph; AE(7, 11) = -dt * sph;
+  AE(8, 6) = dt * (cph * icth * wy - sph * icth * wz);
+  AE(8, 7) = dt * (sph * wy + cph * wz) * sth * sec2;
+  AE(8, 10) = dt * sph * icth; AE(8, 11) = dt * cph * icth;
+  AE(9, 10) = -dt * (Jz - Jy) * wz / Jx; AE(9, 11) = -dt * (Jz - Jy) * wy / Jx;
+  AE(10, 9) = -dt * (Jx - Jz) * wz / Jy; AE(10, 11) = -dt * (Jx - Jz) * wx / Jy;
+  AE(11, 9) = -dt * (Jy - Jx) * wy / Jz; AE(11, 10) = -dt * (Jy - Jx) * wx / Jz;
+  BE(3, 0) = dt * bx / m; BE(4, 0) = dt * by / m; BE(5, 0) = dt * bz / m;
+  BE(9, 1) = dt / Jx; BE(10, 2) = dt / Jy; BE(11, 3) = dt / Jz;
+#undef AE
+#undef BE
+}
+
+}  // namespace
+
+void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
+                      const double *params, double *f, double *fx, double *fu, hipStream_t s) {
+  const long long tot = (long long)M * N;
+  dim3 grid((unsigned)((tot + 255) / 256));
+  if (model == 0) hipLaunchKernelGGL(k_lin_unicycle, grid, dim3(256), 0, s, N, M, x0, X_prev, U_prev, params, f, fx, fu);
+  else hipLaunchKernelGGL(k_lin_quadrotor, grid, dim3(256), 0, s, N, M, x0, X_prev, U_prev, params, f, fx, fu);
+}

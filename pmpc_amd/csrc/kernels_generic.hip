@@ -1,0 +1,501 @@
+// kernels_generic.hip — structured LQ solve for ARBITRARY (xdim, udim, N, Nc, slew) on gfx950.
+//
+// This is the always-available device path: one 64-lane wavefront per particle, stage matrices
+// staged in LDS, lanes striding over output entries.  It handles what the register-resident
+// MFMA path (kernels_fast.hip) does not: slew penalties (stage state augmented with the previous
+// control, n = xdim + udim), any consensus horizon Nc (forward-sensitivity condensing) and any
+// dimensions.  The problem it solves is the Newton system of the joint QP the reference assembles
+// in PMPC.jl/src/lqp_utils.jl:2-393:
+//
+//     min 1/2 dz'(P + D)dz + (g + w)'dz   s.t.  A dz = 0
+//
+// P: block-diagonal Q_j + reg_x I (:130-141), R_j + reg_u I + slew tridiagonal (:17-102);
+// A: the linearised dynamics chain (:219-303); consensus controls (first Nc stages) are shared
+// decision variables (:17-61, :231-244) -> per-particle condensed (H_i, g_i) summed over particles.
+#include "pmpc_dev.h"
+
+namespace {
+
+constexpr int WV = 64;
+
+__device__ __forceinline__ size_t vofs(int i, int j, int N, int d) { return ((size_t)i * N + j) * (size_t)d; }
+__device__ __forceinline__ size_t mofs(int i, int j, int N, int r, int c) {
+  return ((size_t)i * N + j) * (size_t)r * (size_t)c;
+}
+// slew diagonal of control stage j: PMPC.jl/src/lqp_utils.jl:31-39 / :81-88
+__device__ __forceinline__ double slew_diag(double s0, double s, int j, int N) {
+  return j == 0 ? s0 + s : (j == N - 1 ? s : 2.0 * s);
+}
+// OSQP.jl keeps triu(P): effective symmetric entry of a column-major d x d block
+__device__ __forceinline__ double symu(const double *B, int d, int r, int t) {
+  return r <= t ? B[r + d * t] : B[t + d * r];
+}
+
+struct LdsMap {
+  double *S, *F, *G, *H, *Lc, *Kt, *Hi, *sv, *hv, *tv, *Qr, *Rr, *gxs;
+};
+__host__ __device__ inline size_t lds_doubles(int x, int u, int n) {
+  int nt = n + u;
+  return (size_t)n * n + 2 * (size_t)n * nt + (size_t)nt * nt + 2 * (size_t)u * u + (size_t)u * n + n + 2 * nt +
+         (size_t)x * x + (size_t)u * u + x;
+}
+__device__ inline LdsMap lds_map(double *p, int x, int u, int n) {
+  int nt = n + u;
+  LdsMap m;
+  m.S = p;  p += n * n;
+  m.F = p;  p += n * nt;
+  m.G = p;  p += n * nt;
+  m.H = p;  p += nt * nt;
+  m.Lc = p; p += u * u;
+  m.Kt = p; p += u * n;
+  m.Hi = p; p += u * u;
+  m.sv = p; p += n;
+  m.hv = p; p += nt;
+  m.tv = p; p += nt;
+  m.Qr = p; p += x * x;
+  m.Rr = p; p += u * u;
+  m.gxs = p;
+  return m;
+}
+
+// F = [A~ | B~]  (n x (n+u), column-major): A~ = [fx 0; 0 0] (zero at stage 0), B~ = [fu; I_w]
+__device__ inline void build_F(const LQArgs &a, int i, int j, double *F, int lane) {
+  const int x = a.x, u = a.u, n = a.n, nt = a.n + a.u;
+  const double *fx = a.fx + mofs(i, j, a.N, x, x);
+  const double *fu = a.fu + mofs(i, j, a.N, x, u);
+  for (int e = lane; e < n * nt; e += WV) {
+    int r = e % n, c = e / n;
+    double v = 0.0;
+    if (c < x) {
+      if (r < x && j > 0) v = fx[r + x * c];
+    } else if (c >= n) {
+      int t = c - n;
+      if (r < x) v = fu[r + x * t];
+      else v = (r - x == t) ? 1.0 : 0.0;
+    }
+    F[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward sweep: FACTOR = matrix Riccati + condensing + smooth gradient; always the vector sweep
+// ------------------------------------------------------------------------------------------------
+template <bool FACTOR>
+__global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
+  extern __shared__ double lds[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int x = a.x, u = a.u, n = a.n, w = a.w, N = a.N, Nc = a.Nc, nt = n + u, nc = Nc * u;
+  LdsMap L = lds_map(lds, x, u, n);
+  const double sl = a.slew[i], sl0 = a.slew0[i];
+
+  // gxs <- effective state gradient of stage jj (smooth part computed here when FACTOR)
+  auto state_grad = [&](int jj) {
+    if (FACTOR) {
+      const double *Qg = a.Q + mofs(i, jj, N, x, x);
+      for (int e = lane; e < x * x; e += WV) L.Qr[e] = Qg[e];
+      __syncthreads();
+      if (lane < x) {
+        const double *X = a.X + vofs(i, jj, N, x), *Xp = a.X_prev + vofs(i, jj, N, x), *Xr = a.X_ref + vofs(i, jj, N, x);
+        double g = a.reg_x * (X[lane] - Xp[lane]);
+        for (int t = 0; t < x; t++) g += symu(L.Qr, x, lane, t) * X[t] - L.Qr[lane + x * t] * Xr[t];
+        a.gx[vofs(i, jj, N, x) + lane] = g;
+        L.gxs[lane] = g + (a.wx ? a.wx[vofs(i, jj, N, x) + lane] : 0.0);
+      }
+    } else if (lane < x) {
+      L.gxs[lane] = a.gx[vofs(i, jj, N, x) + lane] + (a.wx ? a.wx[vofs(i, jj, N, x) + lane] : 0.0);
+    }
+    __syncthreads();
+  };
+  // tv[0..u) <- smooth control gradient of stage j (Rr holds raw R_j afterwards when FACTOR)
+  auto ctrl_grad = [&](int j) {
+    if (FACTOR) {
+      const double *Rg = a.R + mofs(i, j, N, u, u);
+      for (int e = lane; e < u * u; e += WV) L.Rr[e] = Rg[e];
+      __syncthreads();
+      if (lane < u) {
+        const double *U = a.U + vofs(i, j, N, u), *Up = a.U_prev + vofs(i, j, N, u), *Ur = a.U_ref + vofs(i, j, N, u);
+        double g = a.reg_u * (U[lane] - Up[lane]) + slew_diag(sl0, sl, j, N) * U[lane];
+        for (int t = 0; t < u; t++) g += symu(L.Rr, u, lane, t) * U[t] - L.Rr[lane + u * t] * Ur[t];
+        if (j > 0) g -= sl * a.U[vofs(i, j - 1, N, u) + lane];
+        if (j + 1 < N) g -= sl * a.U[vofs(i, j + 1, N, u) + lane];
+        a.gu[vofs(i, j, N, u) + lane] = g;
+        L.tv[lane] = g;
+      }
+    } else if (lane < u) {
+      L.tv[lane] = a.gu[vofs(i, j, N, u) + lane];
+    }
+    __syncthreads();
+  };
+
+  // ---- terminal condition: S = blkdiag(Qd_{N-1}, 0), s = [g_x,N-1 ; 0] ---------------------------
+  state_grad(N - 1);
+  if (FACTOR) {
+    for (int e = lane; e < n * n; e += WV) {
+      int r = e % n, c = e / n;
+      double v = 0.0;
+      if (r < x && c < x) {
+        v = symu(L.Qr, x, r, c);
+        if (r == c) v += a.reg_x + (a.Dx ? a.Dx[vofs(i, N - 1, N, x) + r] : 0.0);
+      }
+      L.S[e] = v;
+    }
+  }
+  for (int e = lane; e < n; e += WV) L.sv[e] = e < x ? L.gxs[e] : 0.0;
+  __syncthreads();
+
+  // ---- free stages -------------------------------------------------------------------------------
+  for (int j = N - 1; j >= Nc; j--) {
+    build_F(a, i, j, L.F, lane);
+    ctrl_grad(j);  // tv[0..u) = smooth g_u,j ; Rr = raw R_j (FACTOR)
+    if (FACTOR) {
+      // G = S F
+      for (int e = lane; e < n * nt; e += WV) {
+        int r = e % n, c = e / n;
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) acc += L.S[r + n * k] * L.F[k + n * c];
+        L.G[e] = acc;
+      }
+      __syncthreads();
+      // H = F' G + cost blocks
+      for (int e = lane; e < nt * nt; e += WV) {
+        int r = e % nt, c = e / nt;
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) acc += L.F[k + n * r] * L.G[k + n * c];
+        if (r >= n && c >= n) {
+          int rr = r - n, cc = c - n;
+          acc += symu(L.Rr, u, rr, cc);
+          if (rr == cc) acc += a.reg_u + slew_diag(sl0, sl, j, N) + (a.Du ? a.Du[vofs(i, j, N, u) + rr] : 0.0);
+        }
+        if (w && j > 0) {  // slew cross term -s u_j' u_{j-1}
+          if (r >= n && c >= x && c < n && r - n == c - x) acc -= sl;
+          if (c >= n && r >= x && r < n && c - n == r - x) acc -= sl;
+        }
+        L.H[e] = acc;
+      }
+      __syncthreads();
+      // Cholesky of Huu (lane 0), then K = Huu^-1 Hux and Huu^-1 by substitution (one column per lane)
+      for (int e = lane; e < u * u; e += WV) L.Lc[e] = L.H[(n + e % u) + nt * (n + e / u)];
+      __syncthreads();
+      if (lane == 0) {
+        for (int c = 0; c < u; c++) {
+          double d = L.Lc[c + u * c];
+          for (int k = 0; k < c; k++) d -= L.Lc[c + u * k] * L.Lc[c + u * k];
+          if (!(d > 0.0)) { *a.fail = 2; d = 1.0; }
+          d = sqrt(d);
+          L.Lc[c + u * c] = d;
+          for (int r = c + 1; r < u; r++) {
+            double v = L.Lc[r + u * c];
+            for (int k = 0; k < c; k++) v -= L.Lc[r + u * k] * L.Lc[c + u * k];
+            L.Lc[r + u * c] = v / d;
+          }
+        }
+      }
+      __syncthreads();
+      for (int c = lane; c < n + u; c += WV) {
+        double *col = c < n ? L.Kt + u * c : L.Hi + u * (c - n);
+        for (int r = 0; r < u; r++) col[r] = c < n ? L.H[(n + r) + nt * c] : (r == c - n ? 1.0 : 0.0);
+        for (int r = 0; r < u; r++) {  // L y = b
+          double v = col[r];
+          for (int k = 0; k < r; k++) v -= L.Lc[r + u * k] * col[k];
+          col[r] = v / L.Lc[r + u * r];
+        }
+        for (int r = u - 1; r >= 0; r--) {  // L' k = y
+          double v = col[r];
+          for (int k = r + 1; k < u; k++) v -= L.Lc[k + u * r] * col[k];
+          col[r] = v / L.Lc[r + u * r];
+        }
+      }
+      __syncthreads();
+      double *Kg = a.K + mofs(i, j, N, u, n), *Hg = a.Hinv + mofs(i, j, N, u, u);
+      for (int e = lane; e < u * n; e += WV) Kg[e] = L.Kt[e];
+      for (int e = lane; e < u * u; e += WV) Hg[e] = L.Hi[e];
+      // S_new = Hxx - Hux' K  (into G), then symmetrise into S
+      for (int e = lane; e < n * n; e += WV) {
+        int r = e % n, c = e / n;
+        double acc = L.H[r + nt * c];
+        for (int k = 0; k < u; k++) acc -= L.H[(n + k) + nt * r] * L.Kt[k + u * c];
+        L.G[e] = acc;
+      }
+      __syncthreads();
+      for (int e = lane; e < n * n; e += WV) {
+        int r = e % n, c = e / n;
+        L.S[e] = 0.5 * (L.G[r + n * c] + L.G[c + n * r]);
+      }
+      __syncthreads();
+    } else {
+      const double *Kg = a.K + mofs(i, j, N, u, n), *Hg = a.Hinv + mofs(i, j, N, u, u);
+      for (int e = lane; e < u * n; e += WV) L.Kt[e] = Kg[e];
+      for (int e = lane; e < u * u; e += WV) L.Hi[e] = Hg[e];
+      __syncthreads();
+    }
+    // ---- vector sweep: h = F's ; hu = h_u + g_u ; k = Huu^-1 hu ; s = h_x - K'hu (+ g_x,j-1) ----
+    for (int c = lane; c < nt; c += WV) {
+      double acc = 0.0;
+      for (int r = 0; r < n; r++) acc += L.F[r + n * c] * L.sv[r];
+      if (c >= n) acc += L.tv[c - n] + (a.wu ? a.wu[vofs(i, j, N, u) + (c - n)] : 0.0);
+      L.hv[c] = acc;
+    }
+    __syncthreads();
+    if (lane < u) {
+      double acc = 0.0;
+      for (int t = 0; t < u; t++) acc += L.Hi[lane + u * t] * L.hv[n + t];
+      a.kff[vofs(i, j, N, u) + lane] = acc;
+    }
+    if (j > 0) state_grad(j - 1); else __syncthreads();  // gxs / Qr <- stage j-1
+    for (int c = lane; c < n; c += WV) {
+      double acc = L.hv[c];
+      for (int r = 0; r < u; r++) acc -= L.Kt[r + u * c] * L.hv[n + r];
+      if (j > 0 && c < x) acc += L.gxs[c];
+      L.sv[c] = acc;
+    }
+    if (FACTOR && j > 0) {
+      for (int e = lane; e < x * x; e += WV) {
+        int r = e % x, c = e / x;
+        double v = symu(L.Qr, x, r, c);
+        if (r == c) v += a.reg_x + (a.Dx ? a.Dx[vofs(i, j - 1, N, x) + r] : 0.0);
+        L.S[r + n * c] += v;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- consensus stages: adjoint sweep (no minimisation), per-particle condensed gradient --------
+  for (int j = Nc - 1; j >= 0; j--) {
+    build_F(a, i, j, L.F, lane);
+    ctrl_grad(j);
+    for (int c = lane; c < nt; c += WV) {
+      double acc = 0.0;
+      for (int r = 0; r < n; r++) acc += L.F[r + n * c] * L.sv[r];
+      L.hv[c] = acc;
+    }
+    __syncthreads();
+    if (lane < u) {
+      double g = L.hv[n + lane] + L.tv[lane];
+      if (i == 0 && a.owner && a.wu) g += a.wu[vofs(0, j, N, u) + lane];
+      if (j == 0) g -= sl0 * a.um1[(size_t)i * u + lane];  // lqp_utils.jl:165 (kept only when Nc >= 1)
+      a.gc_part[(size_t)i * nc + j * u + lane] = g;
+    }
+    if (j > 0) state_grad(j - 1); else __syncthreads();
+    for (int c = lane; c < n; c += WV) {
+      double acc = L.hv[c];
+      if (j > 0 && c < x) acc += L.gxs[c];
+      L.sv[c] = acc;
+    }
+    __syncthreads();
+  }
+
+  // ---- condensed consensus Hessian H_i = sum_j Phi_j' M_j Phi_j + blkdiag(Rt_j) - slew coupling --
+  if (FACTOR && Nc > 0) {
+    double *Pa = a.scratch + (size_t)i * 3 * n * nc, *Pb = Pa + (size_t)n * nc, *T = Pb + (size_t)n * nc;
+    double *Hc = a.Hc_part + (size_t)i * nc * nc;
+    for (int e = lane; e < nc * nc; e += WV) Hc[e] = 0.0;
+    for (int e = lane; e < n * nc; e += WV) Pa[e] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < Nc; j++) {
+      const double *fx = a.fx + mofs(i, j, N, x, x), *fu = a.fu + mofs(i, j, N, x, u);
+      // Phi_j = A~_j Phi_{j-1} + B~_j E_j
+      for (int e = lane; e < n * nc; e += WV) {
+        int r = e % n, c = e / n;
+        bool mine = (c / u) == j;
+        double v = 0.0;
+        if (r < x) {
+          if (j > 0) for (int k = 0; k < x; k++) v += fx[r + x * k] * Pa[k + n * c];
+          if (mine) v += fu[r + x * (c - j * u)];
+        } else if (mine && (r - x) == (c - j * u)) v = 1.0;
+        Pb[e] = v;
+      }
+      // M_j: S (stage Nc-1) or blkdiag(Qd_j, 0)
+      const bool last = (j == Nc - 1);
+      if (!last) {
+        const double *Qg = a.Q + mofs(i, j, N, x, x);
+        for (int e = lane; e < x * x; e += WV) L.Qr[e] = Qg[e];
+      }
+      const double *Rg = a.R + mofs(i, j, N, u, u);
+      for (int e = lane; e < u * u; e += WV) L.Rr[e] = Rg[e];
+      __syncthreads();
+      for (int e = lane; e < n * nc; e += WV) {
+        int r = e % n, c = e / n;
+        double v = 0.0;
+        if (last) {
+          for (int k = 0; k < n; k++) v += L.S[r + n * k] * Pb[k + n * c];
+        } else if (r < x) {
+          for (int k = 0; k < x; k++) v += symu(L.Qr, x, r, k) * Pb[k + n * c];
+          v += (a.reg_x + (a.Dx ? a.Dx[vofs(i, j, N, x) + r] : 0.0)) * Pb[r + n * c];
+        }
+        T[e] = v;
+      }
+      __syncthreads();
+      for (int e = lane; e < nc * nc; e += WV) {
+        int r = e % nc, c = e / nc;
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) acc += Pb[k + n * r] * T[k + n * c];
+        if (r / u == j && c / u == j) {
+          int rr = r - j * u, cc = c - j * u;
+          acc += symu(L.Rr, u, rr, cc);
+          if (rr == cc) {
+            acc += a.reg_u + slew_diag(sl0, sl, j, N);
+            if (i == 0 && a.owner && a.Du) acc += a.Du[vofs(0, j, N, u) + rr];
+          }
+        }
+        if (j > 0 && (r % u) == (c % u) && ((r / u == j && c / u == j - 1) || (r / u == j - 1 && c / u == j))) acc -= sl;
+        Hc[e] += acc;
+      }
+      __syncthreads();
+      double *tmp = Pa; Pa = Pb; Pb = tmp;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward sweep: consensus stages take the shared step, free stages apply the Riccati gains
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WV) k_fwd_generic(LQArgs a) {
+  extern __shared__ double lds[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int x = a.x, u = a.u, n = a.n, N = a.N, Nc = a.Nc;
+  double *xi = lds, *xn = xi + n, *du = xn + n;
+  for (int e = lane; e < n; e += WV) xi[e] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < N; j++) {
+    if (lane < u) {
+      double v;
+      if (j < Nc) v = a.duc[j * u + lane];
+      else {
+        const double *Kg = a.K + mofs(i, j, N, u, n);
+        v = -a.kff[vofs(i, j, N, u) + lane];
+        for (int c = 0; c < n; c++) v -= Kg[lane + u * c] * xi[c];
+      }
+      du[lane] = v;
+      a.dU[vofs(i, j, N, u) + lane] = v;
+    }
+    __syncthreads();
+    const double *fx = a.fx + mofs(i, j, N, x, x), *fu = a.fu + mofs(i, j, N, x, u);
+    for (int r = lane; r < n; r += WV) {
+      double v = 0.0;
+      if (r < x) {
+        if (j > 0) for (int c = 0; c < x; c++) v += fx[r + x * c] * xi[c];
+        for (int t = 0; t < u; t++) v += fu[r + x * t] * du[t];
+        a.dX[vofs(i, j, N, x) + r] = v;
+      } else v = du[r - x];
+      xn[r] = v;
+    }
+    __syncthreads();
+    for (int e = lane; e < n; e += WV) xi[e] = xn[e];
+    __syncthreads();
+  }
+}
+
+// linear rollout of the reference (PMPC.jl/src/types.jl:161-173): X from U
+__global__ void __launch_bounds__(WV) k_rollout(LQArgs a, const double *U, double *X) {
+  extern __shared__ double lds[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const int x = a.x, u = a.u, N = a.N;
+  double *dxp = lds, *dup = dxp + x;
+  for (int j = 0; j < N; j++) {
+    if (lane < x) dxp[lane] = j > 0 ? X[vofs(i, j - 1, N, x) + lane] - a.X_prev[vofs(i, j - 1, N, x) + lane] : 0.0;
+    if (lane < u) dup[lane] = U[vofs(i, j, N, u) + lane] - a.U_prev[vofs(i, j, N, u) + lane];
+    __syncthreads();
+    const double *fx = a.fx + mofs(i, j, N, x, x), *fu = a.fu + mofs(i, j, N, x, u);
+    for (int r = lane; r < x; r += WV) {
+      double v = a.f[vofs(i, j, N, x) + r];
+      if (j > 0) for (int c = 0; c < x; c++) v += fx[r + x * c] * dxp[c];
+      for (int t = 0; t < u; t++) v += fu[r + x * t] * dup[t];
+      X[vofs(i, j, N, x) + r] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// deterministic sum over particles: src [M][E] -> dst [gridDim.y][E]
+__global__ void __launch_bounds__(256) k_reduce_particles(const double *src, double *dst, int M, int E) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int e = blockIdx.x * 64 + tx;
+  double acc = 0.0;
+  if (e < E)
+    for (int i = blockIdx.y * 4 + ty; i < M; i += 4 * gridDim.y) acc += src[(size_t)i * E + e];
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && e < E) dst[(size_t)blockIdx.y * E + e] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// dense SPD solve of the reduced consensus system (single workgroup; nc = Nc*udim)
+__global__ void __launch_bounds__(256) k_cons_solve(const double *Hc, double *Lc, const double *gc, double *duc, int nc,
+                                                    int factor, int *fail) {
+  extern __shared__ double y[];
+  const int tid = threadIdx.x, nth = blockDim.x;
+  if (factor) {
+    for (int e = tid; e < nc * nc; e += nth) Lc[e] = Hc[e];
+    __syncthreads();
+    for (int k = 0; k < nc; k++) {
+      if (tid == 0) {
+        double d = Lc[k + (size_t)nc * k];
+        if (!(d > 0.0)) { *fail = 2; d = 1.0; }
+        Lc[k + (size_t)nc * k] = sqrt(d);
+      }
+      __syncthreads();
+      const double dk = Lc[k + (size_t)nc * k];
+      for (int r = k + 1 + tid; r < nc; r += nth) Lc[r + (size_t)nc * k] /= dk;
+      __syncthreads();
+      const int rem = nc - k - 1;
+      for (int e = tid; e < rem * rem; e += nth) {
+        int r = k + 1 + e % rem, c = k + 1 + e / rem;
+        if (r >= c) Lc[r + (size_t)nc * c] -= Lc[r + (size_t)nc * k] * Lc[c + (size_t)nc * k];
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < nc; e += nth) y[e] = -gc[e];
+  __syncthreads();
+  for (int k = 0; k < nc; k++) {  // L y = b
+    if (tid == 0) y[k] /= Lc[k + (size_t)nc * k];
+    __syncthreads();
+    const double yk = y[k];
+    for (int r = k + 1 + tid; r < nc; r += nth) y[r] -= Lc[r + (size_t)nc * k] * yk;
+    __syncthreads();
+  }
+  for (int k = nc - 1; k >= 0; k--) {  // L' x = y
+    if (tid == 0) y[k] /= Lc[k + (size_t)nc * k];
+    __syncthreads();
+    const double yk = y[k];
+    for (int r = tid; r < k; r += nth) y[r] -= Lc[k + (size_t)nc * r] * yk;
+    __syncthreads();
+  }
+  for (int e = tid; e < nc; e += nth) duc[e] = y[e];
+}
+
+}  // namespace
+
+size_t lq_generic_lds_bytes(const LQArgs &a) { return lds_doubles(a.x, a.u, a.n) * sizeof(double); }
+
+void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s) {
+  hipLaunchKernelGGL(k_rollout, dim3(a.M), dim3(WV), (a.x + a.u) * sizeof(double), s, a, U, X);
+}
+
+void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s) {
+  size_t lds = lq_generic_lds_bytes(a);
+  if (factor) hipLaunchKernelGGL(k_bwd_generic<true>, dim3(a.M), dim3(WV), lds, s, a);
+  else hipLaunchKernelGGL(k_bwd_generic<false>, dim3(a.M), dim3(WV), lds, s, a);
+}
+
+void launch_fwd_generic(const LQArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_fwd_generic, dim3(a.M), dim3(WV), (2 * a.n + a.u) * sizeof(double), s, a);
+}
+
+void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s) {
+  int gy = (M + 3) / 4;
+  if (gy > 64) gy = 64;
+  dim3 blk(64, 4), grd((E + 63) / 64, gy);
+  if (gy == 1) {
+    hipLaunchKernelGGL(k_reduce_particles, grd, blk, 0, s, src, dst, M, E);
+  } else {
+    hipLaunchKernelGGL(k_reduce_particles, grd, blk, 0, s, src, tmp, M, E);
+    hipLaunchKernelGGL(k_reduce_particles, dim3((E + 63) / 64, 1), blk, 0, s, (const double *)tmp, dst, gy, E);
+  }
+}
+
+void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(k_cons_solve, dim3(1), dim3(256), nc * sizeof(double), s, (const double *)Hc, Lc, gc, duc, nc,
+                     factor ? 1 : 0, fail);
+}

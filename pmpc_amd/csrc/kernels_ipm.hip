@@ -1,0 +1,353 @@
+// kernels_ipm.hip — elementwise / reduction kernels of the box-constraint interior-point layer.
+//
+// The reference hands `l <= G z <= u` (PMPC.jl/src/lqp_utils.jl:306-393, G = selector rows) to
+// OSQP; here the same constraints are driven to complementarity by a Mehrotra predictor-corrector
+// whose Newton systems are the structured LQ solves of kernels_generic.hip / kernels_fast.hip.
+// All kernels are HBM-streaming, grid-stride, 256 threads; reductions are two-stage and
+// deterministic (block partials summed in index order by a single lane).
+//
+// Per bounded variable z with bounds [lo, hi] (either side may be infinite):
+//   slacks t_l, t_u > 0, multipliers l_l, l_u > 0, residuals r_l = z - lo - t_l, r_u = hi - z - t_u
+//   D = l_l/t_l + l_u/t_u
+//   w_l = (sigma*mu - c_l - l_l r_l)/t_l,  w_u likewise;  Newton gradient shift w = -w_l + w_u
+//   dt_l = dz + r_l, dt_u = -dz + r_u, dl_l = w_l - l_l - (l_l/t_l) dz, dl_u = w_u - l_u + (l_u/t_u) dz
+// Consensus controls (stages j < Nc) are ONE variable stored M times (lqp_utils.jl:17-61); they are
+// counted once, on the owner rank's particle 0, whose bounds they use (lqp_utils.jl:329-330).
+#include "pmpc_dev.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+__device__ __forceinline__ double slab_weight(const Slab &s, long long idx) {
+  if (!s.is_u || s.Nc == 0) return 1.0;
+  int j = (int)((idx / s.d) % s.N);
+  if (j >= s.Nc) return 1.0;
+  long long i = idx / ((long long)s.d * s.N);
+  return (i == 0 && s.owner) ? 1.0 : 0.0;
+}
+
+struct Elem {
+  bool ml, mu;
+  double lo, hi, tl, tu, ll, lu, rl, ru, wl, wu, dtl, dtu, dll, dlu;
+};
+
+// everything the Newton step needs for one variable; corrector terms (sigmu, cl, cu) optional
+__device__ __forceinline__ Elem load_elem(const Slab &s, long long k, double sigmu, bool corrector, bool with_dz) {
+  Elem e;
+  e.lo = s.lo[k];
+  e.hi = s.hi[k];
+  e.ml = isfinite(e.lo);
+  e.mu = isfinite(e.hi);
+  const double z = s.z[k];
+  e.tl = s.tl[k]; e.tu = s.tu[k]; e.ll = s.ll[k]; e.lu = s.lu[k];
+  e.rl = e.ml ? z - e.lo - e.tl : 0.0;
+  e.ru = e.mu ? e.hi - z - e.tu : 0.0;
+  const double cl = corrector ? s.cl[k] : 0.0, cu = corrector ? s.cu[k] : 0.0;
+  e.wl = e.ml ? (sigmu - cl - e.ll * e.rl) / e.tl : 0.0;
+  e.wu = e.mu ? (sigmu - cu - e.lu * e.ru) / e.tu : 0.0;
+  if (with_dz) {
+    const double dz = s.dz[k];
+    e.dtl = e.ml ? dz + e.rl : 0.0;
+    e.dtu = e.mu ? -dz + e.ru : 0.0;
+    e.dll = e.ml ? e.wl - e.ll - (e.ll / e.tl) * dz : 0.0;
+    e.dlu = e.mu ? e.wu - e.lu + (e.lu / e.tu) * dz : 0.0;
+  }
+  return e;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (t < o) sh[t] += sh[t + o];
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double *sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (t < o) sh[t] = fmax(sh[t], sh[t + o]);
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double block_min(double v, double *sh) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (t < o) sh[t] = fmin(sh[t], sh[t + o]);
+    __syncthreads();
+  }
+  double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(TB) k_axpy(double *y, const double *x, double alpha, long long n) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) y[k] += alpha * x[k];
+}
+__global__ void __launch_bounds__(TB) k_axpy_alpha(double *y, const double *x, const IpmScal *sc, long long n) {
+  const double alpha = sc->alpha;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) y[k] += alpha * x[k];
+}
+__global__ void __launch_bounds__(TB) k_fill(double *y, double v, long long n) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) y[k] = v;
+}
+
+// consensus-control bounds come from particle 0 (lqp_utils.jl:329-330): replicate them
+__global__ void __launch_bounds__(TB) k_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc) {
+  const long long per = (long long)Nc * u, tot = per * (M - 1);
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
+    long long i = 1 + k / per, e = k % per;
+    lo[i * (long long)N * u + e] = lo[e];
+    hi[i * (long long)N * u + e] = hi[e];
+  }
+}
+
+// dynamics-consistent base point: free controls = U_prev, consensus controls = 0
+__global__ void __launch_bounds__(TB) k_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc) {
+  const long long tot = (long long)M * N * u;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
+    int j = (int)((k / u) % N);
+    U[k] = j < Nc ? 0.0 : U_prev[k];
+  }
+}
+
+__global__ void __launch_bounds__(TB) k_violation(Slab s, double *part_max) {
+  __shared__ double sh[TB];
+  double v = 0.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const double z = s.z[k], lo = s.lo[k], hi = s.hi[k];
+    if (isfinite(lo)) v = fmax(v, lo - z);
+    if (isfinite(hi)) v = fmax(v, z - hi);
+    if (!(z == z)) v = INFINITY;
+  }
+  v = block_max(v, sh);
+  if (threadIdx.x == 0) part_max[blockIdx.x] = v;
+}
+
+// pull the controls strictly inside their box so that control slack residuals start at zero
+__global__ void __launch_bounds__(TB) k_ipm_clip(Slab s) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const double lo = s.lo[k], hi = s.hi[k];
+    const bool ml = isfinite(lo), mu = isfinite(hi);
+    double wid = (ml && mu) ? hi - lo : fmax(1.0, ml ? fabs(lo) : (mu ? fabs(hi) : 1.0));
+    double z = s.z[k];
+    if (ml) z = fmax(z, lo + 0.1 * wid);
+    if (mu) z = fmin(z, hi - 0.1 * wid);
+    s.z[k] = z;
+  }
+}
+
+__global__ void __launch_bounds__(TB) k_ipm_init_slack(Slab s, double mu0) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const double lo = s.lo[k], hi = s.hi[k], z = s.z[k];
+    const bool ml = isfinite(lo), mu = isfinite(hi);
+    const double wid = (ml && mu) ? hi - lo : 1.0;
+    const double thr = fmax(1e-2 * wid, 1e-4);
+    const double tl = ml ? fmax(z - lo, thr) : 1.0, tu = mu ? fmax(hi - z, thr) : 1.0;
+    s.tl[k] = tl;
+    s.tu[k] = tu;
+    s.ll[k] = ml ? mu0 / tl : 0.0;
+    s.lu[k] = mu ? mu0 / tu : 0.0;
+    s.cl[k] = 0.0;
+    s.cu[k] = 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(TB) k_ipm_prepare(Slab s, int corrector, const IpmScal *sc, double *part_sum,
+                                                    double *part_cnt, double *part_max) {
+  __shared__ double sh[TB];
+  const double sigmu = corrector ? sc->sigmu : 0.0;
+  double comp = 0.0, cnt = 0.0, res = 0.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    Elem e = load_elem(s, k, sigmu, corrector != 0, false);
+    if (!corrector) {
+      s.D[k] = (e.ml ? e.ll / e.tl : 0.0) + (e.mu ? e.lu / e.tu : 0.0);
+      const double wgt = slab_weight(s, k);
+      comp += wgt * ((e.ml ? e.tl * e.ll : 0.0) + (e.mu ? e.tu * e.lu : 0.0));
+      cnt += wgt * ((e.ml ? 1.0 : 0.0) + (e.mu ? 1.0 : 0.0));
+      res = fmax(res, fmax(fabs(e.rl), fabs(e.ru)));
+    }
+    s.w[k] = -e.wl + e.wu;
+  }
+  if (!corrector) {
+    comp = block_sum(comp, sh);
+    cnt = block_sum(cnt, sh);
+    res = block_max(res, sh);
+    if (threadIdx.x == 0) {
+      part_sum[blockIdx.x] = comp;
+      part_cnt[blockIdx.x] = cnt;
+      part_max[blockIdx.x] = res;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal *sc) {
+  __shared__ double sh[TB];
+  const double sigmu = corrector ? sc->sigmu : 0.0;
+  double a = 1.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    Elem e = load_elem(s, k, sigmu, corrector != 0, true);
+    if (e.ml) {
+      if (e.dtl < 0.0) a = fmin(a, -e.tl / e.dtl);
+      if (e.dll < 0.0) a = fmin(a, -e.ll / e.dll);
+    }
+    if (e.mu) {
+      if (e.dtu < 0.0) a = fmin(a, -e.tu / e.dtu);
+      if (e.dlu < 0.0) a = fmin(a, -e.lu / e.dlu);
+    }
+    if (!corrector) {
+      s.cl[k] = e.dtl * e.dll;
+      s.cu[k] = e.dtu * e.dlu;
+    }
+  }
+  a = block_min(a, sh);
+  if (threadIdx.x == 0) {
+    if (!(a >= 0.0)) a = 0.0;  // NaN guard
+    atomicMin(&sc->amin_bits, (unsigned long long)__double_as_longlong(a));
+  }
+}
+
+__global__ void __launch_bounds__(TB) k_ipm_muaff(Slab s, const IpmScal *sc, double *part_sum) {
+  __shared__ double sh[TB];
+  const double a = sc->alpha_aff;
+  double acc = 0.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    Elem e = load_elem(s, k, 0.0, false, true);
+    const double wgt = slab_weight(s, k);
+    if (e.ml) acc += wgt * (e.tl + a * e.dtl) * (e.ll + a * e.dll);
+    if (e.mu) acc += wgt * (e.tu + a * e.dtu) * (e.lu + a * e.dlu);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part_sum[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(TB) k_ipm_update(Slab s, const IpmScal *sc) {
+  const double a = sc->alpha, sigmu = sc->sigmu;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    Elem e = load_elem(s, k, sigmu, true, true);
+    s.z[k] += a * s.dz[k];
+    if (e.ml) { s.tl[k] = e.tl + a * e.dtl; s.ll[k] = e.ll + a * e.dll; }
+    if (e.mu) { s.tu[k] = e.tu + a * e.dtu; s.lu[k] = e.lu + a * e.dlu; }
+  }
+}
+
+__global__ void k_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt,
+                              const double *part_max, int nb) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
+  switch (stage) {
+    case 0:
+      sc->comp_sum = sc->cnt = sc->muaff_sum = sc->pad0 = 0.0;
+      sc->res_max = sc->viol_max = 0.0;
+      sc->amin_bits = one_bits;
+      sc->mu = sc->sigma = sc->sigmu = 0.0;
+      sc->alpha_aff = sc->alpha = 1.0;
+      sc->nu = 1.0;
+      sc->iter = 0;
+      sc->status = 0;
+      break;
+    case 1: {
+      double m = 0.0;
+      for (int b = 0; b < nb; b++) m = fmax(m, part_max[b]);
+      sc->viol_max = m;
+    } break;
+    case 2: {
+      double s = 0.0, c = 0.0, m = 0.0;
+      for (int b = 0; b < nb; b++) { s += part_sum[b]; c += part_cnt[b]; m = fmax(m, part_max[b]); }
+      sc->comp_sum = s; sc->cnt = c; sc->res_max = m;
+    } break;
+    case 3:
+      sc->mu = sc->comp_sum / fmax(sc->cnt, 1.0);
+      sc->amin_bits = one_bits;
+      break;
+    case 4:
+      sc->alpha_aff = __longlong_as_double((long long)sc->amin_bits);
+      sc->amin_bits = one_bits;
+      break;
+    case 5: {
+      double s = 0.0;
+      for (int b = 0; b < nb; b++) s += part_sum[b];
+      sc->muaff_sum = s;
+    } break;
+    case 6: {
+      double mu_aff = sc->muaff_sum / fmax(sc->cnt, 1.0);
+      double r = mu_aff / sc->mu;
+      sc->sigma = r * r * r;
+      sc->sigmu = sc->sigma * sc->mu;
+    } break;
+    case 7: {
+      double a = __longlong_as_double((long long)sc->amin_bits);
+      if (a < 1.0) a = fmin(1.0, fmax(0.99, 1.0 - sc->mu) * a);
+      sc->alpha = a;
+      sc->nu *= (1.0 - a);
+      sc->iter += 1;
+      sc->amin_bits = one_bits;
+    } break;
+  }
+}
+
+inline int grid_for(long long n) {
+  long long b = (n + TB - 1) / TB;
+  if (b > PMPC_RED_BLOCKS) b = PMPC_RED_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_axpy, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, xv, alpha, n);
+}
+void launch_axpy_alpha(double *y, const double *xv, const IpmScal *sc, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_axpy_alpha, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, xv, sc, n);
+}
+void launch_fill(double *y, double v, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, v, n);
+}
+void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hipStream_t s) {
+  if (M <= 1 || Nc <= 0) return;
+  hipLaunchKernelGGL(k_cons_bounds, dim3(grid_for((long long)Nc * u * (M - 1))), dim3(TB), 0, s, lo, hi, M, N, u, Nc);
+}
+void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_base, dim3(grid_for((long long)M * N * u)), dim3(TB), 0, s, U, U_prev, M, N, u, Nc);
+}
+// NOTE: every reduction kernel below runs exactly PMPC_RED_BLOCKS blocks so that unused
+// partial slots never hold stale values.
+void launch_violation(const Slab &sl, double *part_max, hipStream_t s) {
+  hipLaunchKernelGGL(k_violation, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, part_max);
+}
+void launch_ipm_clip(const Slab &sl, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_clip, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl);
+}
+void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_init_slack, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl, mu0);
+}
+void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
+                        double *part_max, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_prepare, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, corrector, sc, part_sum, part_cnt, part_max);
+}
+void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_step, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, corrector, sc);
+}
+void launch_ipm_muaff(const Slab &sl, const IpmScal *sc, double *part_sum, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_muaff, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, sc, part_sum);
+}
+void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_update, dim3(grid_for(sl.count) * 4), dim3(TB), 0, s, sl, sc);
+}
+void launch_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt, const double *part_max,
+                        int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_scalars, dim3(1), dim3(64), 0, s, stage, sc, part_sum, part_cnt, part_max, nblocks);
+}

@@ -1,0 +1,115 @@
+// pmpc_dev.h — shared declarations of the device solver (gfx950 only).
+//
+// Data layout in HBM (everything fp64, the C-ABI layout of include/pmpc_abi.h):
+//   vectors  v[(i*N + j)*d + r]                  particle i, stage j, component r
+//   matrices m[((i*N + j)*cols + t)*rows + r]    column-major (rows x cols) block per (i, j)
+// so one particle's horizon is one contiguous slab and a GPU shard is a contiguous slice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      fprintf(stderr, "pmpc_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, \
+              __LINE__, #expr);                                                               \
+      abort();                                                                                \
+    }                                                                                         \
+  } while (0)
+
+// Arguments of the structured LQ kernels (Riccati factor / vector sweeps / forward sweep).
+struct LQArgs {
+  int x, u, N, M, Nc;
+  int w;  // u if slew penalties are active (stage state augmented with the previous control) else 0
+  int n;  // x + w
+  double reg_x, reg_u;
+  // ABI inputs
+  const double *f, *fx, *fu, *Q, *R, *X_prev, *U_prev, *X_ref, *U_ref;
+  const double *slew, *slew0, *um1;  // per particle, never null (zeros when absent)
+  // current iterate (dynamics-consistent)
+  const double *X, *U;
+  // IPM terms: extra Hessian diagonals / gradient shifts (null when absent)
+  const double *Dx, *Du, *wx, *wu;
+  // factor storage
+  double *K;     // [M][N][u*n]  col-major u x n
+  double *Hinv;  // [M][N][u*u]
+  double *kff;   // [M][N][u]
+  double *gx;    // [M][N][x]  smooth gradient P z + q (state part)
+  double *gu;    // [M][N][u]
+  // consensus condensing
+  double *gc_part;  // [M][nc]
+  double *Hc_part;  // [M][nc*nc]
+  double *scratch;  // [M][3*n*nc]
+  const double *duc;  // [nc] consensus step
+  // outputs of the forward sweep
+  double *dX, *dU;
+  int owner;  // this rank holds global particle 0 (whose bounds the consensus controls use)
+  int *fail;
+};
+
+// One "slab" of box-constrained variables for the elementwise IPM kernels.
+struct Slab {
+  long long count;  // M*N*d
+  int d, N, Nc;
+  int is_u;   // consensus duplicates exist for stages j < Nc
+  int owner;
+  const double *lo, *hi;
+  double *z, *dz;
+  double *tl, *tu, *ll, *lu, *cl, *cu, *D, *w;
+};
+
+// Device-resident IPM scalars.
+struct IpmScal {
+  double comp_sum;   // sum w * (t_l l_l + t_u l_u)           (all-reduced: sum)
+  double cnt;        // number of finite bounds (weighted)    (all-reduced: sum)
+  double muaff_sum;  //                                         (all-reduced: sum)
+  double pad0;
+  double res_max;    // max |slack residual|                  (all-reduced: max)
+  double viol_max;   // max bound violation of the unconstrained optimum (all-reduced: max)
+  unsigned long long amin_bits;  // min step ratio as u64 bits (all-reduced: min)
+  unsigned long long pad1;
+  double mu, sigma, sigmu, alpha_aff, alpha, nu;
+  int iter, status;
+};
+
+#define PMPC_RED_BLOCKS 512
+
+// ---- kernels_generic.hip ------------------------------------------------------------------------
+size_t lq_generic_lds_bytes(const LQArgs &a);
+void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s);
+void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s);
+void launch_fwd_generic(const LQArgs &a, hipStream_t s);
+void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s);
+void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
+                       hipStream_t s);
+
+// ---- kernels_fast.hip ---------------------------------------------------------------------------
+bool lq_fast_supported(const LQArgs &a);
+void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s);
+void launch_fwd_fast(const LQArgs &a, hipStream_t s);
+
+// ---- kernels_ipm.hip ----------------------------------------------------------------------------
+void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s);
+void launch_fill(double *y, double v, long long n, hipStream_t s);
+void launch_axpy_alpha(double *y, const double *xv, const IpmScal *sc, long long n, hipStream_t s);
+void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hipStream_t s);
+void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc, hipStream_t s);
+void launch_violation(const Slab &sl, double *part_max, hipStream_t s);
+void launch_ipm_clip(const Slab &sl, hipStream_t s);
+void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s);
+void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
+                        double *part_max, hipStream_t s);
+void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, hipStream_t s);
+void launch_ipm_muaff(const Slab &sl, const IpmScal *sc, double *part_sum, hipStream_t s);
+void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s);
+// stage: 0 reset, 1 finalize local partials (viol), 2 finalize (comp,cnt,res) partials, 3 mu + reset amin,
+//        4 alpha_aff from amin, 5 finalize muaff partials, 6 sigma, 7 final alpha + nu
+void launch_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt,
+                        const double *part_max, int nblocks, hipStream_t s);
+
+// ---- dynamics.hip -------------------------------------------------------------------------------
+void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
+                      const double *params, double *f, double *fx, double *fu, hipStream_t s);

@@ -1,0 +1,499 @@
+// solver.hip — host orchestration of the device solver and the C ABI of include/pmpc_abi.h.
+//
+// One call = one convex sub-problem of the reference's SCP loop, i.e. what
+// PMPC.jl/src/main.jl:115-171 `lqp_solve` does (assemble joint QP -> OSQP -> split), solved here as
+//   1. equality-only optimum by ONE structured Newton step (Riccati + consensus condensing),
+//   2. if a box constraint is violated: Mehrotra predictor-corrector on the boxes, each Newton
+//      system being the same structured solve with modified diagonals.
+// The only cross-particle (and therefore cross-GPU) data are the condensed consensus Hessian /
+// gradient [Hc | gc] and a handful of IPM scalars -> RCCL all-reduce when a communicator is set.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../include/pmpc_abi.h"
+#include "pmpc_dev.h"
+
+namespace {
+
+// ---- lazily bound RCCL (the library must load on machines where no communicator is ever made) ----
+struct Rccl {
+  void *h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  bool load() {
+    if (h) return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names)
+      if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return false;
+    GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+    AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+    Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast");
+    return GetUniqueId && CommInitRank && AllReduce && Broadcast;
+  }
+};
+Rccl g_rccl;
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  void ensure(size_t b) {
+    if (b <= bytes) return;
+    if (p) HIP_CHECK(hipFree(p));
+    HIP_CHECK(hipMalloc(&p, b ? b : 8));
+    bytes = b;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  double *d() const { return (double *)p; }
+};
+
+struct SlabBufs {
+  DevBuf lo, hi, tl, tu, ll, lu, cl, cu, D, w;
+};
+
+struct Workspace {
+  DevBuf X, U, dX, dU, gx, gu, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
+  DevBuf zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
+  SlabBufs sx, su;
+};
+
+}  // namespace
+
+struct pmpc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Workspace ws;
+  IpmScal *sc_host = nullptr;  // pinned
+  int *fail_host = nullptr;    // pinned
+  // RCCL
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  // staging for the host-pointer ABI
+  DevBuf stage[19];
+};
+
+namespace {
+
+void allreduce(pmpc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t op) {
+  if (c->world <= 1) return;
+  ncclResult_t r = g_rccl.AllReduce(buf, buf, n, dt, op, c->comm, c->stream);
+  if (r != ncclSuccess) {
+    fprintf(stderr, "pmpc_hip: ncclAllReduce failed (%d)\n", (int)r);
+    abort();
+  }
+}
+
+void read_scalars(pmpc_ctx *c) {
+  HIP_CHECK(hipMemcpyAsync(c->sc_host, c->ws.sc.p, sizeof(IpmScal), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->fail_host, c->ws.fail.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// one structured Newton solve: backward (factor or vector-only) -> reduce -> all-reduce -> dense solve -> forward
+void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast) {
+  hipStream_t s = c->stream;
+  Workspace &w = c->ws;
+  const int nc = a.Nc * a.u;
+  if (fast) launch_bwd_fast(a, factor, s);
+  else launch_bwd_generic(a, factor, s);
+  if (nc > 0) {
+    double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
+    if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
+    launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
+    if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
+    else allreduce(c, gc, nc, ncclFloat64, ncclSum);
+    launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
+  }
+  if (fast) launch_fwd_fast(a, s);
+  else launch_fwd_generic(a, s);
+}
+
+void fill_nan_outputs(pmpc_ctx *c, const pmpc_problem *p) {
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  launch_fill(p->X_out, nan, (long long)p->M * p->N * p->xdim, c->stream);
+  launch_fill(p->U_out, nan, (long long)p->M * p->N * p->udim, c->stream);
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *pmpc_version(void) { return "pmpc_hip 0.1 (gfx950)"; }
+
+int pmpc_create(pmpc_ctx **out, int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) {
+    fprintf(stderr, "pmpc_hip: no HIP device %d available (found %d) — this library has no CPU path\n", device, ndev);
+    return 1;
+  }
+  pmpc_ctx *c = new pmpc_ctx();
+  c->device = device;
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipHostMalloc((void **)&c->sc_host, sizeof(IpmScal)));
+  HIP_CHECK(hipHostMalloc((void **)&c->fail_host, sizeof(int)));
+  *out = c;
+  return 0;
+}
+
+void pmpc_destroy(pmpc_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  Workspace &w = c->ws;
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.gx, &w.gu, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
+                   &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
+                   &w.part_max, &w.sc, &w.fail};
+  for (DevBuf *b : all) b->release();
+  for (SlabBufs *sb : {&w.sx, &w.su})
+    for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
+  for (DevBuf &b : c->stage) b.release();
+  (void)hipHostFree(c->sc_host);
+  (void)hipHostFree(c->fail_host);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+void *pmpc_stream(pmpc_ctx *c) { return (void *)c->stream; }
+void pmpc_sync(pmpc_ctx *c) { HIP_CHECK(hipStreamSynchronize(c->stream)); }
+
+int pmpc_comm_unique_id(void *out128) {
+  if (!g_rccl.load()) return 1;
+  ncclUniqueId id;
+  if (g_rccl.GetUniqueId(&id) != ncclSuccess) return 2;
+  memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+int pmpc_comm_init(pmpc_ctx *c, int rank, int world, const void *id128) {
+  if (world <= 1) {
+    c->rank = 0;
+    c->world = 1;
+    return 0;
+  }
+  if (!g_rccl.load()) return 1;
+  HIP_CHECK(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return 2;
+  c->rank = rank;
+  c->world = world;
+  return 0;
+}
+int pmpc_comm_rank(pmpc_ctx *c) { return c->rank; }
+int pmpc_comm_world(pmpc_ctx *c) { return c->world; }
+
+int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const double *x0, const double *X_prev,
+                          const double *U_prev, const double *params, double *f, double *fx, double *fu) {
+  HIP_CHECK(hipSetDevice(c->device));
+  launch_linearize(model, (int)N, (int)M, x0, X_prev, U_prev, params, f, fx, fu, c->stream);
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  Workspace &w = c->ws;
+  const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
+  const int Nc = p->Nc < 0 ? N : (p->Nc > (long long)N ? N : (int)p->Nc);  // main.jl:127-128
+  const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
+  const bool has_slew = p->flags & PMPC_HAS_SLEW, has_slew0 = p->flags & PMPC_HAS_SLEW0;
+  const int nc = Nc * u;
+  pmpc_info inf;
+  memset(&inf, 0, sizeof(inf));
+  if (x <= 0 || u <= 0 || N <= 0 || M <= 0) {
+    inf.status = 2;
+    if (info) *info = inf;
+    return inf.status;
+  }
+  const size_t nx = (size_t)M * N * x, nu = (size_t)M * N * u, D8 = sizeof(double);
+
+  LQArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.u = u; a.N = N; a.M = M; a.Nc = Nc;
+  a.w = has_slew ? u : 0;  // a zero slew vector still takes the augmented path: correct, only slower
+  a.n = x + a.w;
+  a.reg_x = p->reg_x; a.reg_u = p->reg_u;
+  a.f = p->f; a.fx = p->fx; a.fu = p->fu; a.Q = p->Q; a.R = p->R;
+  a.X_prev = p->X_prev; a.U_prev = p->U_prev; a.X_ref = p->X_ref; a.U_ref = p->U_ref;
+  a.owner = (c->rank == 0);
+
+  // ---- workspace ---------------------------------------------------------------------------------
+  w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8);
+  w.gx.ensure(nx * D8); w.gu.ensure(nu * D8);
+  w.K.ensure(nu * a.n * D8); w.Hinv.ensure(nu * u * D8); w.kff.ensure(nu * D8);
+  w.gc_part.ensure((size_t)M * nc * D8); w.Hc_part.ensure((size_t)M * nc * nc * D8);
+  w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
+  w.red_tmp.ensure((size_t)64 * ((size_t)nc * nc + nc) * D8);
+  w.Hg.ensure(((size_t)nc * nc + nc) * D8); w.Lc.ensure((size_t)nc * nc * D8); w.duc.ensure((size_t)nc * D8);
+  w.sc.ensure(sizeof(IpmScal)); w.fail.ensure(sizeof(int));
+  const bool fresh_parts = w.part_sum.bytes == 0;
+  w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_cnt.ensure(2 * PMPC_RED_BLOCKS * D8);
+  w.part_max.ensure(2 * PMPC_RED_BLOCKS * D8);
+  if (fresh_parts) {
+    HIP_CHECK(hipMemsetAsync(w.part_sum.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.part_cnt.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
+  }
+  HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+  if (!has_slew || !has_slew0) {
+    if (w.zslew.bytes < (size_t)M * D8 || w.zum1.bytes < (size_t)M * u * D8) {
+      w.zslew.ensure((size_t)M * D8); w.zslew0.ensure((size_t)M * D8); w.zum1.ensure((size_t)M * u * D8);
+      HIP_CHECK(hipMemsetAsync(w.zslew.p, 0, (size_t)M * D8, s));
+      HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, (size_t)M * D8, s));
+      HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, (size_t)M * u * D8, s));
+    }
+  }
+  a.slew = has_slew ? p->slew_reg : w.zslew.d();
+  a.slew0 = has_slew0 ? p->slew_reg0 : w.zslew0.d();
+  a.um1 = has_slew0 ? p->slew_um1 : w.zum1.d();
+  a.K = w.K.d(); a.Hinv = w.Hinv.d(); a.kff = w.kff.d(); a.gx = w.gx.d(); a.gu = w.gu.d();
+  a.gc_part = w.gc_part.d(); a.Hc_part = w.Hc_part.d(); a.scratch = w.scratch.d(); a.duc = w.duc.d();
+  a.dX = w.dX.d(); a.dU = w.dU.d(); a.fail = (int *)w.fail.p;
+  a.X = w.X.d(); a.U = w.U.d();
+  const bool fast = !(p->flags & PMPC_FORCE_GENERIC) && lq_fast_supported(a);
+  inf.fast_path = fast ? 1 : 0;
+  IpmScal *sc = (IpmScal *)w.sc.p;
+
+  // ---- 1. equality-only optimum: one Newton step from a dynamics-consistent base point -----------
+  launch_ipm_scalars(0, sc, nullptr, nullptr, nullptr, 0, s);
+  launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
+  launch_rollout(a, w.U.d(), w.X.d(), s);
+  a.Dx = a.Du = a.wx = a.wu = nullptr;
+  structured_solve(c, a, true, fast);
+  inf.structured_solves = 1;
+  launch_axpy(w.X.d(), w.dX.d(), 1.0, (long long)nx, s);
+  launch_axpy(w.U.d(), w.dU.d(), 1.0, (long long)nu, s);
+
+  auto finish = [&](int status) {
+    inf.status = status;
+    if (status == 0) {
+      HIP_CHECK(hipMemcpyAsync(p->X_out, w.X.p, nx * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(p->U_out, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+    } else {
+      fill_nan_outputs(c, p);
+    }
+    if (info) *info = inf;
+    return status;
+  };
+
+  // ---- slabs of bounded variables ----------------------------------------------------------------
+  Slab sx, su;
+  memset(&sx, 0, sizeof(sx));
+  memset(&su, 0, sizeof(su));
+  auto setup_slab = [&](Slab &sl, SlabBufs &b, size_t cnt, int d, bool is_u, const double *lo, const double *hi, double *z,
+                        double *dz) {
+    for (DevBuf *q : {&b.tl, &b.tu, &b.ll, &b.lu, &b.cl, &b.cu, &b.D, &b.w}) q->ensure(cnt * D8);
+    sl.count = (long long)cnt; sl.d = d; sl.N = N; sl.Nc = Nc; sl.is_u = is_u ? 1 : 0; sl.owner = a.owner;
+    sl.lo = lo; sl.hi = hi; sl.z = z; sl.dz = dz;
+    sl.tl = b.tl.d(); sl.tu = b.tu.d(); sl.ll = b.ll.d(); sl.lu = b.lu.d(); sl.cl = b.cl.d(); sl.cu = b.cu.d();
+    sl.D = b.D.d(); sl.w = b.w.d();
+  };
+  if (has_xb) setup_slab(sx, w.sx, nx, x, false, p->lx, p->ux, w.X.d(), w.dX.d());
+  if (has_ub) {
+    const double *lo = p->lu, *hi = p->uu;
+    if (Nc > 0 && (M > 1 || c->world > 1)) {  // consensus bounds = global particle 0's (lqp_utils.jl:329-330)
+      w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
+      HIP_CHECK(hipMemcpyAsync(w.su.lo.p, p->lu, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(w.su.hi.p, p->uu, nu * D8, hipMemcpyDeviceToDevice, s));
+      if (c->world > 1) {
+        g_rccl.Broadcast(w.su.lo.p, w.su.lo.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
+        g_rccl.Broadcast(w.su.hi.p, w.su.hi.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
+      }
+      launch_cons_bounds(w.su.lo.d(), w.su.hi.d(), M, N, u, Nc, s);
+      lo = w.su.lo.d(); hi = w.su.hi.d();
+    }
+    setup_slab(su, w.su, nu, u, true, lo, hi, w.U.d(), w.dU.d());
+  }
+  const int B = PMPC_RED_BLOCKS;
+
+  if (!has_xb && !has_ub) {
+    read_scalars(c);
+    if (*c->fail_host) return finish(2);
+    return finish(0);
+  }
+  if (has_xb) launch_violation(sx, w.part_max.d(), s);
+  if (has_ub) launch_violation(su, w.part_max.d() + B, s);
+  launch_ipm_scalars(1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), 2 * B, s);
+  allreduce(c, &sc->res_max, 2, ncclFloat64, ncclMax);
+  allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
+  read_scalars(c);
+  inf.max_violation = c->sc_host->viol_max;
+  if (*c->fail_host || !(c->sc_host->viol_max == c->sc_host->viol_max)) return finish(2);
+  if (verbose) printf("pmpc_hip: equality-only optimum, max bound violation %.3e\n", c->sc_host->viol_max);
+  if (c->sc_host->viol_max <= 0.0) return finish(0);
+
+  // ---- 2. Mehrotra predictor-corrector on the boxes ----------------------------------------------
+  if (has_ub) {
+    launch_ipm_clip(su, s);
+    launch_rollout(a, w.U.d(), w.X.d(), s);
+  }
+  if (has_xb) launch_ipm_init_slack(sx, 1.0, s);
+  if (has_ub) launch_ipm_init_slack(su, 1.0, s);
+  a.Dx = has_xb ? sx.D : nullptr; a.wx = has_xb ? sx.w : nullptr;
+  a.Du = has_ub ? su.D : nullptr; a.wu = has_ub ? su.w : nullptr;
+  const double tol = 1e-12;
+  const int max_iter = 80;
+  int status = 1;
+  for (int it = 1; it <= max_iter; it++) {
+    if (has_xb) launch_ipm_prepare(sx, 0, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+    if (has_ub) launch_ipm_prepare(su, 0, sc, w.part_sum.d() + B, w.part_cnt.d() + B, w.part_max.d() + B, s);
+    launch_ipm_scalars(2, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), 2 * B, s);
+    allreduce(c, &sc->comp_sum, 2, ncclFloat64, ncclSum);
+    allreduce(c, &sc->res_max, 1, ncclFloat64, ncclMax);
+    allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
+    launch_ipm_scalars(3, sc, nullptr, nullptr, nullptr, 0, s);
+    read_scalars(c);
+    const IpmScal &h = *c->sc_host;
+    if (verbose)
+      printf("pmpc_hip: ipm it %2d  mu %9.3e  slack_res %9.3e  nu %9.3e  alpha %6.4f  sigma %8.2e\n", it, h.mu, h.res_max,
+             h.nu, h.alpha, h.sigma);
+    inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
+    if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
+    if (h.mu <= tol && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+    if (it == max_iter) break;
+    // predictor (factorisation) ...
+    structured_solve(c, a, true, fast);
+    inf.structured_solves++;
+    if (has_xb) launch_ipm_step(sx, 0, sc, s);
+    if (has_ub) launch_ipm_step(su, 0, sc, s);
+    allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
+    launch_ipm_scalars(4, sc, nullptr, nullptr, nullptr, 0, s);
+    if (has_xb) launch_ipm_muaff(sx, sc, w.part_sum.d(), s);
+    if (has_ub) launch_ipm_muaff(su, sc, w.part_sum.d() + B, s);
+    launch_ipm_scalars(5, sc, w.part_sum.d(), nullptr, nullptr, 2 * B, s);
+    allreduce(c, &sc->muaff_sum, 1, ncclFloat64, ncclSum);
+    launch_ipm_scalars(6, sc, nullptr, nullptr, nullptr, 0, s);
+    // ... corrector (vector sweeps only, same factorisation)
+    if (has_xb) launch_ipm_prepare(sx, 1, sc, nullptr, nullptr, nullptr, s);
+    if (has_ub) launch_ipm_prepare(su, 1, sc, nullptr, nullptr, nullptr, s);
+    structured_solve(c, a, false, fast);
+    if (has_xb) launch_ipm_step(sx, 1, sc, s);
+    if (has_ub) launch_ipm_step(su, 1, sc, s);
+    allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
+    launch_ipm_scalars(7, sc, nullptr, nullptr, nullptr, 0, s);
+    // z, t, lambda += alpha * step   (a slab without bounds moves by the same device-resident alpha)
+    if (has_xb) launch_ipm_update(sx, sc, s);
+    else launch_axpy_alpha(w.X.d(), w.dX.d(), sc, (long long)nx, s);
+    if (has_ub) launch_ipm_update(su, sc, s);
+    else launch_axpy_alpha(w.U.d(), w.dU.d(), sc, (long long)nu, s);
+  }
+  if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
+  return finish(status);
+}
+
+// -------------------------------------------------------------------------------------------------
+// host-pointer drop-in entry points
+// -------------------------------------------------------------------------------------------------
+static pmpc_ctx *g_ctx = nullptr;
+
+static bool any_nan(const double *p, size_t n) {
+  if (!p) return true;
+  for (size_t k = 0; k < n; k++)
+    if (p[k] != p[k]) return true;
+  return false;
+}
+
+static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
+                       double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R,
+                       double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x,
+                       double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose) {
+  const size_t nx = xdim * N * M, nu = udim * N * M;
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  auto fail_out = [&]() {  // osqp_solver.jl:65-71 convention
+    for (size_t k = 0; k < nx; k++) X_out[k] = nan;
+    for (size_t k = 0; k < nu; k++) U_out[k] = nan;
+  };
+  if (!g_ctx && pmpc_create(&g_ctx, 0) != 0) {
+    fprintf(stderr, "pmpc_hip: c_lqp_solve needs a HIP device; failing the solve (NaN outputs)\n");
+    fail_out();
+    return;
+  }
+  pmpc_ctx *c = g_ctx;
+  HIP_CHECK(hipSetDevice(c->device));
+  pmpc_problem p;
+  memset(&p, 0, sizeof(p));
+  p.xdim = xdim; p.udim = udim; p.N = N; p.M = M; p.Nc = Nc; p.reg_x = reg_x; p.reg_u = reg_u;
+  // sentinels: c_interface.jl:56-70
+  if (!(any_nan(lx, nx) || any_nan(ux, nx))) p.flags |= PMPC_HAS_XBOUNDS;
+  if (!(any_nan(lu, nu) || any_nan(uu, nu))) p.flags |= PMPC_HAS_UBOUNDS;
+  bool slew_nonzero = false;
+  if (!any_nan(slew_reg, M)) {
+    for (size_t k = 0; k < M; k++) slew_nonzero |= (slew_reg[k] != 0.0);
+    if (slew_nonzero) p.flags |= PMPC_HAS_SLEW;
+  }
+  if (!(any_nan(slew_reg0, M) || any_nan(slew_um1, udim * M))) p.flags |= PMPC_HAS_SLEW0;
+  const void *src[19] = {x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1,
+                         nullptr, nullptr};
+  const size_t cnt[19] = {xdim * M, nx, nx * xdim, nx * udim, nx, nu, nx * xdim, nu * udim, nx, nu, nx, nx, nu, nu, M, M,
+                          udim * M, nx, nu};
+  const bool used[19] = {true, true, true, true, true, true, true, true, true, true,
+                         (bool)(p.flags & PMPC_HAS_XBOUNDS), (bool)(p.flags & PMPC_HAS_XBOUNDS),
+                         (bool)(p.flags & PMPC_HAS_UBOUNDS), (bool)(p.flags & PMPC_HAS_UBOUNDS),
+                         (bool)(p.flags & PMPC_HAS_SLEW), (bool)(p.flags & PMPC_HAS_SLEW0), (bool)(p.flags & PMPC_HAS_SLEW0),
+                         true, true};
+  for (int k = 0; k < 19; k++) {
+    if (!used[k]) continue;
+    c->stage[k].ensure(cnt[k] * sizeof(double));
+    if (src[k]) HIP_CHECK(hipMemcpyAsync(c->stage[k].p, src[k], cnt[k] * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  auto dp = [&](int k) { return used[k] ? (const double *)c->stage[k].p : (const double *)nullptr; };
+  p.x0 = dp(0); p.f = dp(1); p.fx = dp(2); p.fu = dp(3); p.X_prev = dp(4); p.U_prev = dp(5); p.Q = dp(6); p.R = dp(7);
+  p.X_ref = dp(8); p.U_ref = dp(9); p.lx = dp(10); p.ux = dp(11); p.lu = dp(12); p.uu = dp(13);
+  p.slew_reg = dp(14); p.slew_reg0 = dp(15); p.slew_um1 = dp(16);
+  p.X_out = c->stage[17].d(); p.U_out = c->stage[18].d();
+  pmpc_info info;
+  pmpc_lqp_solve_device(c, &p, &info, (int)verbose);
+  HIP_CHECK(hipMemcpyAsync(X_out, p.X_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(U_out, p.U_out, nu * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (verbose)
+    printf("pmpc_hip: status %d, ipm iterations %d, structured solves %d, fast path %d\n", info.status, info.ipm_iters,
+           info.structured_solves, info.fast_path);
+}
+
+void c_lqp_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc, double *x0,
+                 double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R, double *X_ref,
+                 double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x, double reg_u,
+                 double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose) {
+  host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
+             reg_u, slew_reg, slew_reg0, slew_um1, verbose);
+}
+
+void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc, double *x0,
+                   double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R, double *X_ref,
+                   double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x, double reg_u,
+                   double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, double smooth_alpha,
+                   char *solver) {
+  // DESIGN.md "cone entry point": the reference's epsilon-anchored epigraph objective
+  // (PMPC.jl/src/main.jl:204-238) has the same minimiser as the QP for M = 1 and differs at the
+  // 1e-3 relative level for M > 1; smoothing (smooth_alpha != NaN) is not reproduced yet.
+  static bool warned = false;
+  if (smooth_alpha == smooth_alpha && !warned) {
+    fprintf(stderr, "pmpc_hip: c_lcone_solve(smooth_alpha=%g, solver=%s): constraint smoothing is not reproduced; "
+                    "solving the hard-constrained QP\n", smooth_alpha, solver ? solver : "?");
+    warned = true;
+  }
+  host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
+             reg_u, slew_reg, slew_reg0, slew_um1, verbose);
+}
+
+}  // extern "C"

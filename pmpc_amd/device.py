@@ -1,0 +1,136 @@
+"""Device-resident API: the same solve with every buffer already in HBM (torch ROCm tensors are
+used purely as device-memory handles), the on-device linearisation of the built-in models and
+particle sharding over RCCL (one process per GPU, torch.distributed only bootstraps the
+communicator).  This is the path bench.py times; it has no reference counterpart — the reference
+copies the Jacobian stacks host<->Julia every SCP iteration (pmpc/static_backend.py:71-74)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MODEL_UNICYCLE, MODEL_QUADROTOR = 0, 1
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class DeviceSolver:
+    """Owns a pmpc_ctx (HIP stream + workspace cache + optional RCCL communicator)."""
+
+    def __init__(self, device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pmpc_amd.DeviceSolver needs a HIP device: there is no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        rc = self.lib.pmpc_create(ctypes.byref(h), self.device)
+        if rc != 0:
+            raise RuntimeError(f"pmpc_create failed ({rc})")
+        self.h = h
+        self.stream = torch.cuda.ExternalStream(self.lib.pmpc_stream(h), device=self.device)
+        self.rank, self.world = 0, 1
+        self.last_info: Dict[str, float] = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pmpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- RCCL bootstrap over an existing torch.distributed group ------------------------------------
+    def init_comm(self):
+        import torch.distributed as dist
+
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            rc = self.lib.pmpc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+            if rc != 0:
+                raise RuntimeError(f"pmpc_comm_unique_id failed ({rc})")
+            uid[0] = bytes(buf.raw)
+        dist.broadcast_object_list(uid, src=0)
+        buf = ctypes.create_string_buffer(uid[0], 128)
+        rc = self.lib.pmpc_comm_init(self.h, rank, world, ctypes.cast(buf, ctypes.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"pmpc_comm_init failed ({rc})")
+        self.rank, self.world = rank, world
+
+    # ---- solve -----------------------------------------------------------------------------------------
+    def lqp_solve(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
+                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, verbose=False,
+                  force_generic=False, wait_current_stream=True):
+        """All tensors float64 CUDA, ABI layout: vectors (M,N,d); matrices (M,N,col,row) i.e. the
+        transpose of the py layout.  Returns X (M,N,x), U (M,N,u) (steps 1..N, no x0)."""
+        M, N, x = f.shape
+        u = U_prev.shape[-1]
+        assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
+        if X_out is None:
+            X_out = torch.empty((M, N, x), dtype=torch.float64, device=f.device)
+        if U_out is None:
+            U_out = torch.empty((M, N, u), dtype=torch.float64, device=f.device)
+        flags = 0
+        if lx is not None and ux is not None:
+            flags |= _lib.HAS_XBOUNDS
+        if lu is not None and uu is not None:
+            flags |= _lib.HAS_UBOUNDS
+        if slew_reg is not None:
+            flags |= _lib.HAS_SLEW
+        if slew_reg0 is not None and slew_um1 is not None:
+            flags |= _lib.HAS_SLEW0
+        if force_generic:
+            flags |= _lib.FORCE_GENERIC
+        prob = _lib.PmpcProblem(
+            xdim=x, udim=u, N=N, M=M, Nc=int(Nc), flags=flags, reg_x=float(reg_x), reg_u=float(reg_u),
+            x0=_p(x0), f=_p(f), fx=_p(fx), fu=_p(fu), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q), R=_p(R),
+            X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
+            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out))
+        info = _lib.PmpcInfo()
+        if wait_current_stream:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        status = self.lib.pmpc_lqp_solve_device(self.h, ctypes.byref(prob), ctypes.byref(info), int(verbose))
+        self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
+        return X_out, U_out, status
+
+    def linearize(self, model: int, x0, X_prev, U_prev, params, f=None, fx=None, fu=None):
+        """f, fx, fu (ABI layout) at X_ = [x0, X_prev[:-1]], U_prev for a built-in model."""
+        M, N, x = X_prev.shape
+        u = U_prev.shape[-1]
+        dev = X_prev.device
+        f = torch.empty((M, N, x), dtype=torch.float64, device=dev) if f is None else f
+        fx = torch.empty((M, N, x, x), dtype=torch.float64, device=dev) if fx is None else fx
+        fu = torch.empty((M, N, u, x), dtype=torch.float64, device=dev) if fu is None else fu
+        self.lib.pmpc_linearize_device(self.h, int(model), N, M, _p(x0), _p(X_prev), _p(U_prev), _p(params), _p(f), _p(fx),
+                                       _p(fu))
+        return f, fx, fu
+
+    def sync(self):
+        self.lib.pmpc_sync(self.h)
+
+
+def to_device_problem(prob: dict, device="cuda"):
+    """py-layout numpy problem (pmpc_amd.dynamics.make_*_problem) -> ABI-layout CUDA tensors."""
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+    tm = lambda a: torch.as_tensor(np.ascontiguousarray(np.swapaxes(a, -1, -2)), dtype=torch.float64, device=device)
+    out = dict(x0=t(prob["x0"]), Q=tm(prob["Q"]), R=tm(prob["R"]), X_ref=t(prob["X_ref"]), U_ref=t(prob["U_ref"]),
+               X_prev=t(prob["X_prev"]), U_prev=t(prob["U_prev"]), params=t(prob["params"]))
+    for k_src, k_dst in (("u_l", "lu"), ("u_u", "uu"), ("x_l", "lx"), ("x_u", "ux")):
+        if prob.get(k_src) is not None:
+            out[k_dst] = t(prob[k_src])
+    return out
