@@ -74,6 +74,8 @@ void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_
 #define PMPC_HAS_SLEW 4u     /* slew_reg valid (else treated as 0) */
 #define PMPC_HAS_SLEW0 8u    /* slew_reg0 and slew_um1 valid */
 #define PMPC_FORCE_GENERIC 16u /* debugging: never take the MFMA fast path */
+#define PMPC_SYMMETRIC_COST 32u /* caller guarantees Q_j == Q_j' and R_j == R_j' exactly (OSQP keeps
+                                   triu(P); the register-resident path relies on symmetric blocks) */
 
 typedef struct pmpc_problem {
   size_t xdim, udim, N, M; /* M = particles held by THIS rank */
@@ -124,6 +126,11 @@ int pmpc_comm_world(pmpc_ctx *ctx);
  * 1 = synthetic quadrotor (params (4,M)).  X_prev/U_prev/x0 and outputs in ABI layout. */
 int pmpc_linearize_device(pmpc_ctx *ctx, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu);
+
+/* Live kernel timing for bench.py: HIP events on pmpc_stream() around each launch class
+ * (0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve). */
+void pmpc_profile_enable(pmpc_ctx *ctx, int on);
+void pmpc_profile_read(pmpc_ctx *ctx, double *ms4, long long *n4);
 
 /* version / build probe used by the loader and the tests */
 const char *pmpc_version(void);

@@ -18,12 +18,12 @@ _lib = None
 c_dp = ctypes.POINTER(ctypes.c_double)
 
 # flags of pmpc_problem.flags (include/pmpc_abi.h)
-HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC = 1, 2, 4, 8, 16
+HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST = 1, 2, 4, 8, 16, 32
 
 ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
-    "pmpc_version",
+    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version",
 ]
 
 
@@ -77,6 +77,10 @@ def load():
     lib.pmpc_comm_world.restype = ctypes.c_int
     lib.pmpc_linearize_device.argtypes = [vp, ctypes.c_int, sz, sz] + [vp] * 7
     lib.pmpc_linearize_device.restype = ctypes.c_int
+    lib.pmpc_profile_enable.argtypes = [vp, ctypes.c_int]
+    lib.pmpc_profile_enable.restype = None
+    lib.pmpc_profile_read.argtypes = [vp, c_dp, ctypes.POINTER(ctypes.c_longlong)]
+    lib.pmpc_profile_read.restype = None
     lib.pmpc_version.argtypes = []
     lib.pmpc_version.restype = ctypes.c_char_p
     _lib = lib

@@ -78,7 +78,9 @@ __device__ inline void build_F(const LQArgs &a, int i, int j, double *F, int lan
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward sweep: FACTOR = matrix Riccati + condensing + smooth gradient; always the vector sweep
+// backward sweep.  FACTOR: matrix Riccati + condensing, gradient = smooth gradient (P z + q) + w.
+// !FACTOR: vector sweep only with the stored gains, gradient = w alone (the corrector solves for the
+// DIFFERENCE between the corrector and predictor steps, so the smooth gradient is never re-read).
 // ------------------------------------------------------------------------------------------------
 template <bool FACTOR>
 __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
@@ -98,11 +100,10 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
         const double *X = a.X + vofs(i, jj, N, x), *Xp = a.X_prev + vofs(i, jj, N, x), *Xr = a.X_ref + vofs(i, jj, N, x);
         double g = a.reg_x * (X[lane] - Xp[lane]);
         for (int t = 0; t < x; t++) g += symu(L.Qr, x, lane, t) * X[t] - L.Qr[lane + x * t] * Xr[t];
-        a.gx[vofs(i, jj, N, x) + lane] = g;
         L.gxs[lane] = g + (a.wx ? a.wx[vofs(i, jj, N, x) + lane] : 0.0);
       }
-    } else if (lane < x) {
-      L.gxs[lane] = a.gx[vofs(i, jj, N, x) + lane] + (a.wx ? a.wx[vofs(i, jj, N, x) + lane] : 0.0);
+    } else if (lane < x) {  // vector-only sweep: the gradient is the IPM shift alone
+      L.gxs[lane] = a.wx ? a.wx[vofs(i, jj, N, x) + lane] : 0.0;
     }
     __syncthreads();
   };
@@ -118,11 +119,10 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
         for (int t = 0; t < u; t++) g += symu(L.Rr, u, lane, t) * U[t] - L.Rr[lane + u * t] * Ur[t];
         if (j > 0) g -= sl * a.U[vofs(i, j - 1, N, u) + lane];
         if (j + 1 < N) g -= sl * a.U[vofs(i, j + 1, N, u) + lane];
-        a.gu[vofs(i, j, N, u) + lane] = g;
         L.tv[lane] = g;
       }
     } else if (lane < u) {
-      L.tv[lane] = a.gu[vofs(i, j, N, u) + lane];
+      L.tv[lane] = 0.0;
     }
     __syncthreads();
   };
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
     if (lane < u) {
       double g = L.hv[n + lane] + L.tv[lane];
       if (i == 0 && a.owner && a.wu) g += a.wu[vofs(0, j, N, u) + lane];
-      if (j == 0) g -= sl0 * a.um1[(size_t)i * u + lane];  // lqp_utils.jl:165 (kept only when Nc >= 1)
+      if (FACTOR && j == 0) g -= sl0 * a.um1[(size_t)i * u + lane];  // lqp_utils.jl:165 (kept only when Nc >= 1)
       a.gc_part[(size_t)i * nc + j * u + lane] = g;
     }
     if (j > 0) state_grad(j - 1); else __syncthreads();
@@ -366,7 +366,8 @@ __global__ void __launch_bounds__(WV) k_fwd_generic(LQArgs a) {
         for (int c = 0; c < n; c++) v -= Kg[lane + u * c] * xi[c];
       }
       du[lane] = v;
-      a.dU[vofs(i, j, N, u) + lane] = v;
+      if (a.accumulate) a.dU[vofs(i, j, N, u) + lane] += v;
+      else a.dU[vofs(i, j, N, u) + lane] = v;
     }
     __syncthreads();
     const double *fx = a.fx + mofs(i, j, N, x, x), *fu = a.fu + mofs(i, j, N, x, u);
@@ -375,7 +376,8 @@ __global__ void __launch_bounds__(WV) k_fwd_generic(LQArgs a) {
       if (r < x) {
         if (j > 0) for (int c = 0; c < x; c++) v += fx[r + x * c] * xi[c];
         for (int t = 0; t < u; t++) v += fu[r + x * t] * du[t];
-        a.dX[vofs(i, j, N, x) + r] = v;
+        if (a.accumulate) a.dX[vofs(i, j, N, x) + r] += v;
+        else a.dX[vofs(i, j, N, x) + r] = v;
       } else v = du[r - x];
       xn[r] = v;
     }

@@ -179,7 +179,9 @@ __global__ void __launch_bounds__(TB) k_ipm_prepare(Slab s, int corrector, const
       cnt += wgt * ((e.ml ? 1.0 : 0.0) + (e.mu ? 1.0 : 0.0));
       res = fmax(res, fmax(fabs(e.rl), fabs(e.ru)));
     }
-    s.w[k] = -e.wl + e.wu;
+    if (!corrector) s.w[k] = -e.wl + e.wu;
+    else  // difference between the corrector and the predictor gradient shifts
+      s.w[k] = -(e.ml ? (sigmu - s.cl[k]) / e.tl : 0.0) + (e.mu ? (sigmu - s.cu[k]) / e.tu : 0.0);
   }
   if (!corrector) {
     comp = block_sum(comp, sh);

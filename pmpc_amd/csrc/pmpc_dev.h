@@ -37,8 +37,6 @@ struct LQArgs {
   double *K;     // [M][N][u*n]  col-major u x n
   double *Hinv;  // [M][N][u*u]
   double *kff;   // [M][N][u]
-  double *gx;    // [M][N][x]  smooth gradient P z + q (state part)
-  double *gu;    // [M][N][u]
   // consensus condensing
   double *gc_part;  // [M][nc]
   double *Hc_part;  // [M][nc*nc]
@@ -46,7 +44,10 @@ struct LQArgs {
   const double *duc;  // [nc] consensus step
   // outputs of the forward sweep
   double *dX, *dU;
-  int owner;  // this rank holds global particle 0 (whose bounds the consensus controls use)
+  int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
+  int accumulate;  // forward sweep adds into dX/dU (corrector = predictor step + difference step)
+  int any_slew;    // slew_reg or slew_reg0 present
+  int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
   int *fail;
 };
 

