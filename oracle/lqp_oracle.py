@@ -196,6 +196,8 @@ def osqp_admm(P, q, Aa, la, ua, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, rho=0
     it, status = 0, "max_iter"
     for it in range(1, max_iter + 1):
         rhs = np.concatenate([sigma * x - q, z - y / rho_vec])
+        if not np.isfinite(rhs).all() or np.max(np.abs(rhs)) > 1e30:
+            raise FloatingPointError("restated OSQP diverged: the QP is primal or dual infeasible")
         sol = lu.solve(rhs)
         xt, nu = sol[:n], sol[n:]
         zt = z + (nu - y) / rho_vec
@@ -205,6 +207,8 @@ def osqp_admm(P, q, Aa, la, ua, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000, rho=0
         y = y + rho_vec * (zr - z_new)
         z = z_new
         if it % check_every == 0 or it == max_iter:
+            if not (np.all(np.isfinite(x)) and np.max(np.abs(x)) < 1e15):
+                raise FloatingPointError("restated OSQP diverged: the QP is primal or dual infeasible")
             Ax, Px, Aty = Aa @ x, P @ x, AaT @ y
             rp, rd = np.linalg.norm(Ax - z, np.inf), np.linalg.norm(Px + q + Aty, np.inf)
             ep = eps_abs + eps_rel * max(np.linalg.norm(Ax, np.inf), np.linalg.norm(z, np.inf))

@@ -12,15 +12,21 @@
 //   A operand   lane (i,g), step r <->  A[i][k = g + 4r]        B operand  lane (j,g) <-> B[k = g + 4r][j]
 // so a C-layout tile is directly the B operand of the next product, a SYMMETRIC C-layout tile is
 // directly an A operand, and F = [fx | fu] loaded once as Fr[r] = F[g + 4r][c] serves both as the B
-// operand of G = S F and as the A operand of H = F' G.  Per stage: 2*KS + 2 MFMAs
-//   G = S F;  H = F' G + blkdiag(Q~_{j-1}, R~_j);  K = Huu^-1 Hux;  S' = H_xx - H_xu K
-// plus a 4x4 Cholesky done redundantly per lane on readlane-broadcast values.
+// operand of G = S F and as the A operand of H = F' G.  Per stage: 2*KS + 1 MFMAs
+//   G = S F;   H = F' G + blkdiag(Q~_{j-1}, R~_j);   S' = H_xx - H_xu K
+// and K = Huu^-1 Hux by gathering the udim control rows column-wise (4 bpermute shuffles) and an
+// in-lane Cholesky substitution per column; the udim x udim Cholesky itself runs redundantly in
+// every lane on readlane-broadcast values (rsq + Newton, no divides).
 //
 // HBM access: the kernel state index rho = g + 4r is mapped to the ORIGINAL state index
 // pi(rho) = KS*g + r, so each lane reads KS CONSECUTIVE doubles of one column and the 64 lanes
 // together cover the contiguous [fx_j | fu_j] (resp. Q_j) block exactly once — fully coalesced
-// streaming of the (M,N,xdim,xdim) stacks.  The permutation is applied wherever a global address
-// is formed from a state index and nowhere else.
+// streaming of the (M,N,xdim,xdim) stacks; the next stage's matrices are prefetched while the
+// current stage computes.  The permutation is applied wherever a global address is formed from a
+// state index and nowhere else.
+//
+// Factor storage of this path (private to it): a.K = gains (udim x xdim, col-major),
+// a.Hinv = Cholesky factor of Huu, col-major lower triangle with RECIPROCAL diagonal.
 //
 // Reference semantics: same Newton system as kernels_generic.hip (PMPC.jl/src/lqp_utils.jl:2-393).
 #include "pmpc_dev.h"
@@ -57,14 +63,36 @@ __device__ __forceinline__ double grp_allsum(double v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps
+__device__ __forceinline__ double rsqrt_d(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  double h = 0.5 * d;
+  r = r * (1.5 - h * r * r);
+  r = r * (1.5 - h * r * r);
+  return r;
+}
+__device__ __forceinline__ const double *badd(const double *p, long long bytes) {
+  return (const double *)((const char *)p + bytes);
+}
+__device__ __forceinline__ double ldo(const double *base, unsigned boff) {  // uniform base + 32-bit byte offset
+  return *(const double *)((const char *)base + boff);
+}
+
+// unconditional load from a per-lane VALID address, zeroed by a select (no exec-mask branch);
+// `rv` guards padding rows (only when xdim is not a multiple of 4, where p[r] could leave the block)
+template <bool PADX>
+__device__ __forceinline__ double ldsel(const double *p, bool keep, bool rv) {
+  if (PADX) return (keep && rv) ? *p : 0.0;
+  const double t = *p;
+  return keep ? t : 0.0;
+}
 
 template <int XD, int UD>
 struct Lane {
   static constexpr int KS = (XD + 3) / 4, XP = 4 * KS;
-  int i, c, g, oc, cb, row0;
+  int c, g, oc, cb, row0;
   bool cxv, cu;
   __device__ explicit Lane(int lane) {
-    i = blockIdx.x;
     c = lane & 15;
     g = lane >> 4;
     oc = (c & 3) * KS + (c >> 2);  // original state index of kernel column c
@@ -75,26 +103,6 @@ struct Lane {
   }
 };
 
-// Fr[r] = F[g + 4r][c], F = [A~ | B~] with A~ = fx_j (0 at stage 0), B~ = fu_j
-template <int XD, int UD>
-__device__ __forceinline__ void load_F(const LQArgs &a, const Lane<XD, UD> &L, int j, double *Fr) {
-  constexpr int KS = Lane<XD, UD>::KS;
-  const size_t blk = (size_t)L.i * a.N + j;
-  const double *p = L.cxv ? a.fx + blk * (XD * XD) + XD * L.oc : a.fu + blk * (XD * UD) + XD * (L.cu ? L.cb : 0);
-  const bool ld = (L.cxv && j > 0) || L.cu;
-#pragma unroll
-  for (int r = 0; r < KS; r++) Fr[r] = (ld && L.row0 + r < XD) ? p[L.row0 + r] : 0.0;
-}
-
-// C-layout registers of the (symmetric) state cost block Q_j
-template <int XD, int UD>
-__device__ __forceinline__ void load_Q(const LQArgs &a, const Lane<XD, UD> &L, int j, double *Qr) {
-  constexpr int KS = Lane<XD, UD>::KS;
-  const double *p = a.Q + ((size_t)L.i * a.N + j) * (XD * XD) + XD * (L.cxv ? L.oc : 0);
-#pragma unroll
-  for (int r = 0; r < KS; r++) Qr[r] = (L.cxv && L.row0 + r < XD) ? p[L.row0 + r] : 0.0;
-}
-
 // s_row[r] = s_col of the lane that owns kernel column g + 4r (same k-group)
 template <int KS>
 __device__ __forceinline__ void col_to_row(double s_col, int g, double *s_row) {
@@ -104,49 +112,97 @@ __device__ __forceinline__ void col_to_row(double s_col, int g, double *s_row) {
 
 template <int UD>
 __device__ __forceinline__ double pick(const double (&v)[UD], int k) {
-  double o = 0.0;
+  double o = v[0];
 #pragma unroll
-  for (int b = 0; b < UD; b++) o = (k == b) ? v[b] : o;
+  for (int b = 1; b < UD; b++) o = (k == b) ? v[b] : o;
   return o;
+}
+
+// y = (L L')^-1 y with L given as strict lower part + reciprocal diagonal
+template <int UD>
+__device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const double (&Ld)[UD], double (&y)[UD]) {
+#pragma unroll
+  for (int p = 0; p < UD; p++) {
+    double v = y[p];
+#pragma unroll
+    for (int k = 0; k < p; k++) v -= Lc[p][k] * y[k];
+    y[p] = v * Ld[p];
+  }
+#pragma unroll
+  for (int p = UD - 1; p >= 0; p--) {
+    double v = y[p];
+#pragma unroll
+    for (int k = p + 1; k < UD; k++) v -= Lc[k][p] * y[k];
+    y[p] = v * Ld[p];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward sweep (see kernels_generic.hip for the FACTOR / vector-only protocol)
+//   HXB: state bounds active (Dx, wx valid)   HUB: control bounds active (Du, wu valid)
 // ------------------------------------------------------------------------------------------------
-template <int XD, int UD, bool FACTOR>
+template <int XD, int UD, bool FACTOR, bool HXB, bool HUB>
 __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
+  constexpr bool PADX = (XD != XP);
   const int lane = threadIdx.x;
   const LT L(lane);
-  const int N = a.N, Nc = a.Nc, i = L.i, g = L.g, c = L.c;
+  const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
   const size_t pbase = (size_t)i * N;
   const bool own0 = (i == 0 && a.owner);
+  const bool gu = g < UD;
+  const bool diag_x = L.cxv && ((c & 3) == g);  // kernel row g + 4r == c for r = c >> 2
+  const int diag_r = c >> 2;
 
-  double S[KS], s_row[KS], Qn[KS];
+  // ---- per-lane pointers / byte offsets at stage N-1, decremented by constant strides ----------------
+  // matrices: 64-bit per-lane pointers (stacks may exceed 4 GB); every lane gets a VALID address and
+  // the value is zeroed by a select where the lane has no entry.
+  const long long sF = -(long long)sizeof(double) * (L.cxv ? XD * XD : XD * UD);
+  const double *pF = L.cxv ? a.fx + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0
+                           : a.fu + (pbase + N - 1) * (XD * UD) + XD * (L.cu ? L.cb : 0) + L.row0;
+  const bool ldF = L.cxv || L.cu;
+  const double *pQ = a.Q + (pbase + N - 1) * (XD * XD) + XD * (L.cxv ? L.oc : 0) + L.row0;
+  const double *pR = a.R + (pbase + N - 1) * (UD * UD) + (gu ? g : 0) + UD * (L.cu ? L.cb : 0);
+  double *pK = a.K + (pbase + N - 1) * (UD * XD) + (gu ? g : 0) + UD * (L.cxv ? L.oc : 0);
+  double *pL = a.Hinv + (pbase + N - 1) * (UD * UD);
+  // vectors: uniform base + 32-bit byte offsets (lq_fast_supported bounds the array sizes)
+  unsigned ox_row = (unsigned)(((pbase + N - 1) * XD + L.row0) * sizeof(double));
+  unsigned ox_col = (unsigned)(((pbase + N - 1) * XD + (L.cxv ? L.oc : 0)) * sizeof(double));
+  unsigned ou_g = (unsigned)(((pbase + N - 1) * UD + (gu ? g : 0)) * sizeof(double));
+  unsigned ou_c = (unsigned)(((pbase + N - 1) * UD + (L.cu ? L.cb : 0)) * sizeof(double));
+  unsigned ou_0 = (unsigned)(((pbase + N - 1) * UD) * sizeof(double));
+  constexpr unsigned SX = XD * sizeof(double), SU = UD * sizeof(double);
+
+  double S[KS], s_row[KS], Qn[KS], Fn[KS];
   double s_col;
 
-  // ---- terminal: S = Q~_{N-1} (+Dx), s = g_x,N-1 ----------------------------------------------------
+  // ---- terminal: S = Q~_{N-1} (+Dx), s = g_x,N-1 ; prefetch F_{N-1} -----------------------------------
   {
-    const int jj = N - 1;
+    {
+      const bool ld0 = (L.cxv && N - 1 > 0) || L.cu;
+#pragma unroll
+      for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, ld0, L.row0 + r < XD);
+    }
+    (void)ldF;
     double gsum = 0.0;
     if (FACTOR) {
-      load_Q<XD, UD>(a, L, jj, Qn);
-      const double *X = a.X + (pbase + jj) * XD, *Xr = a.X_ref + (pbase + jj) * XD, *Xp = a.X_prev + (pbase + jj) * XD;
       double part = 0.0;
 #pragma unroll
       for (int r = 0; r < KS; r++) {
-        const int ro = L.row0 + r;
-        const double xm = ro < XD ? X[ro] - Xr[ro] : 0.0;
+        const bool rv = !PADX || (L.row0 + r < XD);
+        Qn[r] = ldsel<PADX>(pQ + r, L.cxv, rv);
+        const unsigned o = rv ? ox_row + r * 8u : ox_row;
+        const double xm = rv ? ldo(a.X, o) - ldo(a.X_ref, o) : 0.0;
         part += Qn[r] * xm;
-        double d = 0.0;
-        if (L.cxv && g + 4 * r == c) d = a.reg_x + (a.Dx ? a.Dx[(pbase + jj) * XD + L.oc] : 0.0);
-        S[r] = Qn[r] + d;
       }
-      gsum = grp_allsum(part);
-      if (L.cxv) gsum += a.reg_x * (X[L.oc] - Xp[L.oc]);
+      double dd = a.reg_x;
+      if (HXB) dd += ldo(a.Dx, ox_col);
+#pragma unroll
+      for (int r = 0; r < KS; r++) S[r] = Qn[r] + ((diag_x && diag_r == r) ? dd : 0.0);
+      gsum = grp_allsum(part) + a.reg_x * (ldo(a.X, ox_col) - ldo(a.X_prev, ox_col));
     }
-    if (L.cxv && a.wx) gsum += a.wx[(pbase + jj) * XD + L.oc];
+    if (HXB) gsum += ldo(a.wx, ox_col);
     s_col = L.cxv ? gsum : 0.0;
     col_to_row<KS>(s_col, g, s_row);
   }
@@ -154,50 +210,64 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   for (int j = N - 1; j >= 0; j--) {
     const bool cons = j < Nc;
     double Fr[KS];
-    load_F<XD, UD>(a, L, j, Fr);
-    const double *Uj = a.U + (pbase + j) * UD;
+#pragma unroll
+    for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
 
-    // ---- control-side gradient pieces -------------------------------------------------------------
-    double Rraw = 0.0, hp = 0.0;
+    // ---- loads of this stage: control-side vectors, R_j, and the state side of stage j-1 ------------
+    double Rraw = 0.0, um_g = 0.0, ud_c = 0.0, Du_c = 0.0;
+    if (FACTOR) {
+      Rraw = (L.cu && gu) ? *pR : 0.0;
+      um_g = gu ? ldo(a.U, ou_g) - ldo(a.U_ref, ou_g) : 0.0;
+      ud_c = a.reg_u * (ldo(a.U, ou_c) - ldo(a.U_prev, ou_c));
+      if (HUB) Du_c = ldo(a.Du, ou_c);
+    }
+    if (HUB) ud_c += ((!cons || own0) ? ldo(a.wu, ou_c) : 0.0);
+    // prefetch next stage's dynamics (F_{j-1}; its state columns are zero at stage 0)
+    if (j > 0) {
+      pF = badd(pF, sF);
+      const bool ldn = (L.cxv && j - 1 > 0) || L.cu;
+#pragma unroll
+      for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, ldn, L.row0 + r < XD);
+    }
+    double xm_row[KS], xd_c = 0.0, Dx_c = 0.0;
+    if (j > 0) {
+      ox_row -= SX;
+      ox_col -= SX;
+      if (FACTOR) {
+        pQ -= XD * XD;
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          const bool rv = !PADX || (L.row0 + r < XD);
+          Qn[r] = ldsel<PADX>(pQ + r, L.cxv, rv);
+          const unsigned o = rv ? ox_row + r * 8u : ox_row;
+          xm_row[r] = rv ? ldo(a.X, o) - ldo(a.X_ref, o) : 0.0;
+        }
+        xd_c = a.reg_x * (ldo(a.X, ox_col) - ldo(a.X_prev, ox_col));
+        if (HXB) Dx_c = ldo(a.Dx, ox_col);
+      }
+      if (HXB) xd_c += ldo(a.wx, ox_col);
+    }
+
+    // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
+    double hp = Rraw * um_g;
 #pragma unroll
     for (int r = 0; r < KS; r++) hp += Fr[r] * s_row[r];
-    if (FACTOR) {
-      if (L.cu && g < UD) {
-        Rraw = a.R[(pbase + j) * (UD * UD) + g + UD * L.cb];
-        hp += Rraw * (Uj[g] - a.U_ref[(pbase + j) * UD + g]);
-      }
-    }
     double h_col = grp_allsum(hp);
-    if (L.cu) {
-      if (FACTOR) h_col += a.reg_u * (Uj[L.cb] - a.U_prev[(pbase + j) * UD + L.cb]);
-      if (a.wu && (!cons || own0)) h_col += a.wu[(pbase + j) * UD + L.cb];
-    }
+    if (L.cu) h_col += ud_c;
     double hu[UD];
 #pragma unroll
     for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
 
-    double Kreg = 0.0, Hinv[UD][UD];
+    double Kreg = 0.0, Lc[UD][UD], Ld[UD];
     v4d H = {0.0, 0.0, 0.0, 0.0};
     if (FACTOR) {
-      // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) --------------------------------------------------
-      if (j > 0) load_Q<XD, UD>(a, L, j - 1, Qn);
+      // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) ------------------------------------------------------
+      if (j > 0) {
+        const double dd = a.reg_x + Dx_c;
 #pragma unroll
-      for (int r = 0; r < KS; r++) {
-        double v = 0.0;
-        if (j > 0) {
-          v = Qn[r];
-          if (L.cxv && g + 4 * r == c) v += a.reg_x + (a.Dx ? a.Dx[(pbase + j - 1) * XD + L.oc] : 0.0);
-        }
-        H[r] = v;
+        for (int r = 0; r < KS; r++) H[r] = Qn[r] + ((diag_x && diag_r == r) ? dd : 0.0);
       }
-      {
-        double v = Rraw;
-        if (L.cu && g == L.cb) {
-          v += a.reg_u;
-          if (a.Du && !cons) v += a.Du[(pbase + j) * UD + L.cb];
-        }
-        H[KS] = v;
-      }
+      H[KS] = Rraw + ((L.cu && g == L.cb) ? a.reg_u + (cons ? 0.0 : Du_c) : 0.0);
       v4d G = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
@@ -206,178 +276,182 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     }
 
     if (cons) {
-      // ---- consensus stage (Nc == 1, j == 0): export the per-particle condensed (H_i, g_i) -------
+      // ---- consensus stage (Nc == 1, j == 0): export the per-particle condensed (H_i, g_i) ----------
       if (FACTOR) {
-        double Huu[UD][UD];
-#pragma unroll
-        for (int p = 0; p < UD; p++)
-#pragma unroll
-          for (int q = 0; q < UD; q++) Huu[p][q] = readlane_d(H[KS], (XP + q) + 16 * p);
-        if (lane < UD * UD) {
-          double v = 0.0;
-#pragma unroll
-          for (int p = 0; p < UD; p++)
-#pragma unroll
-            for (int q = 0; q < UD; q++) v = (lane == p + UD * q) ? Huu[p][q] : v;
-          if (own0 && a.Du && (lane % UD) == (lane / UD)) v += a.Du[(pbase + j) * UD + lane % UD];
-          a.Hc_part[(size_t)i * (UD * UD) + lane] = v;
-        }
+        // Hc_part[i][p + UD q] = Huu[p][q] lives in lane (XP + q, p), register KS
+        double v = H[KS];
+        if (own0 && HUB && L.cu && g == L.cb) v += Du_c;
+        if (L.cu && gu) a.Hc_part[(size_t)i * (UD * UD) + g + UD * L.cb] = v;
       }
       if (lane < UD) a.gc_part[(size_t)i * UD + lane] = pick<UD>(hu, lane);
       break;
     }
 
     if (FACTOR) {
-      // ---- Huu^-1 by Cholesky on lane-uniform values ---------------------------------------------
-      double Lc[UD][UD], Li[UD][UD];
-#pragma unroll
-      for (int p = 0; p < UD; p++)
-#pragma unroll
-        for (int q = 0; q <= p; q++) Lc[p][q] = readlane_d(H[KS], (XP + q) + 16 * p);
+      // ---- Cholesky of Huu on lane-uniform values (readlane broadcast of the lower triangle) --------
       bool bad = false;
 #pragma unroll
       for (int q = 0; q < UD; q++) {
-        double d = Lc[q][q];
 #pragma unroll
-        for (int k = 0; k < q; k++) d -= Lc[q][k] * Lc[q][k];
-        bad |= !(d > 0.0);
-        d = sqrt(d);
-        const double inv = 1.0 / d;
-        Lc[q][q] = d;
-        Li[q][q] = inv;
-#pragma unroll
-        for (int p = q + 1; p < UD; p++) {
-          double v = Lc[p][q];
+        for (int p = q; p < UD; p++) {
+          double v = readlane_d(H[KS], (XP + q) + 16 * p);  // Huu[p][q]
 #pragma unroll
           for (int k = 0; k < q; k++) v -= Lc[p][k] * Lc[q][k];
-          Lc[p][q] = v * inv;
+          if (p == q) {
+            bad |= !(v > 0.0);
+            Ld[q] = rsqrt_d(v);
+          } else {
+            Lc[p][q] = v * Ld[q];
+          }
         }
       }
       if (bad && lane == 0) *a.fail = 2;
+      // ---- K = Huu^-1 Hux: gather the control rows column-wise, substitute in-lane ------------------
+      double col[UD];
+#pragma unroll
+      for (int k = 0; k < UD; k++) col[k] = __shfl(H[KS], c + 16 * k, 64);  // H[XP + k][c]
+      chol_solve<UD>(Lc, Ld, col);
+      const double Kg = pick<UD>(col, g);
+      Kreg = (L.cxv && gu) ? Kg : 0.0;
+      v4d Sn = mfma(H[KS], gu ? -Kg : 0.0, H);  // S' = Hxx - Hxu K (columns >= XP are never used)
+#pragma unroll
+      for (int r = 0; r < KS; r++) S[r] = Sn[r];
+      if (L.cxv && gu) *pK = Kreg;
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < UD; q++)
+#pragma unroll
+          for (int p = q; p < UD; p++) pL[p + UD * q] = (p == q) ? Ld[q] : Lc[p][q];
+      }
+    } else {
+      Kreg = (L.cxv && gu) ? *pK : 0.0;
 #pragma unroll
       for (int q = 0; q < UD; q++)
 #pragma unroll
-        for (int p = q + 1; p < UD; p++) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = q; k < p; k++) v += Lc[p][k] * Li[k][q];
-          Li[p][q] = -v * Li[p][p];
+        for (int p = q; p < UD; p++) {
+          const double v = pL[p + UD * q];
+          if (p == q) Ld[q] = v;
+          else Lc[p][q] = v;
         }
-#pragma unroll
-      for (int p = 0; p < UD; p++)
-#pragma unroll
-        for (int q = 0; q <= p; q++) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = p; k < UD; k++) v += Li[k][p] * Li[k][q];
-          Hinv[p][q] = v;
-          Hinv[q][p] = v;
-        }
-      // ---- K = Huu^-1 Hux, S' = Hxx - Hxu K -------------------------------------------------------
-      double av = 0.0;
-#pragma unroll
-      for (int p = 0; p < UD; p++)
-#pragma unroll
-        for (int q = 0; q < UD; q++) av = (c == p && g == q) ? Hinv[p][q] : av;
-      v4d Kacc = {0.0, 0.0, 0.0, 0.0};
-      Kacc = mfma(av, H[KS], Kacc);
-      Kreg = (L.cxv && g < UD) ? Kacc[0] : 0.0;
-      v4d Sn = mfma(H[KS], -Kacc[0], H);
-#pragma unroll
-      for (int r = 0; r < KS; r++) S[r] = Sn[r];
-      if (L.cxv && g < UD) a.K[(pbase + j) * (UD * XD) + g + UD * L.oc] = Kreg;
-      if (lane < UD * UD) {
-        double v = 0.0;
-#pragma unroll
-        for (int p = 0; p < UD; p++)
-#pragma unroll
-          for (int q = 0; q < UD; q++) v = (lane == p + UD * q) ? Hinv[p][q] : v;
-        a.Hinv[(pbase + j) * (UD * UD) + lane] = v;
-      }
-    } else {
-      if (L.cxv && g < UD) Kreg = a.K[(pbase + j) * (UD * XD) + g + UD * L.oc];
-      const double *Hg = a.Hinv + (pbase + j) * (UD * UD);
-#pragma unroll
-      for (int p = 0; p < UD; p++)
-#pragma unroll
-        for (int q = 0; q < UD; q++) Hinv[p][q] = Hg[p + UD * q];
     }
 
-    // ---- feed-forward k = Huu^-1 hu and s_{j-1} = h_x - K' hu + g_x,j-1 ---------------------------
-    if (lane < UD) {
-      double kv[UD];
+    // ---- feed-forward k = Huu^-1 hu and s_{j-1} = h_x - K' hu + g_x,j-1 -----------------------------
+    const double hug = pick<UD>(hu, g);
+    chol_solve<UD>(Lc, Ld, hu);
+    if (lane == 0) {
 #pragma unroll
-      for (int p = 0; p < UD; p++) {
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < UD; q++) v += Hinv[p][q] * hu[q];
-        kv[p] = v;
-      }
-      a.kff[(pbase + j) * UD + lane] = pick<UD>(kv, lane);
+      for (int b = 0; b < UD; b++) *(double *)((char *)a.kff + ou_0 + b * 8u) = hu[b];
     }
     if (j == 0) break;
-    double p2 = -Kreg * pick<UD>(hu, g);
-    double add = 0.0;
+    double p2 = -Kreg * hug;
     if (FACTOR) {
-      const double *X = a.X + (pbase + j - 1) * XD, *Xr = a.X_ref + (pbase + j - 1) * XD, *Xp = a.X_prev + (pbase + j - 1) * XD;
 #pragma unroll
-      for (int r = 0; r < KS; r++) {
-        const int ro = L.row0 + r;
-        const double xm = ro < XD ? X[ro] - Xr[ro] : 0.0;
-        p2 += Qn[r] * xm;
-      }
-      if (L.cxv) add = a.reg_x * (X[L.oc] - Xp[L.oc]);
+      for (int r = 0; r < KS; r++) p2 += Qn[r] * xm_row[r];
     }
-    if (L.cxv && a.wx) add += a.wx[(pbase + j - 1) * XD + L.oc];
     const double red2 = grp_allsum(p2);
-    s_col = L.cxv ? h_col + red2 + add : 0.0;
+    s_col = L.cxv ? h_col + red2 + xd_c : 0.0;
     col_to_row<KS>(s_col, g, s_row);
+    pR -= UD * UD;
+    pK -= UD * XD;
+    pL -= UD * UD;
+    ou_g -= SU;
+    ou_c -= SU;
+    ou_0 -= SU;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward sweep
+// forward sweep (ROLLOUT: absolute linear rollout X from U, PMPC.jl/src/types.jl:161-173)
 // ------------------------------------------------------------------------------------------------
-template <int XD, int UD>
-__global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a) {
+template <int XD, int UD, bool ROLLOUT>
+__global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, double *Xout) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
+  constexpr bool PADX = (XD != LT::XP);
   const int lane = threadIdx.x;
   const LT L(lane);
-  const int N = a.N, Nc = a.Nc, i = L.i, g = L.g, c = L.c;
+  const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
   const size_t pbase = (size_t)i * N;
-  double xcol = 0.0;  // dx[oc] on valid state columns
+  const bool gu = g < UD;
+  const long long sF = (long long)sizeof(double) * (L.cxv ? XD * XD : XD * UD);
+  const double *pF = L.cxv ? a.fx + pbase * (XD * XD) + XD * L.oc + L.row0
+                           : a.fu + pbase * (XD * UD) + XD * (L.cu ? L.cb : 0) + L.row0;
+  const bool ldF = L.cxv || L.cu;
+  const double *pK = a.K + pbase * (UD * XD) + (gu ? g : 0) + UD * (L.cxv ? L.oc : 0);
+  unsigned ox_row = (unsigned)((pbase * XD + L.row0) * sizeof(double));
+  unsigned ou_g = (unsigned)((pbase * UD + (gu ? g : 0)) * sizeof(double));
+  unsigned ou_c = (unsigned)((pbase * UD + (L.cu ? L.cb : 0)) * sizeof(double));
+  unsigned ou_0 = (unsigned)((pbase * UD) * sizeof(double));
+  constexpr unsigned SX = XD * sizeof(double), SU = UD * sizeof(double);
+
+  double xcol = 0.0;  // dx[oc] on valid state columns (ROLLOUT: X_{j-1} - X_prev_{j-1})
+  double Fn[KS], Kn = 0.0, kn = 0.0;  // next stage's F, gains and feed-forward (prefetched one stage ahead)
+#pragma unroll
+  for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, L.cu, L.row0 + r < XD);  // stage 0: state columns are zero
+  if (!ROLLOUT && Nc == 0) {
+    Kn = (L.cxv && gu) ? *pK : 0.0;
+    kn = gu ? ldo(a.kff, ou_g) : 0.0;
+  }
   for (int j = 0; j < N; j++) {
     double Fr[KS];
-    load_F<XD, UD>(a, L, j, Fr);
-    double du[UD];
-    if (j < Nc) {
 #pragma unroll
-      for (int b = 0; b < UD; b++) du[b] = a.duc[j * UD + b];
-    } else {
-      double Kreg = 0.0;
-      if (L.cxv && g < UD) Kreg = a.K[(pbase + j) * (UD * XD) + g + UD * L.oc];
-      const double sum = row_allsum(Kreg * xcol);
-      const double dug = g < UD ? -sum - a.kff[(pbase + j) * UD + g] : 0.0;
+    for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
+    const double Kreg = Kn, kreg = kn;
+    if (j + 1 < N) {
+      pF = badd(pF, sF);
 #pragma unroll
-      for (int b = 0; b < UD; b++) du[b] = readlane_d(dug, 16 * b);
+      for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, ldF, L.row0 + r < XD);
+      if (!ROLLOUT) {
+        pK += UD * XD;
+        Kn = (L.cxv && gu && j + 1 >= Nc) ? *pK : 0.0;
+        kn = (gu && j + 1 >= Nc) ? ldo(a.kff, ou_g + SU) : 0.0;
+      }
     }
-    const double ycol = L.cxv ? xcol : (L.cu ? pick<UD>(du, L.cb) : 0.0);
+    double ycol;
+    double du[UD];
+    if (ROLLOUT) {
+      ycol = L.cxv ? xcol : (L.cu ? ldo(Uin, ou_c) - ldo(a.U_prev, ou_c) : 0.0);
+    } else {
+      if (j < Nc) {
+#pragma unroll
+        for (int b = 0; b < UD; b++) du[b] = a.duc[j * UD + b];
+      } else {
+        const double sum = row_allsum(Kreg * xcol);
+        const double dug = gu ? -sum - kreg : 0.0;
+#pragma unroll
+        for (int b = 0; b < UD; b++) du[b] = readlane_d(dug, 16 * b);
+      }
+      ycol = L.cxv ? xcol : (L.cu ? pick<UD>(du, L.cb) : 0.0);
+    }
     double xr[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) xr[r] = row_allsum(Fr[r] * ycol);
-    if (c == 0) {
+    if (ROLLOUT) {
+      // X_j = f_j + fx (X_{j-1} - Xp_{j-1}) + fu (U_j - Up_j); next xcol needs X_j - X_prev_j
 #pragma unroll
-      for (int r = 0; r < KS; r++)
-        if (L.row0 + r < XD) {
-          double *o = a.dX + (pbase + j) * XD + L.row0 + r;
-          *o = a.accumulate ? *o + xr[r] : xr[r];
+      for (int r = 0; r < KS; r++) {
+        const bool rv = L.row0 + r < XD;
+        const unsigned o = rv ? ox_row + r * 8u : ox_row;
+        const double xj = xr[r] + ldo(a.f, o);
+        if (c == 0 && rv) *(double *)((char *)Xout + o) = xj;
+        xr[r] = xj - ldo(a.X_prev, o);
+      }
+    } else {
+      if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < KS; r++)
+          if (L.row0 + r < XD) {
+            double *o = (double *)((char *)a.dX + ox_row + r * 8u);
+            *o = a.accumulate ? *o + xr[r] : xr[r];
+          }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < UD; b++) {
+          double *o = (double *)((char *)a.dU + ou_0 + b * 8u);
+          *o = a.accumulate ? *o + du[b] : du[b];
         }
-    }
-    if (lane < UD) {
-      double *o = a.dU + (pbase + j) * UD + lane;
-      const double v = pick<UD>(du, lane);
-      *o = a.accumulate ? *o + v : v;
+      }
     }
     // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2
     double nx = 0.0;
@@ -387,26 +461,49 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a) {
       nx = ((c >> 2) == r) ? t : nx;
     }
     xcol = L.cxv ? nx : 0.0;
+    ox_row += SX;
+    ou_g += SU;
+    ou_c += SU;
+    ou_0 += SU;
   }
 }
 
 template <int XD, int UD>
 void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
-  if (factor) hipLaunchKernelGGL((k_bwd_fast<XD, UD, true>), dim3(a.M), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((k_bwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a);
+  const bool xb = a.wx != nullptr, ub = a.wu != nullptr;
+  const dim3 grd(a.M), blk(64);
+#define PMPC_BWD(F, XB, UB) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB>), grd, blk, 0, s, a)
+  if (factor) {
+    if (xb && ub) PMPC_BWD(true, true, true);
+    else if (xb) PMPC_BWD(true, true, false);
+    else if (ub) PMPC_BWD(true, false, true);
+    else PMPC_BWD(true, false, false);
+  } else {
+    if (xb && ub) PMPC_BWD(false, true, true);
+    else if (xb) PMPC_BWD(false, true, false);
+    else if (ub) PMPC_BWD(false, false, true);
+    else PMPC_BWD(false, false, false);
+  }
+#undef PMPC_BWD
 }
 template <int XD, int UD>
 void launch_fwd_t(const LQArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL((k_fwd_fast<XD, UD>), dim3(a.M), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
+}
+template <int XD, int UD>
+void launch_rollout_t(const LQArgs &a, const double *U, double *X, hipStream_t s) {
+  hipLaunchKernelGGL((k_fwd_fast<XD, UD, true>), dim3(a.M), dim3(64), 0, s, a, U, X);
 }
 
 }  // namespace
 
 // (xdim, udim) pairs with compiled instances
-#define PMPC_FAST_DIMS(X) X(12, 4) X(4, 2) X(2, 1) X(3, 2) X(5, 3) X(6, 2) X(8, 4) X(4, 4) X(6, 3) X(10, 4) X(8, 2) X(4, 1) X(3, 1)
+#define PMPC_FAST_DIMS(X) X(12, 4) X(4, 2) X(2, 1) X(3, 2) X(5, 3) X(6, 2) X(8, 4)
 
 bool lq_fast_supported(const LQArgs &a) {
   if (a.w != 0 || a.any_slew || a.Nc > 1 || !a.sym_cost) return false;
+  // vector arrays are addressed with 32-bit byte offsets
+  if ((size_t)a.M * a.N * (size_t)(a.x > a.u ? a.x : a.u) * sizeof(double) >= (1ull << 31)) return false;
 #define X(xd, ud) if (a.x == xd && a.u == ud) return true;
   PMPC_FAST_DIMS(X)
 #undef X
@@ -422,6 +519,13 @@ void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s) {
 
 void launch_fwd_fast(const LQArgs &a, hipStream_t s) {
 #define X(xd, ud) if (a.x == xd && a.u == ud) { launch_fwd_t<xd, ud>(a, s); return; }
+  PMPC_FAST_DIMS(X)
+#undef X
+  abort();
+}
+
+void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s) {
+#define X(xd, ud) if (a.x == xd && a.u == ud) { launch_rollout_t<xd, ud>(a, U, X, s); return; }
   PMPC_FAST_DIMS(X)
 #undef X
   abort();

@@ -245,58 +245,79 @@ __global__ void __launch_bounds__(TB) k_ipm_update(Slab s, const IpmScal *sc) {
   }
 }
 
-__global__ void k_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt,
-                              const double *part_max, int nb) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// 64-lane deterministic reductions of the block partials (fixed order: lane-strided, then butterfly)
+__device__ __forceinline__ double wave_sum(const double *p, int nb) {
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 64) v += p[b];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(const double *p, int nb) {
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 64) v = fmax(v, p[b]);
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ void __launch_bounds__(64) k_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt,
+                                                    const double *part_max, int nb) {
   const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
+  const bool l0 = threadIdx.x == 0;
   switch (stage) {
     case 0:
-      sc->comp_sum = sc->cnt = sc->muaff_sum = sc->pad0 = 0.0;
-      sc->res_max = sc->viol_max = 0.0;
-      sc->amin_bits = one_bits;
-      sc->mu = sc->sigma = sc->sigmu = 0.0;
-      sc->alpha_aff = sc->alpha = 1.0;
-      sc->nu = 1.0;
-      sc->iter = 0;
-      sc->status = 0;
+      if (l0) {
+        sc->comp_sum = sc->cnt = sc->muaff_sum = sc->pad0 = 0.0;
+        sc->res_max = sc->viol_max = 0.0;
+        sc->amin_bits = one_bits;
+        sc->mu = sc->sigma = sc->sigmu = 0.0;
+        sc->alpha_aff = sc->alpha = 1.0;
+        sc->nu = 1.0;
+        sc->iter = 0;
+        sc->status = 0;
+      }
       break;
     case 1: {
-      double m = 0.0;
-      for (int b = 0; b < nb; b++) m = fmax(m, part_max[b]);
-      sc->viol_max = m;
+      const double m = wave_max(part_max, nb);
+      if (l0) sc->viol_max = m;
     } break;
     case 2: {
-      double s = 0.0, c = 0.0, m = 0.0;
-      for (int b = 0; b < nb; b++) { s += part_sum[b]; c += part_cnt[b]; m = fmax(m, part_max[b]); }
-      sc->comp_sum = s; sc->cnt = c; sc->res_max = m;
+      const double s = wave_sum(part_sum, nb), c = wave_sum(part_cnt, nb), m = wave_max(part_max, nb);
+      if (l0) { sc->comp_sum = s; sc->cnt = c; sc->res_max = m; }
     } break;
     case 3:
-      sc->mu = sc->comp_sum / fmax(sc->cnt, 1.0);
-      sc->amin_bits = one_bits;
+      if (l0) {
+        sc->mu = sc->comp_sum / fmax(sc->cnt, 1.0);
+        sc->amin_bits = one_bits;
+      }
       break;
     case 4:
-      sc->alpha_aff = __longlong_as_double((long long)sc->amin_bits);
-      sc->amin_bits = one_bits;
+      if (l0) {
+        sc->alpha_aff = __longlong_as_double((long long)sc->amin_bits);
+        sc->amin_bits = one_bits;
+      }
       break;
     case 5: {
-      double s = 0.0;
-      for (int b = 0; b < nb; b++) s += part_sum[b];
-      sc->muaff_sum = s;
+      const double s = wave_sum(part_sum, nb);
+      if (l0) sc->muaff_sum = s;
     } break;
-    case 6: {
-      double mu_aff = sc->muaff_sum / fmax(sc->cnt, 1.0);
-      double r = mu_aff / sc->mu;
-      sc->sigma = r * r * r;
-      sc->sigmu = sc->sigma * sc->mu;
-    } break;
-    case 7: {
-      double a = __longlong_as_double((long long)sc->amin_bits);
-      if (a < 1.0) a = fmin(1.0, fmax(0.99, 1.0 - sc->mu) * a);
-      sc->alpha = a;
-      sc->nu *= (1.0 - a);
-      sc->iter += 1;
-      sc->amin_bits = one_bits;
-    } break;
+    case 6:
+      if (l0) {
+        double mu_aff = sc->muaff_sum / fmax(sc->cnt, 1.0);
+        double r = mu_aff / sc->mu;
+        sc->sigma = r * r * r;
+        sc->sigmu = sc->sigma * sc->mu;
+      }
+      break;
+    case 7:
+      if (l0) {
+        double a = __longlong_as_double((long long)sc->amin_bits);
+        if (a < 1.0) a = fmin(1.0, fmax(0.99, 1.0 - sc->mu) * a);
+        sc->alpha = a;
+        sc->nu *= (1.0 - a);
+        sc->iter += 1;
+        sc->amin_bits = one_bits;
+      }
+      break;
   }
 }
 

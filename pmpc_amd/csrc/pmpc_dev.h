@@ -91,6 +91,7 @@ void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, in
 bool lq_fast_supported(const LQArgs &a);
 void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_fast(const LQArgs &a, hipStream_t s);
+void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s);

@@ -336,7 +336,8 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   // ---- 1. equality-only optimum: one Newton step from a dynamics-consistent base point -----------
   launch_ipm_scalars(0, sc, nullptr, nullptr, nullptr, 0, s);
   launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
-  launch_rollout(a, w.U.d(), w.X.d(), s);
+  if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+  else launch_rollout(a, w.U.d(), w.X.d(), s);
   a.Dx = a.Du = a.wx = a.wu = nullptr;
   structured_solve(c, a, true, fast);
   inf.structured_solves = 1;
@@ -404,7 +405,8 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   // ---- 2. Mehrotra predictor-corrector on the boxes ----------------------------------------------
   if (has_ub) {
     launch_ipm_clip(su, s);
-    launch_rollout(a, w.U.d(), w.X.d(), s);
+    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+    else launch_rollout(a, w.U.d(), w.X.d(), s);
   }
   if (has_xb) launch_ipm_init_slack(sx, 1.0, s);
   if (has_ub) launch_ipm_init_slack(su, 1.0, s);

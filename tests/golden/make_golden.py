@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.  Runs ONLY in the build container (needs /root/reference).
+
+What is pinned and by what:
+  * sub-problem fixtures (`qp_*.npz`): the reference's own example / test problem definitions
+    (restated here from the cited lines, numpy-seeded where the reference draws random numbers),
+    solved by the oracle (oracle/lqp_oracle.py) whose KKT certificate is stored alongside.
+  * SCP fixtures (`scp_*.npz`): the REFERENCE's own Python SCP loop, imported from
+    /root/reference (pmpc/scp_mpc.py:205-442) with its torch unicycle (tests/dubins_car.py),
+    run with `pmpc.scp_mpc.aff_solve` replaced by the oracle (the loop looks it up as a module
+    global, scp_mpc.py:370; Julia itself cannot run here).  Stored: final X, U and every `hist` row.
+
+The reference holds no numeric golden vectors for this path: these files pin the
+oracle + host loop against the reference's loop, not against Julia/OSQP output.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+REF = Path("/root/reference")
+
+from oracle import lqp_oracle as orc  # noqa: E402
+
+
+def save(name, **kw):
+    np.savez_compressed(HERE / name, **kw)
+    print("wrote", name, {k: np.shape(v) for k, v in kw.items()})
+
+
+def solve_and_pack(args, kw, Nc):
+    X, U, info = orc.lqp_solve_py(*args, Nc=Nc, return_info=True, **kw)
+    names = ["x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref"]
+    pack = dict(zip(names, args))
+    pack.update({k: np.asarray(v, float) for k, v in kw.items()})
+    pack.update(Nc=np.array(Nc), X=X, U=U, cert=np.array([info["cert"][k] for k in ("stationarity", "equality", "bound_violation", "complementarity")]))
+    return pack
+
+
+# ---- 1. canonical ABI example: tests/pmpcjl_test.py:164-219 (and the u in +-1 variant of
+#         PMPC.jl/src/c_precompile.jl:7-49) --------------------------------------------------------------
+def double_integrator(u_limit):
+    M, N, xdim, udim, Nc = 1, 30, 2, 1, 3
+    x0 = np.array([5.0, 5.0])
+    A = np.array([[1.0, 0.1], [0.0, 1.0]])
+    fx = np.tile(A, (M, N, 1, 1))
+    fu = np.tile(np.array([[0.0], [1.0]]), (M, N, 1, 1))
+    f = np.zeros((M, N, xdim))
+    f[:, 0] = A @ x0
+    zx, zu = np.zeros((M, N, xdim)), np.zeros((M, N, udim))
+    Q = np.tile(np.eye(2), (M, N, 1, 1))
+    R = np.tile(np.eye(1), (M, N, 1, 1))
+    kw = dict(reg_x=1.0, reg_u=0.1, u_l=-u_limit * np.ones((M, N, udim)), u_u=u_limit * np.ones((M, N, udim)),
+              x_l=-20.0 * np.ones((M, N, xdim)), x_u=20.0 * np.ones((M, N, xdim)), slew_reg=np.ones(M), slew_reg0=np.zeros(M),
+              slew_um1=np.zeros((M, udim)))
+    args = (x0[None], f, fx, fu, zx, zu, Q, R, zx.copy(), zu.copy())
+    return args, kw, Nc
+
+
+# ---- 3. chain problem of PMPC.jl/test/test.jl:334-377 (Julia's RNG stream restated with numpy) ----------
+def chain(rng, M=100, N=30):
+    xdim, udim = 4, 2
+    x0 = np.full(4, 5.0)
+    fx, fu, f = np.zeros((M, N, 4, 4)), np.zeros((M, N, 4, 2)), np.zeros((M, N, 4))
+    for i in range(M):
+        r1, r2 = rng.choice(np.linspace(0.1, 0.9, 10), 2)
+        A = np.array([[1, r1, 0, 0], [0, 1, 0, 0], [0, 0, 1, r2], [0, 0, 0, 1.0]])
+        fx[i], fu[i] = A, np.array([[0, 0], [1, 0], [0, 0], [0, 1.0]])
+        f[i, 0] = A @ x0
+    zx, zu = np.zeros((M, N, xdim)), np.zeros((M, N, udim))
+    Q, R = np.tile(np.eye(4), (M, N, 1, 1)), np.tile(np.eye(2), (M, N, 1, 1))
+    kw = dict(reg_x=0.0, reg_u=0.0, u_l=-np.ones((M, N, udim)), u_u=np.ones((M, N, udim)))
+    return (np.tile(x0, (M, 1)), f, fx, fu, zx, zu, Q, R, zx.copy(), zu.copy()), kw
+
+
+# ---- 4. random SPD problem of PMPC.jl/test/runtests.jl:6-27 ----------------------------------------------
+def random_spd(rng):
+    M, N, xdim, udim = 3, 11, 4, 2
+    g = rng.standard_normal
+    x0, f = g((M, xdim)), g((M, N, xdim))
+    fx, fu = g((M, N, xdim, xdim)), g((M, N, xdim, udim))
+    X_prev, U_prev = g((M, N, xdim)), g((M, N, udim))
+    Qh, Rh = g((M, N, xdim, xdim)), g((M, N, udim, udim))
+    Q, R = np.swapaxes(Qh, -1, -2) @ Qh, np.swapaxes(Rh, -1, -2) @ Rh
+    X_ref, U_ref = g((M, N, xdim)), g((M, N, udim))
+    # runtests.jl:24-27 also sets |x| <= 100, which this random unstable fx makes infeasible (the
+    # reference only asserts "does not throw" there); the goldens keep the solvable variants:
+    # unconstrained (runtests.jl:33-35) and |u| <= 0.2 only.
+    kw = dict(reg_x=0.0, reg_u=0.0, u_l=-0.2 * np.ones((M, N, udim)), u_u=0.2 * np.ones((M, N, udim)))
+    return (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref), kw
+
+
+def scp_reference_run(N, reg_x, reg_u, max_it):
+    """tests/simple.py:20-29 (N=25, default regs) / tests/remote.py:20-39 (N=30, reg 1/1) through the
+    REFERENCE scp_solve, oracle as aff_solve."""
+    sys.path.insert(0, str(REF))
+    sys.path.insert(0, str(REF / "tests"))
+    import torch
+
+    torch.set_default_dtype(torch.float64)
+    import pmpc.scp_mpc as ref_scp
+    from dubins_car import f_np, fu_np, fx_np
+
+    ref_scp.aff_solve = orc.aff_solve
+    xdim, udim = 4, 2
+
+    def f_fx_fu_fn(X, U):
+        p = np.array([1.0, 1.0, 0.3])
+        return f_np(X, U, p), fx_np(X, U, p), fu_np(X, U, p)
+
+    Q = np.tile(np.eye(xdim), (N, 1, 1))
+    R = np.tile(1e-2 * np.eye(udim), (N, 1, 1))
+    x0 = np.ones(xdim)
+    X_ref, U_ref = np.zeros((N, xdim)), np.zeros((N, udim))
+    u_l, u_u = -np.ones((N, udim)), np.ones((N, udim))
+    kw = dict(u_l=u_l, u_u=u_u, max_it=max_it, solver_settings=dict(solver="osqp"))
+    if reg_x is not None:
+        kw.update(reg_x=reg_x, reg_u=reg_u)
+    X, U, data = ref_scp.scp_solve(f_fx_fu_fn, Q, R, x0, X_ref, U_ref, X_ref.copy(), U_ref.copy(), **kw)
+    hist = np.array([[h["it"], h["obj"], h["resid"], h["reg_x"], h["reg_u"]] for h in data["hist"]])
+    return dict(X=X, U=U, hist=hist, N=np.array(N), reg_x=np.array(hist[0, 3]), reg_u=np.array(hist[0, 4]), max_it=np.array(max_it))
+
+
+if __name__ == "__main__":
+    orc.build()
+    for name, ul in (("qp_double_integrator_u04.npz", 0.4), ("qp_double_integrator_u1.npz", 1.0)):
+        args, kw, Nc = double_integrator(ul)
+        save(name, **solve_and_pack(args, kw, Nc))
+    rng = np.random.default_rng(2020)  # cf. Random.seed!(2020), PMPC.jl/test/test.jl:4
+    args, kw = chain(rng, M=24, N=30)
+    for Nc in (0, 1, 3, -1):
+        save(f"qp_chain_Nc{Nc if Nc >= 0 else 'N'}.npz", **solve_and_pack(args, kw, Nc))
+    args, kw = random_spd(np.random.default_rng(2021))
+    save("qp_random_spd_ubox.npz", **solve_and_pack(args, kw, -1))
+    save("qp_random_spd.npz", **solve_and_pack(args, dict(reg_x=0.0, reg_u=0.0), -1))
+    save("scp_unicycle_simple.npz", **scp_reference_run(25, None, None, 40))
+    save("scp_unicycle_remote.npz", **scp_reference_run(30, 1.0, 1.0, 40))

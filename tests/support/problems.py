@@ -6,10 +6,10 @@ import numpy as np
 
 def rand_problem(rng, M, N, x, u, bounds_u=None, bounds_x=None, slew=None, slew0=None):
     """Dense random SPD problem in the style of PMPC.jl/test/runtests.jl:6-27 (random fx, fu, Q'Q, R'R,
-    box bounds), made mildly stable so that box-feasible trajectories exist."""
-    fx = np.eye(x) + 0.3 * rng.standard_normal((M, N, x, x))
+    box bounds), made contractive so that box-feasible trajectories exist."""
+    fx = 0.7 * np.eye(x) + 0.15 * rng.standard_normal((M, N, x, x))
     fu = rng.standard_normal((M, N, x, u))
-    f = rng.standard_normal((M, N, x))
+    f = 0.5 * rng.standard_normal((M, N, x))
     X_prev, U_prev = rng.standard_normal((M, N, x)), 0.1 * rng.standard_normal((M, N, u))
     X_ref, U_ref = rng.standard_normal((M, N, x)), rng.standard_normal((M, N, u))
     A = rng.standard_normal((M, N, x, x))

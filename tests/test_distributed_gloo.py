@@ -1,0 +1,78 @@
+"""world_size-2 `gloo` test (CPU) of the particle-sharded solve: each rank holds a contiguous shard of the
+particles and the ONLY data exchanged are the ones the GPU path all-reduces over RCCL — the condensed
+consensus Hessian/gradient (sum), the IPM complementarity sums (sum), the step-length ratios (min) and the
+residual norms (max) — SURVEY.md §8(e).  The sharded result must equal the oracle's joint solve."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, str(ROOT))
+    import torch
+    import torch.distributed as dist
+
+    from tests.support import structured_np as snp
+    from tests.support.problems import rand_problem
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    M, N, x, u, Nc, bu, bx = case
+    args, kw = rand_problem(np.random.default_rng(7), M, N, x, u, bu, bx)  # every rank draws the same batch
+    ML = M // world
+    sl = slice(rank * ML, (rank + 1) * ML)
+    largs = tuple(a[sl] for a in args)
+    lkw = {k: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (M,) else v) for k, v in kw.items()}
+    k = N if Nc < 0 else Nc
+    if "u_l" in lkw and k > 0:  # consensus-control bounds are global particle 0's (lqp_utils.jl:329-330)
+        lkw["u_l"], lkw["u_u"] = lkw["u_l"].copy(), lkw["u_u"].copy()
+        lkw["u_l"][:, :k], lkw["u_u"][:, :k] = kw["u_l"][0:1, :k], kw["u_u"][0:1, :k]
+
+    def red(op):
+        def f(a):
+            scalar = np.isscalar(a) or np.ndim(a) == 0
+            t = torch.as_tensor(np.atleast_1d(np.asarray(a, dtype=np.float64)).copy())
+            dist.all_reduce(t, op=op)
+            return float(t[0]) if scalar else t.numpy()
+        return f
+
+    p = snp.Problem(*largs[1:], Nc=Nc, **lkw)
+    p.owns_consensus = rank == 0
+    X, U, info = snp.ipm_solve(p, allreduce=red(dist.ReduceOp.SUM), allreduce_min=red(dist.ReduceOp.MIN),
+                               allreduce_max=red(dist.ReduceOp.MAX))
+    np.savez(Path(out_dir) / f"rank{rank}.npz", X=X, U=U, iters=info["iters"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [(6, 7, 3, 2, 1, 0.3, None), (6, 7, 3, 2, 3, 0.3, 6.0), (4, 6, 3, 2, -1, None, None), (8, 6, 4, 2, 0, 0.3, None)],
+                         ids=["Nc1-ubox", "Nc3-ubox-xbox", "NcN-free", "Nc0-ubox"])
+def test_sharded_solve_equals_joint_solve(case, oracle, tmp_path):
+    import torch.multiprocessing as mp
+
+    from tests.support.problems import rand_problem
+
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    M, N, x, u, Nc, bu, bx = case
+    args, kw = rand_problem(np.random.default_rng(7), M, N, x, u, bu, bx)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    X, U = np.concatenate([p["X"] for p in parts]), np.concatenate([p["U"] for p in parts])
+    assert parts[0]["iters"] == parts[1]["iters"]  # identical all-reduced scalars => identical control flow
+    assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-7
+    assert np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0) < 1e-7
+    k = N if Nc < 0 else Nc
+    if k:
+        assert np.all(U[:, :k] == U[0:1, :k])  # consensus across ranks, bitwise

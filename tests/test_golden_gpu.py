@@ -1,0 +1,68 @@
+"""GPU vs the committed golden fixtures (tests/golden/make_golden.py): sub-problems through `c_lqp_solve`,
+and the full SCP loop (pmpc_amd.solve, HIP back end) against the hist rows of the reference's own loop."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests.support.problems import abi_args
+from tests.test_oracle_golden import QP_FILES, load_qp
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+@pytest.mark.parametrize("name", QP_FILES)
+def test_c_lqp_solve_matches_golden(name):
+    from pmpc_amd import backend
+
+    args, kw, Nc, Xg, Ug, _ = load_qp(name)
+    X, U = backend.lqp_solve(*abi_args(args, kw, Nc))
+    assert np.linalg.norm(X - Xg) / np.linalg.norm(Xg) < 1e-7
+    assert np.linalg.norm(U - Ug) / max(np.linalg.norm(Ug), 1.0) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["qp_double_integrator_u04.npz", "qp_chain_Nc1.npz"])
+def test_c_lcone_solve_hard_constraints(name):
+    """smooth_alpha = NaN => hard constraints (PMPC.jl/src/main.jl:242-244).  For M = 1 the cone objective has the
+    QP's minimiser; for M > 1 this entry point documents its deviation and returns the QP optimum."""
+    from pmpc_amd import backend
+
+    args, kw, Nc, Xg, Ug, _ = load_qp(name)
+    a = abi_args(args, kw, Nc)
+    X, U = backend.lcone_solve(*a, smooth_alpha=float("nan"), solver="ecos")
+    assert np.linalg.norm(X - Xg) / np.linalg.norm(Xg) < 1e-7 and np.linalg.norm(U - Ug) / max(np.linalg.norm(Ug), 1.0) < 1e-7
+
+
+@pytest.mark.parametrize("name,regs", [("scp_unicycle_simple.npz", {}), ("scp_unicycle_remote.npz", dict(reg_x=1.0, reg_u=1.0))])
+def test_scp_solve_on_gpu_matches_reference_loop(name, regs):
+    import pmpc_amd
+    from pmpc_amd import dynamics as dyn
+
+    g = np.load(GOLD / name)
+    N = int(g["N"])
+    p = np.array([1.0, 1.0, 0.3])
+    Q, R = np.tile(np.eye(4), (N, 1, 1)), np.tile(1e-2 * np.eye(2), (N, 1, 1))
+    X, U, data = pmpc_amd.solve(lambda X, U: dyn.unicycle(X, U, p), Q, R, np.ones(4), np.zeros((N, 4)), np.zeros((N, 2)),
+                                np.zeros((N, 4)), np.zeros((N, 2)), u_l=-np.ones((N, 2)), u_u=np.ones((N, 2)),
+                                max_it=int(g["max_it"]), solver_settings=dict(solver="osqp"), **regs)
+    hist = np.array([[h["it"], h["obj"], h["resid"]] for h in data["hist"]])
+    assert hist.shape[0] == g["hist"].shape[0]
+    # tolerances as in tests/test_host_logic.py (first linearisation sits on the u2 = 1e-6 singular point)
+    np.testing.assert_allclose(hist[:, 1], g["hist"][:, 1], rtol=2e-4)
+    np.testing.assert_allclose(hist[5:, 1], g["hist"][5:, 1], rtol=1e-5)
+    np.testing.assert_allclose(X, g["X"], atol=2e-5)
+    np.testing.assert_allclose(U, g["U"], atol=2e-5)
+
+
+def test_failure_convention_nan_outputs():
+    """A QP whose Hessian is not positive definite fails loudly: NaN outputs (osqp_solver.jl:65-71) ->
+    (None, None, None) from the host loop (pmpc/scp_mpc.py:391-394)."""
+    from pmpc_amd import backend
+    from tests.support.problems import rand_problem
+
+    args, kw = rand_problem(np.random.default_rng(3), 2, 5, 3, 2)
+    args = list(args)
+    args[7] = -np.tile(np.eye(2), (2, 5, 1, 1))  # R = -I, reg_u = 0.1  ->  Huu indefinite
+    X, U = backend.lqp_solve(*abi_args(tuple(args), kw, 0))
+    assert np.all(np.isnan(X)) and np.all(np.isnan(U))

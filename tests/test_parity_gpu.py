@@ -19,7 +19,7 @@ def test_lqp_solve_matches_oracle(case, oracle):
     from pmpc_amd import backend
 
     M, N, x, u, Nc, bu, bx, sl, sl0 = case
-    rng = np.random.default_rng(abs(hash(case)) % (2**32))
+    rng = np.random.default_rng(1000 + CASES.index(case))
     args, kw = rand_problem(rng, M, N, x, u, bu, bx, sl, sl0)
     Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
     X, U = backend.lqp_solve(*abi_args(args, kw, Nc))
