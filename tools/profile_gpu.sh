@@ -1,0 +1,13 @@
+#!/bin/bash
+# Run ON THE GPU BOX through gpurun:  gpurun -- 'bash tools/profile_gpu.sh r01_c'
+# 1) kernel-trace + stats, 2) PMC FETCH_SIZE, 3) PMC WRITE_SIZE (separate passes, as the MI355X guide prescribes).
+tag=${1:-run}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/prof_$tag
+mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_write.log 2>&1
+python3 bench.py --steps 20 --warmup 3 > $out/bench_full.log 2>&1
+grep '^{' $out/bench_full.log | cut -c1-400
+find $out -name '*.csv' | head -20

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh run into profiles/: kernel stats table, PMC HBM traffic per launch of
+the dominant kernel (gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE
+are in KiB; FETCH_SIZE under-reports wide coalesced reads, so the read-side factor is CALIBRATED in the same
+run on k_axpy_alpha, an 8-B-per-lane streaming kernel with an exactly known byte count)."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+tag = sys.argv[1]
+src = Path("gpurun_out") / f"prof_{tag}"
+dst = Path("profiles")
+dst.mkdir(exist_ok=True)
+
+
+def pmc(kind):
+    f = glob.glob(str(src / f"pmc_{kind}" / "*" / "*counter_collection.csv"))[0]
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = pmc("fetch"), pmc("write")
+M, N, x, u = 4096, 50, 12, 4
+nx = M * N * x
+key = lambda d, s: next(k for k in d if s in k)
+ax = key(fetch, "k_axpy_alpha")
+ax_read_true = 2 * nx * 8  # y and x streams
+ax_fetch = sum(fetch[ax]) / len(fetch[ax]) * 1024
+read_factor = ax_read_true / ax_fetch
+ax_write = sum(write[key(write, "k_axpy_alpha")]) / len(write[key(write, "k_axpy_alpha")]) * 1024
+out = {"calibration": {"kernel": "k_axpy_alpha", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
+                       "read_factor": read_factor, "true_write_bytes": nx * 8, "WRITE_SIZE_bytes": ax_write}}
+for name, label in (("k_bwd_fast<12, 4, true", "bwd_factor"), ("k_bwd_fast<12, 4, false", "bwd_vec"), ("k_fwd_fast<12, 4, false", "fwd")):
+    kf, kw = key(fetch, name), key(write, name)
+    fb = sum(fetch[kf]) / len(fetch[kf]) * 1024
+    wb = sum(write[kw]) / len(write[kw]) * 1024
+    out[label] = {"FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb, "read_bytes_calibrated": fb * read_factor,
+                  "launches_sampled": len(fetch[kf])}
+    out[f"{label}_bytes_per_launch"] = fb * read_factor + wb
+(dst / "traffic.json").write_text(json.dumps(out, indent=1))
+print(json.dumps(out, indent=1))
+
+stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))[0]
+(dst / f"{tag}_kernel_stats.csv").write_text(open(stats).read())
+for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f"{tag}_bench_under_rocprof.json")):
+    lines = [l for l in open(src / log) if l.startswith("{")]
+    if lines:
+        (dst / name).write_text(lines[-1])
