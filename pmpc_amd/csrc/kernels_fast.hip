@@ -45,8 +45,9 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  // every lane has a valid source for these permutations: no "old" value needed (saves the init moves)
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // sum over the 16 lanes of a DPP row (all lanes get the total): xor1, xor2, half-mirror, mirror
@@ -140,134 +141,200 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const dou
 // ------------------------------------------------------------------------------------------------
 // backward sweep (see kernels_generic.hip for the FACTOR / vector-only protocol)
 //   HXB: state bounds active (Dx, wx valid)   HUB: control bounds active (Du, wu valid)
+// FACTOR reads the gradient pre-pass arrays (xm, xd, um, ud; launch_grad_prep), the vector-only sweep
+// reads the IPM shifts (wx, wu) directly.  Everything a stage needs EARLY (F_j, R_j, um_j, ud_j, Du_j,
+// Q_{j-1}, Dx_{j-1} resp. K_j, chol(Huu_j)) is loaded one full stage ahead; what it needs LATE
+// (xm_{j-1}, xd_{j-1}) is issued at the top of the stage.  Lanes without an entry in an array read a
+// zero buffer through a zero-stride pointer, so no load is predicated and no value needs a select.
 // ------------------------------------------------------------------------------------------------
 template <int XD, int UD, bool FACTOR, bool HXB, bool HUB>
 __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
   constexpr bool PADX = (XD != XP);
+  constexpr long long D8 = sizeof(double);
   const int lane = threadIdx.x;
   const LT L(lane);
   const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
   const size_t pbase = (size_t)i * N;
   const bool own0 = (i == 0 && a.owner);
   const bool gu = g < UD;
-  const bool diag_x = L.cxv && ((c & 3) == g);  // kernel row g + 4r == c for r = c >> 2
-  const int diag_r = c >> 2;
+  const double *Z = a.zeros;
 
-  // ---- per-lane pointers / byte offsets at stage N-1, decremented by constant strides ----------------
-  // matrices: 64-bit per-lane pointers (stacks may exceed 4 GB); every lane gets a VALID address and
-  // the value is zeroed by a select where the lane has no entry.
-  const long long sF = -(long long)sizeof(double) * (L.cxv ? XD * XD : XD * UD);
+  // per-lane pointers at stage N-1 and per-lane byte strides (0 for lanes that read the zero buffer)
+  const bool fF = L.cxv || L.cu;
   const double *pF = L.cxv ? a.fx + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0
-                           : a.fu + (pbase + N - 1) * (XD * UD) + XD * (L.cu ? L.cb : 0) + L.row0;
-  const bool ldF = L.cxv || L.cu;
-  const double *pQ = a.Q + (pbase + N - 1) * (XD * XD) + XD * (L.cxv ? L.oc : 0) + L.row0;
-  const double *pR = a.R + (pbase + N - 1) * (UD * UD) + (gu ? g : 0) + UD * (L.cu ? L.cb : 0);
-  double *pK = a.K + (pbase + N - 1) * (UD * XD) + (gu ? g : 0) + UD * (L.cxv ? L.oc : 0);
-  double *pL = a.Hinv + (pbase + N - 1) * (UD * UD);
-  // vectors: uniform base + 32-bit byte offsets (lq_fast_supported bounds the array sizes)
-  unsigned ox_row = (unsigned)(((pbase + N - 1) * XD + L.row0) * sizeof(double));
-  unsigned ox_col = (unsigned)(((pbase + N - 1) * XD + (L.cxv ? L.oc : 0)) * sizeof(double));
-  unsigned ou_g = (unsigned)(((pbase + N - 1) * UD + (gu ? g : 0)) * sizeof(double));
-  unsigned ou_c = (unsigned)(((pbase + N - 1) * UD + (L.cu ? L.cb : 0)) * sizeof(double));
-  unsigned ou_0 = (unsigned)(((pbase + N - 1) * UD) * sizeof(double));
-  constexpr unsigned SX = XD * sizeof(double), SU = UD * sizeof(double);
-
-  double S[KS], s_row[KS], Qn[KS], Fn[KS];
-  double s_col;
-
-  // ---- terminal: S = Q~_{N-1} (+Dx), s = g_x,N-1 ; prefetch F_{N-1} -----------------------------------
-  {
-    {
-      const bool ld0 = (L.cxv && N - 1 > 0) || L.cu;
+                           : (L.cu ? a.fu + (pbase + N - 1) * (XD * UD) + XD * L.cb + L.row0 : Z);
+  const int sF = fF ? -(int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
+  const double *pQ = L.cxv ? a.Q + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0 : Z;
+  const int sQ = L.cxv ? -(int)D8 * (XD * XD) : 0;
+  const bool fR = L.cu && gu;
+  const double *pR = fR ? a.R + (pbase + N - 1) * (UD * UD) + g + UD * L.cb : Z;
+  const int sR = fR ? -(int)D8 * (UD * UD) : 0;
+  // control-side gradient (ud resp. wu) and Du on the control columns
+  const double *gu_src = FACTOR ? a.ud : a.wu;
+  const bool fgu = L.cu && (FACTOR || HUB);
+  const double *pgu = fgu ? gu_src + (pbase + N - 1) * UD + L.cb : Z;
+  const int sgu = fgu ? -(int)D8 * UD : 0;
+  const bool fDu = L.cu && FACTOR && HUB && g == L.cb;
+  const double *pDu = fDu ? a.Du + (pbase + N - 1) * UD + L.cb : Z;
+  const int sDu = fDu ? -(int)D8 * UD : 0;
+  // state-side gradient (xd resp. wx) and Dx on the diagonal lanes
+  const double *gx_src = FACTOR ? a.xd : a.wx;
+  const bool fgx = L.cxv && (FACTOR || HXB);
+  const double *pgx = fgx ? gx_src + (pbase + N - 1) * XD + L.oc : Z;
+  const int sgx = fgx ? -(int)D8 * XD : 0;
+  const bool diag_x = L.cxv && ((c & 3) == g);  // kernel row g + 4r == c for r = c >> 2
+  const bool fDx = diag_x && FACTOR && HXB;
+  const double *pDx = fDx ? a.Dx + (pbase + N - 1) * XD + L.oc : Z;
+  const int sDx = fDx ? -(int)D8 * XD : 0;
+  bool dmask[KS];  // lane masks (SGPR pairs), not VGPRs
 #pragma unroll
-      for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, ld0, L.row0 + r < XD);
-    }
-    (void)ldF;
-    double gsum = 0.0;
+  for (int r = 0; r < KS; r++) dmask[r] = diag_x && (c >> 2) == r;
+  const bool umask = L.cu && g == L.cb;
+  // row-distributed vectors (every lane has an entry unless xdim is padded): 32-bit byte offsets
+  unsigned ox_row = (unsigned)(((pbase + N - 1) * XD + L.row0) * D8);
+  unsigned ou_g = (unsigned)(((pbase + N - 1) * UD + (gu ? g : 0)) * D8);
+  unsigned ou_0 = (unsigned)(((pbase + N - 1) * UD) * D8);
+  constexpr unsigned SX = XD * D8, SU = UD * D8;
+  double *pK = a.K + (pbase + N - 1) * (UD * XD) + (gu ? g : 0) + UD * (L.cxv ? L.oc : 0);
+  const bool fK = L.cxv && gu;
+  const double *pKl = fK ? pK : Z;  // load side of the gains (vector-only sweep)
+  const int sK = fK ? -(int)D8 * (UD * XD) : 0;
+  double *pL = a.Hinv + (pbase + N - 1) * (UD * UD);
+
+  double S[KS], s_row[KS];
+  double s_col;
+  // "next stage" registers
+  double Fn[KS], Qn[KS], Rn = 0.0, umn = 0.0, gun, Dun = 0.0, Dxn = 0.0, Kn = 0.0, Ln[UD][UD], Ldn[UD];
+
+  auto load_row = [&](const double *p, double *dst) {
+#pragma unroll
+    for (int r = 0; r < KS; r++) dst[r] = (!PADX || L.row0 + r < XD || p == Z) ? p[r] : 0.0;
+  };
+  auto load_L = [&]() {
+#pragma unroll
+    for (int q = 0; q < UD; q++)
+#pragma unroll
+      for (int pp = q; pp < UD; pp++) {
+        const double v = pL[pp + UD * q];
+        if (pp == q) Ldn[q] = v;
+        else Ln[pp][q] = v;
+      }
+  };
+
+  // ---- terminal: S = Q~_{N-1} (+Dx), s = g_x,N-1 ; first "next" loads (stage N-1) -----------------------
+  {
+    double Q0[KS], part = 0.0;
     if (FACTOR) {
-      double part = 0.0;
+      load_row(pQ, Q0);
+      double dd = a.reg_x;
+      if (HXB) dd += *pDx;
 #pragma unroll
       for (int r = 0; r < KS; r++) {
         const bool rv = !PADX || (L.row0 + r < XD);
-        Qn[r] = ldsel<PADX>(pQ + r, L.cxv, rv);
-        const unsigned o = rv ? ox_row + r * 8u : ox_row;
-        const double xm = rv ? ldo(a.X, o) - ldo(a.X_ref, o) : 0.0;
-        part += Qn[r] * xm;
+        const double xm = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+        part += Q0[r] * xm;
+        S[r] = Q0[r] + (dmask[r] ? dd : 0.0);
       }
-      double dd = a.reg_x;
-      if (HXB) dd += ldo(a.Dx, ox_col);
-#pragma unroll
-      for (int r = 0; r < KS; r++) S[r] = Qn[r] + ((diag_x && diag_r == r) ? dd : 0.0);
-      gsum = grp_allsum(part) + a.reg_x * (ldo(a.X, ox_col) - ldo(a.X_prev, ox_col));
+      part = grp_allsum(part);
     }
-    if (HXB) gsum += ldo(a.wx, ox_col);
-    s_col = L.cxv ? gsum : 0.0;
+    s_col = part + *pgx;  // zero on lanes without a state column
     col_to_row<KS>(s_col, g, s_row);
+    // stage N-1 early data
+    load_row(pF, Fn);
+    gun = *pgu;
+    if (FACTOR) {
+      Rn = *pR;
+      umn = gu ? ldo(a.um, ou_g) : 0.0;
+      if (HUB) Dun = *pDu;
+      if (N > 1) {
+        pQ = badd(pQ, sQ);
+        load_row(pQ, Qn);
+        if (HXB) { pDx = badd(pDx, sDx); Dxn = *pDx; }
+      }
+    } else {
+      Kn = *pKl;
+      load_L();
+    }
   }
 
   for (int j = N - 1; j >= 0; j--) {
     const bool cons = j < Nc;
-    double Fr[KS];
+    // ---- rotate the pipeline registers ----------------------------------------------------------------
+    double Fr[KS], Qc[KS], Lc[UD][UD], Ld[UD];
 #pragma unroll
-    for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
-
-    // ---- loads of this stage: control-side vectors, R_j, and the state side of stage j-1 ------------
-    double Rraw = 0.0, um_g = 0.0, ud_c = 0.0, Du_c = 0.0;
-    if (FACTOR) {
-      Rraw = (L.cu && gu) ? *pR : 0.0;
-      um_g = gu ? ldo(a.U, ou_g) - ldo(a.U_ref, ou_g) : 0.0;
-      ud_c = a.reg_u * (ldo(a.U, ou_c) - ldo(a.U_prev, ou_c));
-      if (HUB) Du_c = ldo(a.Du, ou_c);
-    }
-    if (HUB) ud_c += ((!cons || own0) ? ldo(a.wu, ou_c) : 0.0);
-    // prefetch next stage's dynamics (F_{j-1}; its state columns are zero at stage 0)
-    if (j > 0) {
-      pF = badd(pF, sF);
-      const bool ldn = (L.cxv && j - 1 > 0) || L.cu;
+    for (int r = 0; r < KS; r++) { Fr[r] = Fn[r]; Qc[r] = Qn[r]; }
+    const double Rc = Rn, um_g = umn, Du_c = Dun, Dx_c = Dxn;
+    double gu_c = gun, Kreg = Kn;
+    if (!FACTOR) {
 #pragma unroll
-      for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, ldn, L.row0 + r < XD);
+      for (int q = 0; q < UD; q++) {
+        Ld[q] = Ldn[q];
+#pragma unroll
+        for (int pp = q + 1; pp < UD; pp++) Lc[pp][q] = Ln[pp][q];
+      }
+      if (HUB && cons && !own0) gu_c = 0.0;  // consensus shift counted once, on the owner's particle 0
     }
-    double xm_row[KS], xd_c = 0.0, Dx_c = 0.0;
+    if (j == 0) {  // stage 0 has no incoming state: A~_0 = 0
+#pragma unroll
+      for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
+    }
+    // ---- late loads of this stage: state side of stage j-1 -------------------------------------------
+    double xm_row[KS], gx_c = 0.0;
     if (j > 0) {
       ox_row -= SX;
-      ox_col -= SX;
+      pgx = badd(pgx, sgx);
+      gx_c = *pgx;
       if (FACTOR) {
-        pQ -= XD * XD;
 #pragma unroll
         for (int r = 0; r < KS; r++) {
           const bool rv = !PADX || (L.row0 + r < XD);
-          Qn[r] = ldsel<PADX>(pQ + r, L.cxv, rv);
-          const unsigned o = rv ? ox_row + r * 8u : ox_row;
-          xm_row[r] = rv ? ldo(a.X, o) - ldo(a.X_ref, o) : 0.0;
+          xm_row[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
         }
-        xd_c = a.reg_x * (ldo(a.X, ox_col) - ldo(a.X_prev, ox_col));
-        if (HXB) Dx_c = ldo(a.Dx, ox_col);
       }
-      if (HXB) xd_c += ldo(a.wx, ox_col);
+      // ---- prefetch stage j-1's early data --------------------------------------------------------------
+      pF = badd(pF, sF);
+      load_row(pF, Fn);
+      pgu = badd(pgu, sgu);
+      gun = *pgu;
+      ou_g -= SU;
+      if (FACTOR) {
+        pR = badd(pR, sR);
+        Rn = *pR;
+        umn = gu ? ldo(a.um, ou_g) : 0.0;
+        if (HUB) { pDu = badd(pDu, sDu); Dun = *pDu; }
+        if (j > 1) {
+          pQ = badd(pQ, sQ);
+          load_row(pQ, Qn);
+          if (HXB) { pDx = badd(pDx, sDx); Dxn = *pDx; }
+        }
+      } else {
+        pKl = badd(pKl, sK);
+        Kn = *pKl;
+        pL -= UD * UD;
+        load_L();
+      }
     }
 
     // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
-    double hp = Rraw * um_g;
+    double hp = Rc * um_g;
 #pragma unroll
-    for (int r = 0; r < KS; r++) hp += Fr[r] * s_row[r];
-    double h_col = grp_allsum(hp);
-    if (L.cu) h_col += ud_c;
+    for (int r = 0; r < KS; r++) hp = fma(Fr[r], s_row[r], hp);
+    const double h_col = grp_allsum(hp) + gu_c;
     double hu[UD];
 #pragma unroll
     for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
 
-    double Kreg = 0.0, Lc[UD][UD], Ld[UD];
     v4d H = {0.0, 0.0, 0.0, 0.0};
     if (FACTOR) {
       // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) ------------------------------------------------------
       if (j > 0) {
         const double dd = a.reg_x + Dx_c;
 #pragma unroll
-        for (int r = 0; r < KS; r++) H[r] = Qn[r] + ((diag_x && diag_r == r) ? dd : 0.0);
+        for (int r = 0; r < KS; r++) H[r] = Qc[r] + (dmask[r] ? dd : 0.0);
       }
-      H[KS] = Rraw + ((L.cu && g == L.cb) ? a.reg_u + (cons ? 0.0 : Du_c) : 0.0);
+      H[KS] = Rc + (umask ? a.reg_u + (cons ? 0.0 : Du_c) : 0.0);
       v4d G = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
@@ -280,40 +347,50 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       if (FACTOR) {
         // Hc_part[i][p + UD q] = Huu[p][q] lives in lane (XP + q, p), register KS
         double v = H[KS];
-        if (own0 && HUB && L.cu && g == L.cb) v += Du_c;
+        if (own0 && HUB && umask) v += Du_c;
         if (L.cu && gu) a.Hc_part[(size_t)i * (UD * UD) + g + UD * L.cb] = v;
       }
       if (lane < UD) a.gc_part[(size_t)i * UD + lane] = pick<UD>(hu, lane);
       break;
     }
 
+    double col[UD];
     if (FACTOR) {
       // ---- Cholesky of Huu on lane-uniform values (readlane broadcast of the lower triangle) --------
       bool bad = false;
 #pragma unroll
       for (int q = 0; q < UD; q++) {
 #pragma unroll
-        for (int p = q; p < UD; p++) {
-          double v = readlane_d(H[KS], (XP + q) + 16 * p);  // Huu[p][q]
+        for (int pp = q; pp < UD; pp++) {
+          double v = readlane_d(H[KS], (XP + q) + 16 * pp);  // Huu[pp][q]
 #pragma unroll
-          for (int k = 0; k < q; k++) v -= Lc[p][k] * Lc[q][k];
-          if (p == q) {
+          for (int k = 0; k < q; k++) v -= Lc[pp][k] * Lc[q][k];
+          if (pp == q) {
             bad |= !(v > 0.0);
             Ld[q] = rsqrt_d(v);
           } else {
-            Lc[p][q] = v * Ld[q];
+            Lc[pp][q] = v * Ld[q];
           }
         }
       }
       if (bad && lane == 0) *a.fail = 2;
-      // ---- K = Huu^-1 Hux: gather the control rows column-wise, substitute in-lane ------------------
-      double col[UD];
+      // ---- gather the control rows column-wise; column XP carries hu so that one in-lane
+      //      substitution yields both K[:, c] and the feed-forward k = Huu^-1 hu -----------------------
 #pragma unroll
-      for (int k = 0; k < UD; k++) col[k] = __shfl(H[KS], c + 16 * k, 64);  // H[XP + k][c]
-      chol_solve<UD>(Lc, Ld, col);
+      for (int k = 0; k < UD; k++) {
+        const double t = __shfl(H[KS], c + 16 * k, 64);  // H[XP + k][c]
+        col[k] = (c == XP) ? hu[k] : t;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < UD; k++) col[k] = hu[k];
+    }
+    const double hug = pick<UD>(hu, g);
+    chol_solve<UD>(Lc, Ld, col);
+    if (FACTOR) {
       const double Kg = pick<UD>(col, g);
       Kreg = (L.cxv && gu) ? Kg : 0.0;
-      v4d Sn = mfma(H[KS], gu ? -Kg : 0.0, H);  // S' = Hxx - Hxu K (columns >= XP are never used)
+      v4d Sn = mfma(H[KS], (gu && c != XP) ? -Kg : 0.0, H);  // S' = Hxx - Hxu K (columns >= XP are never used)
 #pragma unroll
       for (int r = 0; r < KS; r++) S[r] = Sn[r];
       if (L.cxv && gu) *pK = Kreg;
@@ -321,150 +398,193 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
 #pragma unroll
         for (int q = 0; q < UD; q++)
 #pragma unroll
-          for (int p = q; p < UD; p++) pL[p + UD * q] = (p == q) ? Ld[q] : Lc[p][q];
+          for (int pp = q; pp < UD; pp++) pL[pp + UD * q] = (pp == q) ? Ld[q] : Lc[pp][q];
       }
-    } else {
-      Kreg = (L.cxv && gu) ? *pK : 0.0;
-#pragma unroll
-      for (int q = 0; q < UD; q++)
-#pragma unroll
-        for (int p = q; p < UD; p++) {
-          const double v = pL[p + UD * q];
-          if (p == q) Ld[q] = v;
-          else Lc[p][q] = v;
-        }
+      pK -= UD * XD;
+      pL -= UD * UD;
     }
-
-    // ---- feed-forward k = Huu^-1 hu and s_{j-1} = h_x - K' hu + g_x,j-1 -----------------------------
-    const double hug = pick<UD>(hu, g);
-    chol_solve<UD>(Lc, Ld, hu);
-    if (lane == 0) {
+    if (lane == (FACTOR ? XP : 0)) {
 #pragma unroll
-      for (int b = 0; b < UD; b++) *(double *)((char *)a.kff + ou_0 + b * 8u) = hu[b];
+      for (int b = 0; b < UD; b++) *(double *)((char *)a.kff + ou_0 + b * 8u) = col[b];
     }
     if (j == 0) break;
+    // ---- s_{j-1} = h_x - K' hu + g_x,j-1 -------------------------------------------------------------
     double p2 = -Kreg * hug;
     if (FACTOR) {
 #pragma unroll
-      for (int r = 0; r < KS; r++) p2 += Qn[r] * xm_row[r];
+      for (int r = 0; r < KS; r++) p2 = fma(Qc[r], xm_row[r], p2);
     }
     const double red2 = grp_allsum(p2);
-    s_col = L.cxv ? h_col + red2 + xd_c : 0.0;
+    s_col = L.cxv ? h_col + red2 + gx_c : 0.0;
     col_to_row<KS>(s_col, g, s_row);
-    pR -= UD * UD;
-    pK -= UD * XD;
-    pL -= UD * UD;
-    ou_g -= SU;
-    ou_c -= SU;
     ou_0 -= SU;
   }
 }
 
+// gradient pre-pass of a factor solve: xm = X - X_ref, xd = reg_x (X - X_prev) + wx,
+// um = U - U_ref, ud = reg_u (U - U_prev) + wu (consensus stages: wu only on the owner's particle 0)
+__global__ void __launch_bounds__(256) k_grad_prep(LQArgs a) {
+  const long long nx = (long long)a.M * a.N * a.x, nu = (long long)a.M * a.N * a.u;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nx; k += stride) {
+    const double X = a.X[k];
+    a.xm[k] = X - a.X_ref[k];
+    a.xd[k] = a.reg_x * (X - a.X_prev[k]) + (a.wx ? a.wx[k] : 0.0);
+  }
+  for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nu; k += stride) {
+    const double U = a.U[k];
+    a.um[k] = U - a.U_ref[k];
+    double w = 0.0;
+    if (a.wu) {
+      const int j = (int)((k / a.u) % a.N);
+      const long long i = k / ((long long)a.u * a.N);
+      if (j >= a.Nc || (i == 0 && a.owner)) w = a.wu[k];
+    }
+    a.ud[k] = a.reg_u * (U - a.U_prev[k]) + w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
-// forward sweep (ROLLOUT: absolute linear rollout X from U, PMPC.jl/src/types.jl:161-173)
+// forward sweep (ROLLOUT: absolute linear rollout X from U, PMPC.jl/src/types.jl:161-173).
+// Stage data (F_j, K_j, k_j resp. U_j - U_prev_j, f_j, X_prev_j) is loaded one stage ahead; lanes
+// without an entry read the zero buffer through a zero-stride pointer.
 // ------------------------------------------------------------------------------------------------
 template <int XD, int UD, bool ROLLOUT>
 __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, double *Xout) {
   typedef Lane<XD, UD> LT;
-  constexpr int KS = LT::KS;
-  constexpr bool PADX = (XD != LT::XP);
+  constexpr int KS = LT::KS, XP = LT::XP;
+  constexpr bool PADX = (XD != XP);
+  constexpr long long D8 = sizeof(double);
   const int lane = threadIdx.x;
   const LT L(lane);
   const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
   const size_t pbase = (size_t)i * N;
   const bool gu = g < UD;
-  const long long sF = (long long)sizeof(double) * (L.cxv ? XD * XD : XD * UD);
+  const double *Z = a.zeros;
+  const bool fF = L.cxv || L.cu;
   const double *pF = L.cxv ? a.fx + pbase * (XD * XD) + XD * L.oc + L.row0
-                           : a.fu + pbase * (XD * UD) + XD * (L.cu ? L.cb : 0) + L.row0;
-  const bool ldF = L.cxv || L.cu;
-  const double *pK = a.K + pbase * (UD * XD) + (gu ? g : 0) + UD * (L.cxv ? L.oc : 0);
-  unsigned ox_row = (unsigned)((pbase * XD + L.row0) * sizeof(double));
-  unsigned ou_g = (unsigned)((pbase * UD + (gu ? g : 0)) * sizeof(double));
-  unsigned ou_c = (unsigned)((pbase * UD + (L.cu ? L.cb : 0)) * sizeof(double));
-  unsigned ou_0 = (unsigned)((pbase * UD) * sizeof(double));
-  constexpr unsigned SX = XD * sizeof(double), SU = UD * sizeof(double);
+                           : (L.cu ? a.fu + pbase * (XD * UD) + XD * L.cb + L.row0 : Z);
+  const int sF = fF ? (int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
+  const bool fK = L.cxv && gu && !ROLLOUT;
+  const double *pK = fK ? a.K + pbase * (UD * XD) + g + UD * L.oc : Z;
+  const int sK = fK ? (int)D8 * (UD * XD) : 0;
+  // control-column source: feed-forward k_j (per k-group) resp. rollout inputs (per control column)
+  const bool fk = gu && !ROLLOUT;
+  const double *pk = fk ? a.kff + pbase * UD + g : Z;
+  const int sk = fk ? (int)D8 * UD : 0;
+  const bool fc = L.cu;
+  const double *pu = (ROLLOUT && fc) ? Uin + pbase * UD + L.cb : Z;
+  const double *pup = (ROLLOUT && fc) ? a.U_prev + pbase * UD + L.cb : Z;
+  const double *pdc = (!ROLLOUT && fc) ? a.duc + L.cb : Z;  // consensus step of stage 0
+  const int su = (ROLLOUT && fc) ? (int)D8 * UD : 0;
+  unsigned ox_row = (unsigned)((pbase * XD + L.row0) * D8);
+  unsigned ou_g = (unsigned)((pbase * UD + (gu ? g : 0)) * D8);
+  constexpr unsigned SX = XD * D8, SU = UD * D8;
+  const bool store_x = (c == 0), store_u = (c == 0) && gu;
+  const int src_grp = 16 * (c & 3);
+
+  auto load_row = [&](const double *p, double *dst) {
+#pragma unroll
+    for (int r = 0; r < KS; r++) dst[r] = (!PADX || L.row0 + r < XD || p == Z) ? p[r] : 0.0;
+  };
 
   double xcol = 0.0;  // dx[oc] on valid state columns (ROLLOUT: X_{j-1} - X_prev_{j-1})
-  double Fn[KS], Kn = 0.0, kn = 0.0;  // next stage's F, gains and feed-forward (prefetched one stage ahead)
+  double Fn[KS], Kn, kn, un, fn[KS], xpn[KS];
+  load_row(pF, Fn);
+  Kn = *pK;
+  kn = *pk;
+  un = ROLLOUT ? *pu - *pup : 0.0;
+  if (ROLLOUT) {
 #pragma unroll
-  for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, L.cu, L.row0 + r < XD);  // stage 0: state columns are zero
-  if (!ROLLOUT && Nc == 0) {
-    Kn = (L.cxv && gu) ? *pK : 0.0;
-    kn = gu ? ldo(a.kff, ou_g) : 0.0;
+    for (int r = 0; r < KS; r++) {
+      const bool rv = !PADX || (L.row0 + r < XD);
+      fn[r] = rv ? ldo(a.f, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+      xpn[r] = rv ? ldo(a.X_prev, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+    }
   }
   for (int j = 0; j < N; j++) {
-    double Fr[KS];
+    double Fr[KS], fr[KS], xpr[KS];
 #pragma unroll
-    for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
-    const double Kreg = Kn, kreg = kn;
-    if (j + 1 < N) {
+    for (int r = 0; r < KS; r++) { Fr[r] = Fn[r]; fr[r] = fn[r]; xpr[r] = xpn[r]; }
+    const double Kreg = Kn, kreg = kn, ureg = un;
+    if (j == 0) {  // A~_0 = 0
+#pragma unroll
+      for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
+    }
+    if (j + 1 < N) {  // prefetch stage j + 1
       pF = badd(pF, sF);
+      load_row(pF, Fn);
+      if (ROLLOUT) {
+        pu = badd(pu, su);
+        pup = badd(pup, su);
+        un = *pu - *pup;
 #pragma unroll
-      for (int r = 0; r < KS; r++) Fn[r] = ldsel<PADX>(pF + r, ldF, L.row0 + r < XD);
-      if (!ROLLOUT) {
-        pK += UD * XD;
-        Kn = (L.cxv && gu && j + 1 >= Nc) ? *pK : 0.0;
-        kn = (gu && j + 1 >= Nc) ? ldo(a.kff, ou_g + SU) : 0.0;
+        for (int r = 0; r < KS; r++) {
+          const bool rv = !PADX || (L.row0 + r < XD);
+          fn[r] = rv ? ldo(a.f, ox_row + SX + (rv ? r * 8u : 0u)) : 0.0;
+          xpn[r] = rv ? ldo(a.X_prev, ox_row + SX + (rv ? r * 8u : 0u)) : 0.0;
+        }
+      } else {
+        pK = badd(pK, sK);
+        Kn = *pK;
+        pk = badd(pk, sk);
+        kn = *pk;
       }
     }
     double ycol;
-    double du[UD];
     if (ROLLOUT) {
-      ycol = L.cxv ? xcol : (L.cu ? ldo(Uin, ou_c) - ldo(a.U_prev, ou_c) : 0.0);
+      ycol = L.cxv ? xcol : ureg;  // ureg is zero off the control columns
     } else {
+      double du_c;
       if (j < Nc) {
-#pragma unroll
-        for (int b = 0; b < UD; b++) du[b] = a.duc[j * UD + b];
+        du_c = *pdc;  // shared consensus step (zero off the control columns)
+        if (store_u) {
+          double *o = (double *)((char *)a.dU + ou_g);
+          const double v = a.duc[j * UD + g];
+          *o = a.accumulate ? *o + v : v;
+        }
       } else {
         const double sum = row_allsum(Kreg * xcol);
-        const double dug = gu ? -sum - kreg : 0.0;
-#pragma unroll
-        for (int b = 0; b < UD; b++) du[b] = readlane_d(dug, 16 * b);
+        const double dug = -sum - kreg;  // du[g] in every lane of k-group g (zero for g >= udim)
+        const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);  // all lanes take part: the source lanes are not control columns
+        du_c = L.cu ? t : 0.0;
+        if (store_u) {
+          double *o = (double *)((char *)a.dU + ou_g);
+          *o = a.accumulate ? *o + dug : dug;
+        }
       }
-      ycol = L.cxv ? xcol : (L.cu ? pick<UD>(du, L.cb) : 0.0);
+      ycol = L.cxv ? xcol : du_c;
     }
     double xr[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) xr[r] = row_allsum(Fr[r] * ycol);
     if (ROLLOUT) {
-      // X_j = f_j + fx (X_{j-1} - Xp_{j-1}) + fu (U_j - Up_j); next xcol needs X_j - X_prev_j
+      // X_j = f_j + fx (X_{j-1} - Xp_{j-1}) + fu (U_j - Up_j); the next column state is X_j - X_prev_j
 #pragma unroll
       for (int r = 0; r < KS; r++) {
-        const bool rv = L.row0 + r < XD;
-        const unsigned o = rv ? ox_row + r * 8u : ox_row;
-        const double xj = xr[r] + ldo(a.f, o);
-        if (c == 0 && rv) *(double *)((char *)Xout + o) = xj;
-        xr[r] = xj - ldo(a.X_prev, o);
+        const bool rv = !PADX || (L.row0 + r < XD);
+        const double xj = xr[r] + fr[r];
+        if (store_x && rv) *(double *)((char *)Xout + ox_row + r * 8u) = xj;
+        xr[r] = xj - xpr[r];
       }
-    } else {
-      if (c == 0) {
+    } else if (store_x) {
 #pragma unroll
-        for (int r = 0; r < KS; r++)
-          if (L.row0 + r < XD) {
-            double *o = (double *)((char *)a.dX + ox_row + r * 8u);
-            *o = a.accumulate ? *o + xr[r] : xr[r];
-          }
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < UD; b++) {
-          double *o = (double *)((char *)a.dU + ou_0 + b * 8u);
-          *o = a.accumulate ? *o + du[b] : du[b];
+      for (int r = 0; r < KS; r++)
+        if (!PADX || L.row0 + r < XD) {
+          double *o = (double *)((char *)a.dX + ox_row + r * 8u);
+          *o = a.accumulate ? *o + xr[r] : xr[r];
         }
-      }
     }
     // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2
     double nx = 0.0;
 #pragma unroll
     for (int r = 0; r < KS; r++) {
-      const double t = __shfl(xr[r], 16 * (c & 3), 64);
+      const double t = __shfl(xr[r], src_grp, 64);
       nx = ((c >> 2) == r) ? t : nx;
     }
     xcol = L.cxv ? nx : 0.0;
     ox_row += SX;
     ou_g += SU;
-    ou_c += SU;
-    ou_0 += SU;
   }
 }
 
@@ -522,6 +642,13 @@ void launch_fwd_fast(const LQArgs &a, hipStream_t s) {
   PMPC_FAST_DIMS(X)
 #undef X
   abort();
+}
+
+void launch_grad_prep(const LQArgs &a, hipStream_t s) {
+  long long n = (long long)a.M * a.N * a.x;
+  long long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(k_grad_prep, dim3((unsigned)b), dim3(256), 0, s, a);
 }
 
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s) {

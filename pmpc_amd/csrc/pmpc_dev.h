@@ -33,6 +33,11 @@ struct LQArgs {
   const double *X, *U;
   // IPM terms: extra Hessian diagonals / gradient shifts (null when absent)
   const double *Dx, *Du, *wx, *wu;
+  // fast path only: gradient pre-pass outputs (launch_grad_prep), same shapes as X / U
+  //   xm = X - X_ref, xd = reg_x (X - X_prev) + wx, um = U - U_ref, ud = reg_u (U - U_prev) + wu (free stages;
+  //   consensus stages: wu only on the owner's particle 0)
+  double *xm, *xd, *um, *ud;
+  const double *zeros;  // >= 64 readable zero doubles (lanes without an entry load from here, stride 0)
   // factor storage
   double *K;     // [M][N][u*n]  col-major u x n
   double *Hinv;  // [M][N][u*u]
@@ -92,6 +97,7 @@ bool lq_fast_supported(const LQArgs &a);
 void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_fast(const LQArgs &a, hipStream_t s);
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
+void launch_grad_prep(const LQArgs &a, hipStream_t s);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s);

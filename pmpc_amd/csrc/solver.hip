@@ -30,7 +30,7 @@ struct Rccl {
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   bool load() {
     if (h) return true;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};  // torch bundles soname librccl.so: reuse the loaded copy
     for (const char *n : names)
       if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
     if (!h) return false;
@@ -66,8 +66,8 @@ struct SlabBufs {
 };
 
 struct Workspace {
-  DevBuf X, U, dX, dU, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
-  DevBuf zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
+  DevBuf X, U, dX, dU, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
+  DevBuf zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   SlabBufs sx, su;
 };
 
@@ -139,6 +139,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast) {
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
   const int nc = a.Nc * a.u;
+  if (fast && factor) launch_grad_prep(a, s);
   {
     ProfScope ps(c, factor ? 0 : 1);
     if (fast) launch_bwd_fast(a, factor, s);
@@ -194,8 +195,8 @@ void pmpc_destroy(pmpc_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
-                   &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
+                   &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
@@ -330,6 +331,15 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   a.dX = w.dX.d(); a.dU = w.dU.d(); a.fail = (int *)w.fail.p;
   a.X = w.X.d(); a.U = w.U.d();
   const bool fast = !(p->flags & PMPC_FORCE_GENERIC) && lq_fast_supported(a);
+  if (w.zeros.bytes == 0) {
+    w.zeros.ensure(64 * D8);
+    HIP_CHECK(hipMemsetAsync(w.zeros.p, 0, 64 * D8, s));
+  }
+  a.zeros = w.zeros.d();
+  if (fast) {
+    w.xm.ensure(nx * D8); w.xd.ensure(nx * D8); w.um.ensure(nu * D8); w.ud.ensure(nu * D8);
+    a.xm = w.xm.d(); a.xd = w.xd.d(); a.um = w.um.d(); a.ud = w.ud.d();
+  }
   inf.fast_path = fast ? 1 : 0;
   IpmScal *sc = (IpmScal *)w.sc.p;
 
