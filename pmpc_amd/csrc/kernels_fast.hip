@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   double S[KS], s_row[KS];
   double s_col;
   // "next stage" registers
-  double Fn[KS], Qn[KS], Rn = 0.0, umn = 0.0, gun, Dun = 0.0, Dxn = 0.0, Kn = 0.0, Ln[UD][UD], Ldn[UD];
+  double Fn[KS], Qn[KS], xmn[KS], gxn = 0.0, Rn = 0.0, umn = 0.0, gun, Dun = 0.0, Dxn = 0.0, Kn = 0.0, Ln[UD][UD], Ldn[UD];
 
   auto load_row = [&](const double *p, double *dst) {
 #pragma unroll
@@ -257,6 +257,19 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       Kn = *pKl;
       load_L();
     }
+    // state side of stage N-2 (consumed at the END of stage N-1)
+    if (N > 1) {
+      ox_row -= SX;
+      pgx = badd(pgx, sgx);
+      gxn = *pgx;
+      if (FACTOR) {
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          const bool rv = !PADX || (L.row0 + r < XD);
+          xmn[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+        }
+      }
+    }
   }
 
   for (int j = N - 1; j >= 0; j--) {
@@ -280,17 +293,22 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
 #pragma unroll
       for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
     }
-    // ---- late loads of this stage: state side of stage j-1 -------------------------------------------
-    double xm_row[KS], gx_c = 0.0;
-    if (j > 0) {
-      ox_row -= SX;
-      pgx = badd(pgx, sgx);
-      gx_c = *pgx;
-      if (FACTOR) {
+    // ---- state side of stage j-1 (prefetched one stage ahead as well) ---------------------------------
+    double xm_row[KS];
+    const double gx_c = gxn;
 #pragma unroll
-        for (int r = 0; r < KS; r++) {
-          const bool rv = !PADX || (L.row0 + r < XD);
-          xm_row[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+    for (int r = 0; r < KS; r++) xm_row[r] = xmn[r];
+    if (j > 0) {
+      if (j > 1) {
+        ox_row -= SX;
+        pgx = badd(pgx, sgx);
+        gxn = *pgx;
+        if (FACTOR) {
+#pragma unroll
+          for (int r = 0; r < KS; r++) {
+            const bool rv = !PADX || (L.row0 + r < XD);
+            xmn[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+          }
         }
       }
       // ---- prefetch stage j-1's early data --------------------------------------------------------------
@@ -541,7 +559,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         if (store_u) {
           double *o = (double *)((char *)a.dU + ou_g);
           const double v = a.duc[j * UD + g];
-          *o = a.accumulate ? *o + v : v;
+          *o = v;
         }
       } else {
         const double sum = row_allsum(Kreg * xcol);
@@ -550,7 +568,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         du_c = L.cu ? t : 0.0;
         if (store_u) {
           double *o = (double *)((char *)a.dU + ou_g);
-          *o = a.accumulate ? *o + dug : dug;
+          *o = dug;
         }
       }
       ycol = L.cxv ? xcol : du_c;
@@ -572,7 +590,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
       for (int r = 0; r < KS; r++)
         if (!PADX || L.row0 + r < XD) {
           double *o = (double *)((char *)a.dX + ox_row + r * 8u);
-          *o = a.accumulate ? *o + xr[r] : xr[r];
+          *o = xr[r];
         }
     }
     // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2

@@ -366,8 +366,7 @@ __global__ void __launch_bounds__(WV) k_fwd_generic(LQArgs a) {
         for (int c = 0; c < n; c++) v -= Kg[lane + u * c] * xi[c];
       }
       du[lane] = v;
-      if (a.accumulate) a.dU[vofs(i, j, N, u) + lane] += v;
-      else a.dU[vofs(i, j, N, u) + lane] = v;
+      a.dU[vofs(i, j, N, u) + lane] = v;
     }
     __syncthreads();
     const double *fx = a.fx + mofs(i, j, N, x, x), *fu = a.fu + mofs(i, j, N, x, u);
@@ -376,8 +375,7 @@ __global__ void __launch_bounds__(WV) k_fwd_generic(LQArgs a) {
       if (r < x) {
         if (j > 0) for (int c = 0; c < x; c++) v += fx[r + x * c] * xi[c];
         for (int t = 0; t < u; t++) v += fu[r + x * t] * du[t];
-        if (a.accumulate) a.dX[vofs(i, j, N, x) + r] += v;
-        else a.dX[vofs(i, j, N, x) + r] = v;
+        a.dX[vofs(i, j, N, x) + r] = v;
       } else v = du[r - x];
       xn[r] = v;
     }
@@ -466,7 +464,82 @@ __global__ void __launch_bounds__(256) k_cons_solve(const double *Hc, double *Lc
   for (int e = tid; e < nc; e += nth) duc[e] = y[e];
 }
 
+// small consensus systems (nc^2 + nc <= 32, e.g. Nc = 1): the per-particle (H_i, g_i) are summed in a fixed
+// order by gridDim.x slices (stage 1: outH/outg hold one partial per slice) and a final single block
+// (stage 2, gridDim.x == 1, solve_now) sums the slices and solves the dense system.  with_H = 0: gradient
+// only, stored factor.
+__global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, int with_H,
+                                                     double *outH, double *outg, int solve_now, double *Lc, double *duc,
+                                                     int *fail) {
+  __shared__ double red[32][33];
+  __shared__ double y[8];
+  const int tid = threadIdx.x, e = tid & 31, pl = tid >> 5;
+  const int nH = nc * nc, E = with_H ? nH + nc : nc;
+  const int per = (M + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(M, i0 + per);
+  const bool isH = with_H && e < nH;
+  double acc = 0.0;
+  if (e < E) {
+    const double *src = isH ? Hc_part + e : gc_part + (with_H ? e - nH : e);
+    const int stride = isH ? nH : nc;
+    for (int i = i0 + pl; i < i1; i += 32) acc += src[(size_t)i * stride];
+  }
+  red[pl][e] = acc;
+  __syncthreads();
+  if (pl == 0 && e < E) {
+    double t = 0.0;
+    for (int k = 0; k < 32; k++) t += red[k][e];
+    if (isH) outH[(size_t)blockIdx.x * nH + e] = t;
+    else outg[(size_t)blockIdx.x * nc + (with_H ? e - nH : e)] = t;
+  }
+  __syncthreads();
+  if (solve_now && tid == 0) {
+    const double *H = outH, *g = outg;
+    if (with_H) {
+      for (int q = 0; q < nc; q++) {
+        double d = H[q + nc * q];
+        for (int k = 0; k < q; k++) d -= Lc[q + nc * k] * Lc[q + nc * k];
+        if (!(d > 0.0)) { *fail = 2; d = 1.0; }
+        d = sqrt(d);
+        Lc[q + nc * q] = d;
+        for (int p = q + 1; p < nc; p++) {
+          double v = H[p + nc * q];
+          for (int k = 0; k < q; k++) v -= Lc[p + nc * k] * Lc[q + nc * k];
+          Lc[p + nc * q] = v / d;
+        }
+      }
+    }
+    for (int p = 0; p < nc; p++) {
+      double v = -g[p];
+      for (int k = 0; k < p; k++) v -= Lc[p + nc * k] * y[k];
+      y[p] = v / Lc[p + nc * p];
+    }
+    for (int p = nc - 1; p >= 0; p--) {
+      double v = y[p];
+      for (int k = p + 1; k < nc; k++) v -= Lc[k + nc * p] * y[k];
+      y[p] = v / Lc[p + nc * p];
+    }
+    for (int p = 0; p < nc; p++) duc[p] = y[p];
+  }
+}
+
 }  // namespace
+
+void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, bool with_H, double *Hg, double *tmp,
+                       bool solve_now, double *Lc, double *duc, int *fail, hipStream_t s) {
+  const int nH = nc * nc;
+  int G = (M + 127) / 128;  // ~4 particles per lane and slice
+  if (G > 64) G = 64;
+  double *Hc = Hg, *gc = Hg + nH;
+  if (G <= 1) {
+    hipLaunchKernelGGL(k_cons_small, dim3(1), dim3(1024), 0, s, Hc_part, gc_part, M, nc, with_H ? 1 : 0, Hc, gc, solve_now ? 1 : 0,
+                       Lc, duc, fail);
+    return;
+  }
+  double *tH = tmp, *tg = tmp + (size_t)64 * nH;
+  hipLaunchKernelGGL(k_cons_small, dim3(G), dim3(1024), 0, s, Hc_part, gc_part, M, nc, with_H ? 1 : 0, tH, tg, 0, Lc, duc, fail);
+  hipLaunchKernelGGL(k_cons_small, dim3(1), dim3(1024), 0, s, (const double *)tH, (const double *)tg, G, nc, with_H ? 1 : 0, Hc, gc,
+                     solve_now ? 1 : 0, Lc, duc, fail);
+}
 
 size_t lq_generic_lds_bytes(const LQArgs &a) { return lds_doubles(a.x, a.u, a.n) * sizeof(double); }
 

@@ -47,7 +47,7 @@ __device__ __forceinline__ Elem load_elem(const Slab &s, long long k, double sig
   e.wl = e.ml ? (sigmu - cl - e.ll * e.rl) / e.tl : 0.0;
   e.wu = e.mu ? (sigmu - cu - e.lu * e.ru) / e.tu : 0.0;
   if (with_dz) {
-    const double dz = s.dz[k];
+    const double dz = s.dz[k] + (s.dz2 ? s.dz2[k] : 0.0);
     e.dtl = e.ml ? dz + e.rl : 0.0;
     e.dtu = e.mu ? -dz + e.ru : 0.0;
     e.dll = e.ml ? e.wl - e.ll - (e.ll / e.tl) * dz : 0.0;
@@ -195,10 +195,13 @@ __global__ void __launch_bounds__(TB) k_ipm_prepare(Slab s, int corrector, const
   }
 }
 
-__global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal *sc) {
+// ratio test of one Newton step.  Predictor also stores the second-order terms c = dt*dl and the partial
+// sums of  S1 = sum w (t dl + l dt),  S2 = sum w dt dl:  mu_aff(alpha) = (S0 + alpha S1 + alpha^2 S2)/cnt
+// with S0 = comp_sum, so no second pass over the slab is needed once alpha_aff is known.
+__global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal *sc, double *part_s1, double *part_s2) {
   __shared__ double sh[TB];
   const double sigmu = corrector ? sc->sigmu : 0.0;
-  double a = 1.0;
+  double a = 1.0, s1 = 0.0, s2 = 0.0;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
     Elem e = load_elem(s, k, sigmu, corrector != 0, true);
     if (e.ml) {
@@ -210,39 +213,96 @@ __global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal 
       if (e.dlu < 0.0) a = fmin(a, -e.lu / e.dlu);
     }
     if (!corrector) {
-      s.cl[k] = e.dtl * e.dll;
-      s.cu[k] = e.dtu * e.dlu;
+      const double cl = e.dtl * e.dll, cu = e.dtu * e.dlu;
+      s.cl[k] = cl;
+      s.cu[k] = cu;
+      const double wgt = slab_weight(s, k);
+      s1 += wgt * ((e.ml ? e.tl * e.dll + e.ll * e.dtl : 0.0) + (e.mu ? e.tu * e.dlu + e.lu * e.dtu : 0.0));
+      s2 += wgt * ((e.ml ? cl : 0.0) + (e.mu ? cu : 0.0));
     }
   }
   a = block_min(a, sh);
+  if (!corrector) {
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+  }
   if (threadIdx.x == 0) {
     if (!(a >= 0.0)) a = 0.0;  // NaN guard
     atomicMin(&sc->amin_bits, (unsigned long long)__double_as_longlong(a));
+    if (!corrector) {
+      part_s1[blockIdx.x] = s1;
+      part_s2[blockIdx.x] = s2;
+    }
   }
-}
-
-__global__ void __launch_bounds__(TB) k_ipm_muaff(Slab s, const IpmScal *sc, double *part_sum) {
-  __shared__ double sh[TB];
-  const double a = sc->alpha_aff;
-  double acc = 0.0;
-  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
-    Elem e = load_elem(s, k, 0.0, false, true);
-    const double wgt = slab_weight(s, k);
-    if (e.ml) acc += wgt * (e.tl + a * e.dtl) * (e.ll + a * e.dll);
-    if (e.mu) acc += wgt * (e.tu + a * e.dtu) * (e.lu + a * e.dlu);
-  }
-  acc = block_sum(acc, sh);
-  if (threadIdx.x == 0) part_sum[blockIdx.x] = acc;
 }
 
 __global__ void __launch_bounds__(TB) k_ipm_update(Slab s, const IpmScal *sc) {
   const double a = sc->alpha, sigmu = sc->sigmu;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
     Elem e = load_elem(s, k, sigmu, true, true);
-    s.z[k] += a * s.dz[k];
+    s.z[k] += a * (s.dz[k] + (s.dz2 ? s.dz2[k] : 0.0));
     if (e.ml) { s.tl[k] = e.tl + a * e.dtl; s.ll[k] = e.ll + a * e.dll; }
     if (e.mu) { s.tu[k] = e.tu + a * e.dtu; s.lu[k] = e.lu + a * e.dlu; }
   }
+}
+
+// One pass per IPM iteration over BOTH slabs: (optionally) take the previous step z,t,l += alpha*d,
+// then the predictor preparation of the new iterate (D, w, partial sums of complementarity / count /
+// slack residual) and the gradient pre-pass arrays of the fast Riccati path
+//   gm = z - ref,   gd = reg (z - prev) + w      (consensus stages: w only on the owner's particle 0).
+__device__ __forceinline__ void advance_slab(const SlabEx &x, int do_update, double alpha, double sigmu, double &comp,
+                                             double &cnt, double &res) {
+  const Slab &s = x.s;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    double z = s.z[k], w = 0.0;
+    if (x.bounded) {
+      const double lo = s.lo[k], hi = s.hi[k];
+      const bool ml = isfinite(lo), mu = isfinite(hi);
+      double tl = s.tl[k], tu = s.tu[k], ll = s.ll[k], lu = s.lu[k];
+      if (do_update) {  // corrector step, exactly as k_ipm_update
+        const double dz = s.dz[k] + s.dz2[k];
+        const double rl = ml ? z - lo - tl : 0.0, ru = mu ? hi - z - tu : 0.0;
+        const double wl = ml ? (sigmu - s.cl[k] - ll * rl) / tl : 0.0, wu = mu ? (sigmu - s.cu[k] - lu * ru) / tu : 0.0;
+        const double dtl = ml ? dz + rl : 0.0, dtu = mu ? -dz + ru : 0.0;
+        const double dll = ml ? wl - ll - (ll / tl) * dz : 0.0, dlu = mu ? wu - lu + (lu / tu) * dz : 0.0;
+        z += alpha * dz;
+        if (ml) { tl += alpha * dtl; ll += alpha * dll; s.tl[k] = tl; s.ll[k] = ll; }
+        if (mu) { tu += alpha * dtu; lu += alpha * dlu; s.tu[k] = tu; s.lu[k] = lu; }
+        s.z[k] = z;
+      }
+      const double rl = ml ? z - lo - tl : 0.0, ru = mu ? hi - z - tu : 0.0;
+      s.D[k] = (ml ? ll / tl : 0.0) + (mu ? lu / tu : 0.0);
+      w = (ml ? ll * rl / tl : 0.0) - (mu ? lu * ru / tu : 0.0);  // -w_l + w_u with sigma*mu = 0, c = 0
+      s.w[k] = w;
+      const double wgt = slab_weight(s, k);
+      comp += wgt * ((ml ? tl * ll : 0.0) + (mu ? tu * lu : 0.0));
+      cnt += wgt * ((ml ? 1.0 : 0.0) + (mu ? 1.0 : 0.0));
+      res = fmax(res, fmax(fabs(rl), fabs(ru)));
+      if (s.is_u && s.Nc > 0 && slab_weight(s, k) == 0.0) w = 0.0;  // consensus shift counted once
+    } else if (do_update) {
+      z += alpha * (s.dz[k] + s.dz2[k]);
+      s.z[k] = z;
+    }
+    if (x.gm) {
+      x.gm[k] = z - x.ref[k];
+      x.gd[k] = x.reg * (z - x.prev[k]) + w;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(TB) k_ipm_advance(SlabEx X, SlabEx U, int do_update, const IpmScal *sc, double *part_sum,
+                                                    double *part_cnt, double *part_max) {
+  __shared__ double sh[TB];
+  const double alpha = do_update ? sc->alpha : 0.0, sigmu = do_update ? sc->sigmu : 0.0;
+  const int B = gridDim.x;
+  double comp = 0.0, cnt = 0.0, res = 0.0;
+  advance_slab(X, do_update, alpha, sigmu, comp, cnt, res);
+  comp = block_sum(comp, sh); cnt = block_sum(cnt, sh); res = block_max(res, sh);
+  if (threadIdx.x == 0) { part_sum[blockIdx.x] = comp; part_cnt[blockIdx.x] = cnt; part_max[blockIdx.x] = res; }
+  comp = cnt = res = 0.0;
+  advance_slab(U, do_update, alpha, sigmu, comp, cnt, res);
+  comp = block_sum(comp, sh); cnt = block_sum(cnt, sh); res = block_max(res, sh);
+  if (threadIdx.x == 0) { part_sum[B + blockIdx.x] = comp; part_cnt[B + blockIdx.x] = cnt; part_max[B + blockIdx.x] = res; }
 }
 
 // 64-lane deterministic reductions of the block partials (fixed order: lane-strided, then butterfly)
@@ -308,6 +368,21 @@ __global__ void __launch_bounds__(64) k_ipm_scalars(int stage, IpmScal *sc, cons
         sc->sigmu = sc->sigma * sc->mu;
       }
       break;
+    case 9: {  // local S1, S2 (before the cross-rank all-reduce)
+      const double s1 = wave_sum(part_sum, nb), s2 = wave_sum(part_cnt, nb);
+      if (l0) { sc->muaff_sum = s1; sc->pad0 = s2; }
+    } break;
+    case 8:  // alpha_aff, mu_aff(alpha_aff) = (S0 + a S1 + a^2 S2)/cnt, sigma = (mu_aff/mu)^3
+      if (l0) {
+        const double a = __longlong_as_double((long long)sc->amin_bits);
+        sc->alpha_aff = a;
+        sc->amin_bits = one_bits;
+        const double mu_aff = (sc->comp_sum + a * (sc->muaff_sum + a * sc->pad0)) / fmax(sc->cnt, 1.0);
+        const double r = mu_aff / sc->mu;
+        sc->sigma = r * r * r;
+        sc->sigmu = sc->sigma * sc->mu;
+      }
+      break;
     case 7:
       if (l0) {
         double a = __longlong_as_double((long long)sc->amin_bits);
@@ -361,11 +436,12 @@ void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double
                         double *part_max, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_prepare, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, corrector, sc, part_sum, part_cnt, part_max);
 }
-void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_ipm_step, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, corrector, sc);
+void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, double *part_s1, double *part_s2, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_step, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, corrector, sc, part_s1, part_s2);
 }
-void launch_ipm_muaff(const Slab &sl, const IpmScal *sc, double *part_sum, hipStream_t s) {
-  hipLaunchKernelGGL(k_ipm_muaff, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, sc, part_sum);
+void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const IpmScal *sc, double *part_sum, double *part_cnt,
+                        double *part_max, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_advance, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, X, U, do_update, sc, part_sum, part_cnt, part_max);
 }
 void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_update, dim3(grid_for(sl.count) * 4), dim3(TB), 0, s, sl, sc);

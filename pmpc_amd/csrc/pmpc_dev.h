@@ -50,7 +50,6 @@ struct LQArgs {
   // outputs of the forward sweep
   double *dX, *dU;
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
-  int accumulate;  // forward sweep adds into dX/dU (corrector = predictor step + difference step)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
   int *fail;
@@ -64,15 +63,25 @@ struct Slab {
   int owner;
   const double *lo, *hi;
   double *z, *dz;
+  const double *dz2;  // corrector difference step (null during the predictor): the step is dz + dz2
   double *tl, *tu, *ll, *lu, *cl, *cu, *D, *w;
+};
+
+// A slab plus what the fused per-iteration pass needs: bounded or not, and the gradient pre-pass outputs
+struct SlabEx {
+  Slab s;
+  int bounded;
+  const double *ref, *prev;  // X_ref / X_prev (resp. U_ref / U_prev)
+  double *gm, *gd;           // fast-path gradient arrays (null on the generic path)
+  double reg;
 };
 
 // Device-resident IPM scalars.
 struct IpmScal {
   double comp_sum;   // sum w * (t_l l_l + t_u l_u)           (all-reduced: sum)
   double cnt;        // number of finite bounds (weighted)    (all-reduced: sum)
-  double muaff_sum;  //                                         (all-reduced: sum)
-  double pad0;
+  double muaff_sum;  // S1 = sum w (t dl + l dt)                 (all-reduced: sum)
+  double pad0;       // S2 = sum w dt dl                         (all-reduced: sum)
   double res_max;    // max |slack residual|                  (all-reduced: max)
   double viol_max;   // max bound violation of the unconstrained optimum (all-reduced: max)
   unsigned long long amin_bits;  // min step ratio as u64 bits (all-reduced: min)
@@ -89,6 +98,8 @@ void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_generic(const LQArgs &a, hipStream_t s);
 void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s);
+void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, bool with_H, double *Hg, double *tmp, bool solve_now,
+                       double *Lc, double *duc, int *fail, hipStream_t s);
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s);
 
@@ -110,8 +121,9 @@ void launch_ipm_clip(const Slab &sl, hipStream_t s);
 void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s);
 void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s);
-void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, hipStream_t s);
-void launch_ipm_muaff(const Slab &sl, const IpmScal *sc, double *part_sum, hipStream_t s);
+void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, double *part_s1, double *part_s2, hipStream_t s);
+void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const IpmScal *sc, double *part_sum, double *part_cnt,
+                        double *part_max, hipStream_t s);
 void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s);
 // stage: 0 reset, 1 finalize local partials (viol), 2 finalize (comp,cnt,res) partials, 3 mu + reset amin,
 //        4 alpha_aff from amin, 5 finalize muaff partials, 6 sigma, 7 final alpha + nu

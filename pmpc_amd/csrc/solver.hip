@@ -66,7 +66,7 @@ struct SlabBufs {
 };
 
 struct Workspace {
-  DevBuf X, U, dX, dU, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
+  DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   SlabBufs sx, su;
 };
@@ -135,11 +135,11 @@ void read_scalars(pmpc_ctx *c) {
 }
 
 // one structured Newton solve: backward (factor or vector-only) -> reduce -> all-reduce -> dense solve -> forward
-void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast) {
+void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_done = false) {
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
   const int nc = a.Nc * a.u;
-  if (fast && factor) launch_grad_prep(a, s);
+  if (fast && factor && !prep_done) launch_grad_prep(a, s);
   {
     ProfScope ps(c, factor ? 0 : 1);
     if (fast) launch_bwd_fast(a, factor, s);
@@ -148,11 +148,21 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast) {
   if (nc > 0) {
     ProfScope ps(c, 3);
     double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
-    if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
-    launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
-    if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
-    else allreduce(c, gc, nc, ncclFloat64, ncclSum);
-    launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
+    if (nc * nc + nc <= 32) {
+      const bool solve_now = c->world <= 1;
+      launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
+      if (!solve_now) {
+        if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
+        else allreduce(c, gc, nc, ncclFloat64, ncclSum);
+        launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
+      }
+    } else {
+      if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
+      launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
+      if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
+      else allreduce(c, gc, nc, ncclFloat64, ncclSum);
+      launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
+    }
   }
   ProfScope ps(c, 2);
   if (fast) launch_fwd_fast(a, s);
@@ -195,7 +205,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail};
   for (DevBuf *b : all) b->release();
@@ -300,6 +310,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
 
   // ---- workspace ---------------------------------------------------------------------------------
   w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8);
+  w.dX2.ensure(nx * D8); w.dU2.ensure(nu * D8);
   w.K.ensure(nu * a.n * D8); w.Hinv.ensure(nu * u * D8); w.kff.ensure(nu * D8);
   w.gc_part.ensure((size_t)M * nc * D8); w.Hc_part.ensure((size_t)M * nc * nc * D8);
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
@@ -425,9 +436,21 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   const double tol = 1e-12;
   const int max_iter = 80;
   int status = 1;
+  // slabs as the fused per-iteration pass sees them (an unbounded slab still takes the step and feeds the
+  // gradient pre-pass)
+  SlabEx ex, eu;
+  memset(&ex, 0, sizeof(ex));
+  memset(&eu, 0, sizeof(eu));
+  ex.s = sx; eu.s = su;
+  if (!has_xb) { ex.s.count = (long long)nx; ex.s.d = x; ex.s.N = N; ex.s.Nc = Nc; ex.s.owner = a.owner; ex.s.z = w.X.d(); ex.s.dz = w.dX.d(); }
+  if (!has_ub) { eu.s.count = (long long)nu; eu.s.d = u; eu.s.N = N; eu.s.Nc = Nc; eu.s.owner = a.owner; eu.s.is_u = 1; eu.s.z = w.U.d(); eu.s.dz = w.dU.d(); }
+  ex.bounded = has_xb; eu.bounded = has_ub;
+  ex.s.dz2 = w.dX2.d(); eu.s.dz2 = w.dU2.d();
+  ex.ref = p->X_ref; ex.prev = p->X_prev; ex.reg = p->reg_x; ex.gm = fast ? w.xm.d() : nullptr; ex.gd = fast ? w.xd.d() : nullptr;
+  eu.ref = p->U_ref; eu.prev = p->U_prev; eu.reg = p->reg_u; eu.gm = fast ? w.um.d() : nullptr; eu.gd = fast ? w.ud.d() : nullptr;
   for (int it = 1; it <= max_iter; it++) {
-    if (has_xb) launch_ipm_prepare(sx, 0, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
-    if (has_ub) launch_ipm_prepare(su, 0, sc, w.part_sum.d() + B, w.part_cnt.d() + B, w.part_max.d() + B, s);
+    // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
+    launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
     launch_ipm_scalars(2, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), 2 * B, s);
     allreduce(c, &sc->comp_sum, 2, ncclFloat64, ncclSum);
     allreduce(c, &sc->res_max, 1, ncclFloat64, ncclMax);
@@ -443,32 +466,26 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     if (h.mu <= tol && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
     if (it == max_iter) break;
     // predictor (factorisation) ...
-    structured_solve(c, a, true, fast);
+    structured_solve(c, a, true, fast, /*prep_done=*/true);
     inf.structured_solves++;
-    if (has_xb) launch_ipm_step(sx, 0, sc, s);
-    if (has_ub) launch_ipm_step(su, 0, sc, s);
+    if (has_xb) launch_ipm_step(sx, 0, sc, w.part_sum.d(), w.part_cnt.d(), s);
+    if (has_ub) launch_ipm_step(su, 0, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
+    launch_ipm_scalars(9, sc, w.part_sum.d(), w.part_cnt.d(), nullptr, 2 * B, s);
     allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
-    launch_ipm_scalars(4, sc, nullptr, nullptr, nullptr, 0, s);
-    if (has_xb) launch_ipm_muaff(sx, sc, w.part_sum.d(), s);
-    if (has_ub) launch_ipm_muaff(su, sc, w.part_sum.d() + B, s);
-    launch_ipm_scalars(5, sc, w.part_sum.d(), nullptr, nullptr, 2 * B, s);
-    allreduce(c, &sc->muaff_sum, 1, ncclFloat64, ncclSum);
-    launch_ipm_scalars(6, sc, nullptr, nullptr, nullptr, 0, s);
-    // ... corrector (vector sweeps only, same factorisation)
+    allreduce(c, &sc->muaff_sum, 2, ncclFloat64, ncclSum);
+    launch_ipm_scalars(8, sc, nullptr, nullptr, nullptr, 0, s);
+    // ... corrector (vector sweeps only, same factorisation; solves for the difference step)
     if (has_xb) launch_ipm_prepare(sx, 1, sc, nullptr, nullptr, nullptr, s);
     if (has_ub) launch_ipm_prepare(su, 1, sc, nullptr, nullptr, nullptr, s);
-    a.accumulate = 1;  // dz = predictor step + difference step
+    a.dX = w.dX2.d(); a.dU = w.dU2.d();  // the sweeps never read-modify-write: step = dz + dz2
     structured_solve(c, a, false, fast);
-    a.accumulate = 0;
-    if (has_xb) launch_ipm_step(sx, 1, sc, s);
-    if (has_ub) launch_ipm_step(su, 1, sc, s);
+    a.dX = w.dX.d(); a.dU = w.dU.d();
+    sx.dz2 = w.dX2.d(); su.dz2 = w.dU2.d();
+    if (has_xb) launch_ipm_step(sx, 1, sc, nullptr, nullptr, s);
+    if (has_ub) launch_ipm_step(su, 1, sc, nullptr, nullptr, s);
+    sx.dz2 = su.dz2 = nullptr;
     allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
     launch_ipm_scalars(7, sc, nullptr, nullptr, nullptr, 0, s);
-    // z, t, lambda += alpha * step   (a slab without bounds moves by the same device-resident alpha)
-    if (has_xb) launch_ipm_update(sx, sc, s);
-    else launch_axpy_alpha(w.X.d(), w.dX.d(), sc, (long long)nx, s);
-    if (has_ub) launch_ipm_update(su, sc, s);
-    else launch_axpy_alpha(w.U.d(), w.dU.d(), sc, (long long)nu, s);
   }
   if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
   return finish(status);
