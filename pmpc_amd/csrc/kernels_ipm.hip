@@ -212,27 +212,23 @@ __global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal 
       if (e.dtu < 0.0) a = fmin(a, -e.tu / e.dtu);
       if (e.dlu < 0.0) a = fmin(a, -e.lu / e.dlu);
     }
+    const double cl = e.dtl * e.dll, cu = e.dtu * e.dlu;
     if (!corrector) {
-      const double cl = e.dtl * e.dll, cu = e.dtu * e.dlu;
       s.cl[k] = cl;
       s.cu[k] = cu;
-      const double wgt = slab_weight(s, k);
-      s1 += wgt * ((e.ml ? e.tl * e.dll + e.ll * e.dtl : 0.0) + (e.mu ? e.tu * e.dlu + e.lu * e.dtu : 0.0));
-      s2 += wgt * ((e.ml ? cl : 0.0) + (e.mu ? cu : 0.0));
     }
+    const double wgt = slab_weight(s, k);
+    s1 += wgt * ((e.ml ? e.tl * e.dll + e.ll * e.dtl : 0.0) + (e.mu ? e.tu * e.dlu + e.lu * e.dtu : 0.0));
+    s2 += wgt * ((e.ml ? cl : 0.0) + (e.mu ? cu : 0.0));
   }
   a = block_min(a, sh);
-  if (!corrector) {
-    s1 = block_sum(s1, sh);
-    s2 = block_sum(s2, sh);
-  }
+  s1 = block_sum(s1, sh);
+  s2 = block_sum(s2, sh);
   if (threadIdx.x == 0) {
     if (!(a >= 0.0)) a = 0.0;  // NaN guard
     atomicMin(&sc->amin_bits, (unsigned long long)__double_as_longlong(a));
-    if (!corrector) {
-      part_s1[blockIdx.x] = s1;
-      part_s2[blockIdx.x] = s2;
-    }
+    part_s1[blockIdx.x] = s1;
+    part_s2[blockIdx.x] = s2;
   }
 }
 
@@ -319,80 +315,87 @@ __device__ __forceinline__ double wave_max(const double *p, int nb) {
   return v;
 }
 
-__global__ void __launch_bounds__(64) k_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt,
-                                                    const double *part_max, int nb) {
+// Scalar bookkeeping of the IPM with ONE cross-rank exchange per sync point.  PACK finalises this rank's
+// block partials and writes its row of the exchange table xch[world][8] (other rows zeroed); the host
+// all-reduces (sum) the table over RCCL — an all-gather in disguise, so min / max / sum quantities travel
+// together; UNPACK combines the rows and derives the iteration scalars.  world == 1: both in one launch.
+//   columns: 0 step ratio (min)  1 S1 (sum)  2 S2 (sum)  3 failure flag (max)  4 comp (sum)  5 count (sum)
+//            6 slack residual (max)  7 bound violation (max)
+// phases: 0 reset | 1 violation of the equality-only optimum | 2 IPM start (mu) |
+//         3 predictor (alpha_aff, mu_aff polynomial, sigma) | 4 corrector (alpha, nu, next mu / residual)
+__global__ void __launch_bounds__(64) k_ipm_exchange(int phase, int do_pack, int do_unpack, IpmScal *sc, const int *fail,
+                                                     double *xch, int rank, int world, const double *part_sum,
+                                                     const double *part_cnt, const double *part_max, int nb) {
   const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
   const bool l0 = threadIdx.x == 0;
-  switch (stage) {
-    case 0:
-      if (l0) {
-        sc->comp_sum = sc->cnt = sc->muaff_sum = sc->pad0 = 0.0;
-        sc->res_max = sc->viol_max = 0.0;
-        sc->amin_bits = one_bits;
-        sc->mu = sc->sigma = sc->sigmu = 0.0;
-        sc->alpha_aff = sc->alpha = 1.0;
-        sc->nu = 1.0;
-        sc->iter = 0;
-        sc->status = 0;
+  if (phase == 0) {
+    if (l0) {
+      sc->comp_sum = sc->cnt = sc->muaff_sum = sc->pad0 = 0.0;
+      sc->res_max = sc->viol_max = 0.0;
+      sc->amin_bits = one_bits;
+      sc->mu = sc->sigma = sc->sigmu = 0.0;
+      sc->alpha_aff = sc->alpha = 1.0;
+      sc->nu = 1.0;
+      sc->iter = 0;
+      sc->status = 0;
+    }
+    return;
+  }
+  if (do_pack) {
+    double row[8] = {1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (phase == 1) {
+      row[7] = wave_max(part_max, nb);
+    } else if (phase == 2) {
+      row[4] = wave_sum(part_sum, nb);
+      row[5] = wave_sum(part_cnt, nb);
+      row[6] = wave_max(part_max, nb);
+    } else {
+      row[1] = wave_sum(part_sum, nb);
+      row[2] = wave_sum(part_cnt, nb);
+    }
+    row[0] = __longlong_as_double((long long)sc->amin_bits);
+    row[3] = (double)(*fail);
+    for (int k = threadIdx.x; k < world * 8; k += 64) {
+      const int r = k >> 3, cidx = k & 7;
+      double v = 0.0;
+      if (r == rank) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) v = (cidx == q) ? row[q] : v;
       }
-      break;
-    case 1: {
-      const double m = wave_max(part_max, nb);
-      if (l0) sc->viol_max = m;
-    } break;
-    case 2: {
-      const double s = wave_sum(part_sum, nb), c = wave_sum(part_cnt, nb), m = wave_max(part_max, nb);
-      if (l0) { sc->comp_sum = s; sc->cnt = c; sc->res_max = m; }
-    } break;
-    case 3:
-      if (l0) {
-        sc->mu = sc->comp_sum / fmax(sc->cnt, 1.0);
-        sc->amin_bits = one_bits;
-      }
-      break;
-    case 4:
-      if (l0) {
-        sc->alpha_aff = __longlong_as_double((long long)sc->amin_bits);
-        sc->amin_bits = one_bits;
-      }
-      break;
-    case 5: {
-      const double s = wave_sum(part_sum, nb);
-      if (l0) sc->muaff_sum = s;
-    } break;
-    case 6:
-      if (l0) {
-        double mu_aff = sc->muaff_sum / fmax(sc->cnt, 1.0);
-        double r = mu_aff / sc->mu;
-        sc->sigma = r * r * r;
-        sc->sigmu = sc->sigma * sc->mu;
-      }
-      break;
-    case 9: {  // local S1, S2 (before the cross-rank all-reduce)
-      const double s1 = wave_sum(part_sum, nb), s2 = wave_sum(part_cnt, nb);
-      if (l0) { sc->muaff_sum = s1; sc->pad0 = s2; }
-    } break;
-    case 8:  // alpha_aff, mu_aff(alpha_aff) = (S0 + a S1 + a^2 S2)/cnt, sigma = (mu_aff/mu)^3
-      if (l0) {
-        const double a = __longlong_as_double((long long)sc->amin_bits);
-        sc->alpha_aff = a;
-        sc->amin_bits = one_bits;
-        const double mu_aff = (sc->comp_sum + a * (sc->muaff_sum + a * sc->pad0)) / fmax(sc->cnt, 1.0);
-        const double r = mu_aff / sc->mu;
-        sc->sigma = r * r * r;
-        sc->sigmu = sc->sigma * sc->mu;
-      }
-      break;
-    case 7:
-      if (l0) {
-        double a = __longlong_as_double((long long)sc->amin_bits);
-        if (a < 1.0) a = fmin(1.0, fmax(0.99, 1.0 - sc->mu) * a);
-        sc->alpha = a;
-        sc->nu *= (1.0 - a);
-        sc->iter += 1;
-        sc->amin_bits = one_bits;
-      }
-      break;
+      xch[k] = v;
+    }
+  }
+  if (do_pack && do_unpack) __syncthreads();
+  if (do_unpack && l0) {
+    double amin = 1.0, s1 = 0.0, s2 = 0.0, fl = 0.0, comp = 0.0, cnt = 0.0, res = 0.0, viol = 0.0;
+    for (int r = 0; r < world; r++) {  // fixed rank order: every rank computes bit-identical scalars
+      const double *q = xch + r * 8;
+      amin = fmin(amin, q[0]); s1 += q[1]; s2 += q[2]; fl = fmax(fl, q[3]);
+      comp += q[4]; cnt += q[5]; res = fmax(res, q[6]); viol = fmax(viol, q[7]);
+    }
+    sc->status = (int)fl;
+    sc->amin_bits = one_bits;
+    if (phase == 1) {
+      sc->viol_max = viol;
+    } else if (phase == 2) {
+      sc->comp_sum = comp; sc->cnt = cnt; sc->res_max = res;
+      sc->mu = comp / fmax(cnt, 1.0);
+    } else if (phase == 3) {  // mu_aff(alpha_aff) = (S0 + a S1 + a^2 S2)/cnt, sigma = (mu_aff/mu)^3
+      sc->alpha_aff = amin;
+      const double mu_aff = (sc->comp_sum + amin * (s1 + amin * s2)) / fmax(sc->cnt, 1.0);
+      const double r3 = mu_aff / sc->mu;
+      sc->sigma = r3 * r3 * r3;
+      sc->sigmu = sc->sigma * sc->mu;
+    } else {  // phase 4: step length of the corrector, then the scalars of the NEXT iterate by the same polynomial
+      double a = amin;
+      if (a < 1.0) a = fmin(1.0, fmax(0.99, 1.0 - sc->mu) * a);
+      sc->alpha = a;
+      sc->nu *= (1.0 - a);
+      sc->iter += 1;
+      sc->comp_sum = sc->comp_sum + a * (s1 + a * s2);
+      sc->mu = sc->comp_sum / fmax(sc->cnt, 1.0);
+      sc->res_max *= (1.0 - a);
+    }
   }
 }
 
@@ -446,7 +449,8 @@ void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const I
 void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_update, dim3(grid_for(sl.count) * 4), dim3(TB), 0, s, sl, sc);
 }
-void launch_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt, const double *part_max,
-                        int nblocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_ipm_scalars, dim3(1), dim3(64), 0, s, stage, sc, part_sum, part_cnt, part_max, nblocks);
+void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
+                         const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_ipm_exchange, dim3(1), dim3(64), 0, s, phase, pack ? 1 : 0, unpack ? 1 : 0, sc, fail, xch, rank, world,
+                     part_sum, part_cnt, part_max, nblocks);
 }

@@ -125,10 +125,9 @@ void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, double *part_s1
 void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s);
 void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s);
-// stage: 0 reset, 1 finalize local partials (viol), 2 finalize (comp,cnt,res) partials, 3 mu + reset amin,
-//        4 alpha_aff from amin, 5 finalize muaff partials, 6 sigma, 7 final alpha + nu
-void launch_ipm_scalars(int stage, IpmScal *sc, const double *part_sum, const double *part_cnt,
-                        const double *part_max, int nblocks, hipStream_t s);
+// phases: 0 reset | 1 violation | 2 IPM start | 3 predictor | 4 corrector (see kernels_ipm.hip)
+void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
+                         const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s);
 
 // ---- dynamics.hip -------------------------------------------------------------------------------
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,

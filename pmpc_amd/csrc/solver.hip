@@ -67,7 +67,7 @@ struct SlabBufs {
 
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
-  DevBuf zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
+  DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   SlabBufs sx, su;
 };
 
@@ -128,10 +128,27 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
   }
 };
 
-void read_scalars(pmpc_ctx *c) {
+void read_scalars(pmpc_ctx *c) {  // sc->status carries the (cross-rank) failure flag of the last exchange
   HIP_CHECK(hipMemcpyAsync(c->sc_host, c->ws.sc.p, sizeof(IpmScal), hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipMemcpyAsync(c->fail_host, c->ws.fail.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
+  *c->fail_host = c->sc_host->status;
+}
+
+// one sync point of the IPM: local partials -> exchange table -> (RCCL all-reduce(sum) == all-gather) -> scalars
+void exchange(pmpc_ctx *c, int phase) {
+  Workspace &w = c->ws;
+  IpmScal *sc = (IpmScal *)w.sc.p;
+  const int B2 = 2 * PMPC_RED_BLOCKS;
+  if (c->world <= 1) {
+    launch_ipm_exchange(phase, true, true, sc, (const int *)w.fail.p, w.xch.d(), 0, 1, w.part_sum.d(), w.part_cnt.d(),
+                        w.part_max.d(), B2, c->stream);
+    return;
+  }
+  launch_ipm_exchange(phase, true, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, w.part_sum.d(),
+                      w.part_cnt.d(), w.part_max.d(), B2, c->stream);
+  allreduce(c, w.xch.p, (size_t)c->world * 8, ncclFloat64, ncclSum);
+  launch_ipm_exchange(phase, false, true, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, w.part_sum.d(),
+                      w.part_cnt.d(), w.part_max.d(), B2, c->stream);
 }
 
 // one structured Newton solve: backward (factor or vector-only) -> reduce -> all-reduce -> dense solve -> forward
@@ -206,7 +223,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
-                   &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
+                   &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
@@ -316,7 +333,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
   w.red_tmp.ensure((size_t)64 * ((size_t)nc * nc + nc) * D8);
   w.Hg.ensure(((size_t)nc * nc + nc) * D8); w.Lc.ensure((size_t)nc * nc * D8); w.duc.ensure((size_t)nc * D8);
-  w.sc.ensure(sizeof(IpmScal)); w.fail.ensure(sizeof(int));
+  w.sc.ensure(sizeof(IpmScal)); w.fail.ensure(sizeof(int)); w.xch.ensure((size_t)c->world * 8 * D8);
   const bool fresh_parts = w.part_sum.bytes == 0;
   w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_cnt.ensure(2 * PMPC_RED_BLOCKS * D8);
   w.part_max.ensure(2 * PMPC_RED_BLOCKS * D8);
@@ -355,7 +372,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   IpmScal *sc = (IpmScal *)w.sc.p;
 
   // ---- 1. equality-only optimum: one Newton step from a dynamics-consistent base point -----------
-  launch_ipm_scalars(0, sc, nullptr, nullptr, nullptr, 0, s);
+  launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s);
   launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
   if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
   else launch_rollout(a, w.U.d(), w.X.d(), s);
@@ -408,15 +425,14 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   const int B = PMPC_RED_BLOCKS;
 
   if (!has_xb && !has_ub) {
+    exchange(c, 1);  // only for the failure flag
     read_scalars(c);
     if (*c->fail_host) return finish(2);
     return finish(0);
   }
   if (has_xb) launch_violation(sx, w.part_max.d(), s);
   if (has_ub) launch_violation(su, w.part_max.d() + B, s);
-  launch_ipm_scalars(1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), 2 * B, s);
-  allreduce(c, &sc->res_max, 2, ncclFloat64, ncclMax);
-  allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
+  exchange(c, 1);
   read_scalars(c);
   inf.max_violation = c->sc_host->viol_max;
   if (*c->fail_host || !(c->sc_host->viol_max == c->sc_host->viol_max)) return finish(2);
@@ -451,12 +467,10 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   for (int it = 1; it <= max_iter; it++) {
     // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
     launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
-    launch_ipm_scalars(2, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), 2 * B, s);
-    allreduce(c, &sc->comp_sum, 2, ncclFloat64, ncclSum);
-    allreduce(c, &sc->res_max, 1, ncclFloat64, ncclMax);
-    allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
-    launch_ipm_scalars(3, sc, nullptr, nullptr, nullptr, 0, s);
-    read_scalars(c);
+    if (it == 1) {  // later iterates get mu / residual from the corrector's step polynomial (phase 4)
+      exchange(c, 2);
+      read_scalars(c);
+    }
     const IpmScal &h = *c->sc_host;
     if (verbose)
       printf("pmpc_hip: ipm it %2d  mu %9.3e  slack_res %9.3e  nu %9.3e  alpha %6.4f  sigma %8.2e\n", it, h.mu, h.res_max,
@@ -470,10 +484,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     inf.structured_solves++;
     if (has_xb) launch_ipm_step(sx, 0, sc, w.part_sum.d(), w.part_cnt.d(), s);
     if (has_ub) launch_ipm_step(su, 0, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
-    launch_ipm_scalars(9, sc, w.part_sum.d(), w.part_cnt.d(), nullptr, 2 * B, s);
-    allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
-    allreduce(c, &sc->muaff_sum, 2, ncclFloat64, ncclSum);
-    launch_ipm_scalars(8, sc, nullptr, nullptr, nullptr, 0, s);
+    exchange(c, 3);
     // ... corrector (vector sweeps only, same factorisation; solves for the difference step)
     if (has_xb) launch_ipm_prepare(sx, 1, sc, nullptr, nullptr, nullptr, s);
     if (has_ub) launch_ipm_prepare(su, 1, sc, nullptr, nullptr, nullptr, s);
@@ -481,11 +492,11 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     structured_solve(c, a, false, fast);
     a.dX = w.dX.d(); a.dU = w.dU.d();
     sx.dz2 = w.dX2.d(); su.dz2 = w.dU2.d();
-    if (has_xb) launch_ipm_step(sx, 1, sc, nullptr, nullptr, s);
-    if (has_ub) launch_ipm_step(su, 1, sc, nullptr, nullptr, s);
+    if (has_xb) launch_ipm_step(sx, 1, sc, w.part_sum.d(), w.part_cnt.d(), s);
+    if (has_ub) launch_ipm_step(su, 1, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
     sx.dz2 = su.dz2 = nullptr;
-    allreduce(c, &sc->amin_bits, 1, ncclUint64, ncclMin);
-    launch_ipm_scalars(7, sc, nullptr, nullptr, nullptr, 0, s);
+    exchange(c, 4);
+    read_scalars(c);
   }
   if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
   return finish(status);
