@@ -25,8 +25,11 @@
 // current stage computes.  The permutation is applied wherever a global address is formed from a
 // state index and nowhere else.
 //
-// Factor storage of this path (private to it): a.K = gains (udim x xdim, col-major),
-// a.Hinv = Cholesky factor of Huu, col-major lower triangle with RECIPROCAL diagonal.
+// Factor storage of this path (private to it): ONE 64-double record per (particle, stage) in a.K, indexed by
+// the lane that owns the value — record[c + 16 g] = K[g][pi(c)] for state columns c, Huu^-1[g][c - XP] for
+// control columns — so the factor sweep writes it with a single fully coalesced 512-byte store and the
+// vector / forward sweeps read gains and Huu^-1 back with a single coalesced load (per-lane scattered
+// 8/16-byte stores of K, chol(Huu), k cost 25 % of the factor sweep before).  a.kff = feed-forward k.
 //
 // Reference semantics: same Newton system as kernels_generic.hip (PMPC.jl/src/lqp_utils.jl:2-393).
 #include "pmpc_dev.h"
@@ -64,13 +67,12 @@ __device__ __forceinline__ double grp_allsum(double v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
-// 1/sqrt(d) to full double precision: v_rsq_f64 seed + two Newton steps
+// 1/sqrt(d): v_rsq_f64 seed (measured max rel. error 5.1e-8 on gfx950, tools/micro/rsq_test.hip) + ONE Newton
+// step -> 3.8e-15; a second step (3.4e-16) buys nothing for a Cholesky pivot and sits on the critical path
 __device__ __forceinline__ double rsqrt_d(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  double h = 0.5 * d;
-  r = r * (1.5 - h * r * r);
-  r = r * (1.5 - h * r * r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(d);
+  const double e = fma(-0.5 * d * r, r, 0.5);  // 0.5 (1 - d r^2)
+  return fma(r, e, r);
 }
 __device__ __forceinline__ const double *badd(const double *p, long long bytes) {
   return (const double *)((const char *)p + bytes);
@@ -197,32 +199,18 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   unsigned ou_g = (unsigned)(((pbase + N - 1) * UD + (gu ? g : 0)) * D8);
   unsigned ou_0 = (unsigned)(((pbase + N - 1) * UD) * D8);
   constexpr unsigned SX = XD * D8, SU = UD * D8;
-  double *pK = a.K + (pbase + N - 1) * (UD * XD) + (gu ? g : 0) + UD * (L.cxv ? L.oc : 0);
-  const bool fK = L.cxv && gu;
-  const double *pKl = fK ? pK : Z;  // load side of the gains (vector-only sweep)
-  const int sK = fK ? -(int)D8 * (UD * XD) : 0;
-  double *pL = a.Hinv + (pbase + N - 1) * (UD * UD);
+  double *pRec = a.K + (pbase + N - 1) * 64 + lane;  // factor record of stage N-1, this lane's slot
+  const bool frec = (L.cxv || L.cu) && gu;           // lanes whose slot carries a value
 
   double S[KS], s_row[KS];
   double s_col;
   // "next stage" registers
-  double Fn[KS], Qn[KS], xmn[KS], gxn = 0.0, Rn = 0.0, umn = 0.0, gun, Dun = 0.0, Dxn = 0.0, Kn = 0.0, Ln[UD][UD], Ldn[UD];
+  double Fn[KS], Rn = 0.0, umn = 0.0, gun, recn = 0.0;
 
   auto load_row = [&](const double *p, double *dst) {
 #pragma unroll
     for (int r = 0; r < KS; r++) dst[r] = (!PADX || L.row0 + r < XD || p == Z) ? p[r] : 0.0;
   };
-  auto load_L = [&]() {
-#pragma unroll
-    for (int q = 0; q < UD; q++)
-#pragma unroll
-      for (int pp = q; pp < UD; pp++) {
-        const double v = pL[pp + UD * q];
-        if (pp == q) Ldn[q] = v;
-        else Ln[pp][q] = v;
-      }
-  };
-
   // ---- terminal: S = Q~_{N-1} (+Dx), s = g_x,N-1 ; first "next" loads (stage N-1) -----------------------
   {
     double Q0[KS], part = 0.0;
@@ -241,77 +229,48 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     }
     s_col = part + *pgx;  // zero on lanes without a state column
     col_to_row<KS>(s_col, g, s_row);
-    // stage N-1 early data
+    // stage N-1 data needed the moment the stage starts (everything else is issued at the top of its stage)
     load_row(pF, Fn);
     gun = *pgu;
     if (FACTOR) {
       Rn = *pR;
       umn = gu ? ldo(a.um, ou_g) : 0.0;
-      if (HUB) Dun = *pDu;
-      if (N > 1) {
-        pQ = badd(pQ, sQ);
-        load_row(pQ, Qn);
-        if (HXB) { pDx = badd(pDx, sDx); Dxn = *pDx; }
-      }
     } else {
-      Kn = *pKl;
-      load_L();
-    }
-    // state side of stage N-2 (consumed at the END of stage N-1)
-    if (N > 1) {
-      ox_row -= SX;
-      pgx = badd(pgx, sgx);
-      gxn = *pgx;
-      if (FACTOR) {
-#pragma unroll
-        for (int r = 0; r < KS; r++) {
-          const bool rv = !PADX || (L.row0 + r < XD);
-          xmn[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
-        }
-      }
+      recn = *pRec;
     }
   }
 
   for (int j = N - 1; j >= 0; j--) {
     const bool cons = j < Nc;
     // ---- rotate the pipeline registers ----------------------------------------------------------------
-    double Fr[KS], Qc[KS], Lc[UD][UD], Ld[UD];
+    double Fr[KS], Qc[KS];
 #pragma unroll
-    for (int r = 0; r < KS; r++) { Fr[r] = Fn[r]; Qc[r] = Qn[r]; }
-    const double Rc = Rn, um_g = umn, Du_c = Dun, Dx_c = Dxn;
-    double gu_c = gun, Kreg = Kn;
-    if (!FACTOR) {
-#pragma unroll
-      for (int q = 0; q < UD; q++) {
-        Ld[q] = Ldn[q];
-#pragma unroll
-        for (int pp = q + 1; pp < UD; pp++) Lc[pp][q] = Ln[pp][q];
-      }
-      if (HUB && cons && !own0) gu_c = 0.0;  // consensus shift counted once, on the owner's particle 0
-    }
+    for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
+    const double Rc = Rn, um_g = umn;
+    double gu_c = gun, rec = recn;  // rec: this lane's slot of the stage's factor record
+    if (!FACTOR && HUB && cons && !own0) gu_c = 0.0;  // consensus shift counted once, on the owner's particle 0
     if (j == 0) {  // stage 0 has no incoming state: A~_0 = 0
 #pragma unroll
       for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
     }
-    // ---- state side of stage j-1 (prefetched one stage ahead as well) ---------------------------------
-    double xm_row[KS];
-    const double gx_c = gxn;
-#pragma unroll
-    for (int r = 0; r < KS; r++) xm_row[r] = xmn[r];
+    // ---- same-stage loads (consumed after the G products resp. at the end of the stage) ----------------
+    double xm_row[KS], gx_c = 0.0, Du_c = 0.0, Dx_c = 0.0;
+    if (FACTOR && HUB) { Du_c = *pDu; pDu = badd(pDu, sDu); }
     if (j > 0) {
-      if (j > 1) {
-        ox_row -= SX;
-        pgx = badd(pgx, sgx);
-        gxn = *pgx;
-        if (FACTOR) {
+      ox_row -= SX;
+      pgx = badd(pgx, sgx);
+      gx_c = *pgx;
+      if (FACTOR) {
+        pQ = badd(pQ, sQ);
+        load_row(pQ, Qc);
+        if (HXB) { pDx = badd(pDx, sDx); Dx_c = *pDx; }
 #pragma unroll
-          for (int r = 0; r < KS; r++) {
-            const bool rv = !PADX || (L.row0 + r < XD);
-            xmn[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
-          }
+        for (int r = 0; r < KS; r++) {
+          const bool rv = !PADX || (L.row0 + r < XD);
+          xm_row[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
         }
       }
-      // ---- prefetch stage j-1's early data --------------------------------------------------------------
+      // ---- prefetch what stage j-1 needs the moment it starts ------------------------------------------
       pF = badd(pF, sF);
       load_row(pF, Fn);
       pgu = badd(pgu, sgu);
@@ -321,17 +280,9 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
         pR = badd(pR, sR);
         Rn = *pR;
         umn = gu ? ldo(a.um, ou_g) : 0.0;
-        if (HUB) { pDu = badd(pDu, sDu); Dun = *pDu; }
-        if (j > 1) {
-          pQ = badd(pQ, sQ);
-          load_row(pQ, Qn);
-          if (HXB) { pDx = badd(pDx, sDx); Dxn = *pDx; }
-        }
       } else {
-        pKl = badd(pKl, sK);
-        Kn = *pKl;
-        pL -= UD * UD;
-        load_L();
+        pRec -= 64;
+        recn = *pRec;
       }
     }
 
@@ -372,9 +323,9 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       break;
     }
 
-    double col[UD];
     if (FACTOR) {
       // ---- Cholesky of Huu on lane-uniform values (readlane broadcast of the lower triangle) --------
+      double Lc[UD][UD], Ld[UD], col[UD];
       bool bad = false;
 #pragma unroll
       for (int q = 0; q < UD; q++) {
@@ -392,39 +343,29 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
         }
       }
       if (bad && lane == 0) *a.fail = 2;
-      // ---- gather the control rows column-wise; column XP carries hu so that one in-lane
-      //      substitution yields both K[:, c] and the feed-forward k = Huu^-1 hu -----------------------
+      // ---- gather the control rows column-wise and substitute in-lane: state columns give K[:, c], the
+      //      control columns get unit right-hand sides and give Huu^-1[:, c - XP] -------------------------
 #pragma unroll
       for (int k = 0; k < UD; k++) {
         const double t = __shfl(H[KS], c + 16 * k, 64);  // H[XP + k][c]
-        col[k] = (c == XP) ? hu[k] : t;
+        col[k] = L.cu ? (L.cb == k ? 1.0 : 0.0) : t;
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < UD; k++) col[k] = hu[k];
-    }
-    const double hug = pick<UD>(hu, g);
-    chol_solve<UD>(Lc, Ld, col);
-    if (FACTOR) {
+      chol_solve<UD>(Lc, Ld, col);
       const double Kg = pick<UD>(col, g);
-      Kreg = (L.cxv && gu) ? Kg : 0.0;
-      v4d Sn = mfma(H[KS], (gu && c != XP) ? -Kg : 0.0, H);  // S' = Hxx - Hxu K (columns >= XP are never used)
+      rec = frec ? Kg : 0.0;
+      v4d Sn = mfma(H[KS], (L.cxv && gu) ? -Kg : 0.0, H);  // S' = Hxx - Hxu K (columns >= XP are never used)
 #pragma unroll
       for (int r = 0; r < KS; r++) S[r] = Sn[r];
-      if (L.cxv && gu) *pK = Kreg;
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < UD; q++)
-#pragma unroll
-          for (int pp = q; pp < UD; pp++) pL[pp + UD * q] = (pp == q) ? Ld[q] : Lc[pp][q];
-      }
-      pK -= UD * XD;
-      pL -= UD * UD;
+      *pRec = rec;  // one coalesced 512-byte store per stage
+      pRec -= 64;
     }
-    if (lane == (FACTOR ? XP : 0)) {
-#pragma unroll
-      for (int b = 0; b < UD; b++) *(double *)((char *)a.kff + ou_0 + b * 8u) = col[b];
-    }
+    const double Kreg = L.cxv ? rec : 0.0;
+    // ---- feed-forward k = Huu^-1 hu: the control quad of k-group g holds row g of Huu^-1 ---------------
+    const double hug = pick<UD>(hu, g);
+    double kq = L.cu ? rec * pick<UD>(hu, L.cb) : 0.0;
+    kq += dpp_d<0xB1>(kq);
+    kq += dpp_d<0x4E>(kq);  // sum over the aligned quad c = XP .. XP+3
+    if (c == XP && gu) *(double *)((char *)a.kff + ou_0 + g * 8u) = kq;
     if (j == 0) break;
     // ---- s_{j-1} = h_x - K' hu + g_x,j-1 -------------------------------------------------------------
     double p2 = -Kreg * hug;
@@ -484,8 +425,8 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
                            : (L.cu ? a.fu + pbase * (XD * UD) + XD * L.cb + L.row0 : Z);
   const int sF = fF ? (int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
   const bool fK = L.cxv && gu && !ROLLOUT;
-  const double *pK = fK ? a.K + pbase * (UD * XD) + g + UD * L.oc : Z;
-  const int sK = fK ? (int)D8 * (UD * XD) : 0;
+  const double *pK = fK ? a.K + pbase * 64 + lane : Z;  // this lane's slot of the factor records
+  const int sK = fK ? (int)D8 * 64 : 0;
   // control-column source: feed-forward k_j (per k-group) resp. rollout inputs (per control column)
   const bool fk = gu && !ROLLOUT;
   const double *pk = fk ? a.kff + pbase * UD + g : Z;

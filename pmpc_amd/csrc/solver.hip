@@ -328,7 +328,11 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   // ---- workspace ---------------------------------------------------------------------------------
   w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8);
   w.dX2.ensure(nx * D8); w.dU2.ensure(nu * D8);
-  w.K.ensure(nu * a.n * D8); w.Hinv.ensure(nu * u * D8); w.kff.ensure(nu * D8);
+  {  // generic path: K (u x n) per stage; fast path: one 64-double factor record per stage
+    size_t kb = nu * a.n * D8, rb = (size_t)M * N * 64 * D8;
+    w.K.ensure(kb > rb ? kb : rb);
+  }
+  w.Hinv.ensure(nu * u * D8); w.kff.ensure(nu * D8);
   w.gc_part.ensure((size_t)M * nc * D8); w.Hc_part.ensure((size_t)M * nc * nc * D8);
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
   w.red_tmp.ensure((size_t)64 * ((size_t)nc * nc + nc) * D8);
