@@ -302,17 +302,17 @@ __global__ void __launch_bounds__(TB) k_ipm_advance(SlabEx X, SlabEx U, int do_u
 }
 
 // 64-lane deterministic reductions of the block partials (fixed order: lane-strided, then butterfly)
-__device__ __forceinline__ double wave_sum(const double *p, int nb) {
+__device__ __forceinline__ double wave_sum(const double *p, int nb) {  // block of TB threads, fixed order
+  __shared__ double sh[TB];
   double v = 0.0;
-  for (int b = threadIdx.x; b < nb; b += 64) v += p[b];
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int b = threadIdx.x; b < nb; b += TB) v += p[b];
+  return block_sum(v, sh);
 }
 __device__ __forceinline__ double wave_max(const double *p, int nb) {
+  __shared__ double sh[TB];
   double v = 0.0;
-  for (int b = threadIdx.x; b < nb; b += 64) v = fmax(v, p[b]);
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  for (int b = threadIdx.x; b < nb; b += TB) v = fmax(v, p[b]);
+  return block_max(v, sh);
 }
 
 // Scalar bookkeeping of the IPM with ONE cross-rank exchange per sync point.  PACK finalises this rank's
@@ -323,7 +323,7 @@ __device__ __forceinline__ double wave_max(const double *p, int nb) {
 //            6 slack residual (max)  7 bound violation (max)
 // phases: 0 reset | 1 violation of the equality-only optimum | 2 IPM start (mu) |
 //         3 predictor (alpha_aff, mu_aff polynomial, sigma) | 4 corrector (alpha, nu, next mu / residual)
-__global__ void __launch_bounds__(64) k_ipm_exchange(int phase, int do_pack, int do_unpack, IpmScal *sc, const int *fail,
+__global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int do_unpack, IpmScal *sc, const int *fail,
                                                      double *xch, int rank, int world, const double *part_sum,
                                                      const double *part_cnt, const double *part_max, int nb) {
   const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(64) k_ipm_exchange(int phase, int do_pack, int
     }
     row[0] = __longlong_as_double((long long)sc->amin_bits);
     row[3] = (double)(*fail);
-    for (int k = threadIdx.x; k < world * 8; k += 64) {
+    for (int k = threadIdx.x; k < world * 8; k += TB) {
       const int r = k >> 3, cidx = k & 7;
       double v = 0.0;
       if (r == rank) {
@@ -451,6 +451,6 @@ void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
 }
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
                          const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_ipm_exchange, dim3(1), dim3(64), 0, s, phase, pack ? 1 : 0, unpack ? 1 : 0, sc, fail, xch, rank, world,
+  hipLaunchKernelGGL(k_ipm_exchange, dim3(1), dim3(TB), 0, s, phase, pack ? 1 : 0, unpack ? 1 : 0, sc, fail, xch, rank, world,
                      part_sum, part_cnt, part_max, nblocks);
 }

@@ -90,7 +90,7 @@ struct IpmScal {
   int iter, status;
 };
 
-#define PMPC_RED_BLOCKS 512
+#define PMPC_RED_BLOCKS 1024
 
 // ---- kernels_generic.hip ------------------------------------------------------------------------
 size_t lq_generic_lds_bytes(const LQArgs &a);
