@@ -11,3 +11,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 benc
 python3 bench.py --steps 20 --warmup 3 > $out/bench_full.log 2>&1
 grep '^{' $out/bench_full.log | cut -c1-400
 find $out -name '*.csv' | head -20
+# other BASELINE configs (no CPU baseline): C = quadrotor M=1024, B = unicycle M=256 N=30
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M 1024 > $out/bench_C.log 2>&1
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M 256 --N 30 --model unicycle > $out/bench_B.log 2>&1
+grep -h '^{' $out/bench_C.log $out/bench_B.log | cut -c1-200

@@ -2,7 +2,7 @@
 """Summarise a tools/profile_gpu.sh run into profiles/: kernel stats table, PMC HBM traffic per launch of
 the dominant kernel (gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE
 are in KiB; FETCH_SIZE under-reports wide coalesced reads, so the read-side factor is CALIBRATED in the same
-run on k_axpy_alpha, an 8-B-per-lane streaming kernel with an exactly known byte count)."""
+run on k_axpy, an 8-B-per-lane streaming kernel with an exactly known byte count)."""
 import csv
 import glob
 import json
@@ -28,13 +28,14 @@ fetch, write = pmc("fetch"), pmc("write")
 M, N, x, u = 4096, 50, 12, 4
 nx = M * N * x
 key = lambda d, s: next(k for k in d if s in k)
-ax = key(fetch, "k_axpy_alpha")
-ax_read_true = 2 * nx * 8  # y and x streams
+ax = key(fetch, "k_axpy(")  # X += dX after the equality-only solve: 2 streams in, 1 out, nx doubles each
+nu = M * N * u
+ax_read_true = 2 * 8 * (nx + nu) / 2  # y and x streams; k_axpy runs once on X (nx) and once on U (nu) per solve
 ax_fetch = sum(fetch[ax]) / len(fetch[ax]) * 1024
 read_factor = ax_read_true / ax_fetch
-ax_write = sum(write[key(write, "k_axpy_alpha")]) / len(write[key(write, "k_axpy_alpha")]) * 1024
-out = {"calibration": {"kernel": "k_axpy_alpha", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
-                       "read_factor": read_factor, "true_write_bytes": nx * 8, "WRITE_SIZE_bytes": ax_write}}
+ax_write = sum(write[key(write, "k_axpy(")]) / len(write[key(write, "k_axpy(")]) * 1024
+out = {"calibration": {"kernel": "k_axpy", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
+                       "read_factor": read_factor, "true_write_bytes": 8 * (nx + nu) / 2, "WRITE_SIZE_bytes": ax_write}}
 for name, label in (("k_bwd_fast<12, 4, true", "bwd_factor"), ("k_bwd_fast<12, 4, false", "bwd_vec"), ("k_fwd_fast<12, 4, false", "fwd")):
     kf, kw = key(fetch, name), key(write, name)
     fb = sum(fetch[kf]) / len(fetch[kf]) * 1024
