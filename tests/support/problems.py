@@ -51,6 +51,17 @@ CASES = [
     (70, 7, 5, 3, 1, 0.5, None, None, None),
     (5, 9, 12, 4, 1, 0.4, None, None, None),
     (5, 9, 12, 4, 0, None, None, None, None),
+    # edge cases: single stage / single particle, state bounds only, padded fast-path dims, odd particle counts
+    (1, 1, 4, 2, 0, 0.3, None, None, None),
+    (3, 1, 4, 2, 1, 0.3, None, None, None),
+    (1, 2, 2, 1, 0, 0.5, None, None, None),
+    (6, 10, 4, 2, 1, None, 2.5, None, None),
+    (6, 10, 12, 4, 0, None, 4.0, None, None),
+    (7, 12, 5, 3, 1, 0.4, 6.0, None, None),
+    (301, 5, 2, 1, 1, 0.5, None, None, None),
+    (9, 6, 6, 2, 0, 0.3, 8.0, None, None),
+    (4, 7, 8, 4, 1, 0.5, None, None, None),
+    (3, 5, 4, 2, 1, None, None, None, 0.4),
 ]
 
 

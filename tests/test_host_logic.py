@@ -140,3 +140,52 @@ def test_filters_and_table_printer():
     assert tp.make_values((3, 1.5)).count("|") == 3 and "0003" in tp.make_values((3, 1.5))
     assert tp.make_header().splitlines()[0] == tp.make_footer()
     assert atleast_nd(np.zeros((2, 3)), 4).shape == (1, 1, 2, 3) and atleast_nd(None, 3) is None
+
+
+def test_problem_builder_defaults_and_tiling():
+    """pmpc/problem_struct.py:10-155 behaviour: dims inference, defaults, M-tiling, Nc injection, Mapping."""
+    from pmpc_amd.problem_struct import Problem
+
+    p = Problem(N=20, xdim=4, udim=2)
+    assert p.Q.shape == (20, 4, 4) and np.all(p.R[0] == 0.1 * np.eye(2)) and p.reg_x == 1.0 and p.max_it == 30
+    p.x0 = np.ones(4)
+    p.u_l = -np.ones(2)  # tiled over N
+    assert p.u_l.shape == (20, 2) and p.x_l is None
+    p.f_fx_fu_fn = lambda X, U: None
+    d = dict(**p)
+    assert set(d) >= {"Q", "R", "x0", "X_ref", "U_ref", "X_prev", "U_prev", "u_l", "u_u", "x_l", "x_u", "solver_settings",
+                      "reg_x", "reg_u", "max_it", "res_tol", "verbose", "slew_rate", "f_fx_fu_fn"}
+    assert "Nc" not in d["solver_settings"]
+    q = Problem(xdim=4, udim=2, N=20, M=3, Nc=3, max_it=100, verbose=False)
+    q.X_ref = np.ones((20, 4))
+    assert q.X_ref.shape == (3, 20, 4) and q.Q.shape == (3, 20, 4, 4) and q.x0.shape == (3, 4)
+    q.f_fx_fu_fn = lambda X, U: None
+    assert q.to_dict()["solver_settings"]["Nc"] == 3 and q.to_dict()["max_it"] == 100
+    r = Problem(Q=np.tile(np.eye(3), (7, 1, 1)), R=np.tile(np.eye(1), (7, 1, 1)))  # dims from arrays
+    assert r.dims == dict(N=7, xdim=3, udim=1)
+    with pytest.raises(ValueError):
+        Problem(N=3, xdim=2)
+
+
+@pytest.mark.skipif(not (ROOT.parent / "reference" / "pmpc" / "problem_struct.py").exists(), reason="needs /root/reference (build container only)")
+def test_problem_builder_matches_reference():
+    import importlib.util
+
+    from pmpc_amd.problem_struct import Problem
+
+    spec = importlib.util.spec_from_file_location("ref_problem_struct", ROOT.parent / "reference" / "pmpc" / "problem_struct.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    kw = dict(xdim=4, udim=2, N=9, M=2, Nc=2, reg_x=3.0, X_ref=np.arange(36.0).reshape(9, 4))
+    a, b = Problem(**kw), ref.Problem(**kw)
+    fn = lambda X, U: None
+    for p in (a, b):
+        p.f_fx_fu_fn = fn
+        p.u_l, p.u_u = -np.ones(2), np.ones(2)
+    da, db = a.to_dict(), b.to_dict()
+    assert set(da) == set(db)
+    for k in db:
+        if isinstance(db[k], np.ndarray):
+            np.testing.assert_array_equal(da[k], db[k], err_msg=k)
+        elif k != "f_fx_fu_fn":
+            assert da[k] == db[k], k
