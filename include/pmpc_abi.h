@@ -57,7 +57,7 @@ void c_lqp_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t 
 /* replaces PMPC.jl/src/c_interface.jl:146-214 (prototype: module.cpp:17-23).
  * smooth_alpha = NaN => hard constraints (PMPC.jl/src/main.jl:242-244).  `solver` is accepted
  * for signature compatibility ("ecos" | "cosmo" | "mosek" | "gurobi"); see DESIGN.md for the
- * documented deviation of this entry point from the reference's epsilon-anchored cone objective. */
+ * documented deviation of this entry point from the reference's epsilon-anchored cone objective (M > 1). */
 void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
                    double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
                    double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,

@@ -600,9 +600,9 @@ void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_
                    double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x, double reg_u,
                    double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, double smooth_alpha,
                    char *solver) {
-  // DESIGN.md "cone entry point": the reference's epsilon-anchored epigraph objective
-  // (PMPC.jl/src/main.jl:204-238) has the same minimiser as the QP for M = 1 and differs at the
-  // 1e-3 relative level for M > 1; smoothing (smooth_alpha != NaN) is not reproduced yet.
+  // DESIGN.md section 2, "c_lcone_solve": the reference's epsilon-anchored epigraph objective
+  // (PMPC.jl/src/main.jl:204-238) has the QP's minimiser for M = 1; for M > 1 it down-weights the
+  // cheapest particle(s); neither that nor smoothing (smooth_alpha != NaN) is reproduced yet.
   static bool warned = false;
   if (smooth_alpha == smooth_alpha && !warned) {
     fprintf(stderr, "pmpc_hip: c_lcone_solve(smooth_alpha=%g, solver=%s): constraint smoothing is not reproduced; "
