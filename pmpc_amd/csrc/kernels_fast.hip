@@ -61,11 +61,37 @@ __device__ __forceinline__ double row_allsum(double v) {
   v += dpp_d<0x140>(v);
   return v;
 }
+// Cross-row exchanges on the VALU (gfx950 v_permlane32_swap / v_permlane16_swap; semantics checked on
+// hardware, tools/micro/swap_test): with both operands equal to v,
+//   permlane32_swap -> [0] = v of the lane in rows {0,1} at the same position, [1] = same for rows {2,3}
+//   permlane16_swap -> [0] = v of the even row of this row pair,               [1] = v of the odd row
+// Same-box A/B vs ds_bpermute shuffles: factor sweep -4.5 %, vector sweep -6 % at 256 particles (latency-bound).
+__device__ __forceinline__ void swap32_d(double v, double &a, double &b) {
+  auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap16_d(double v, double &a, double &b) {
+  auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
 // sum over the 4 k-groups (lanes c, c+16, c+32, c+48), all lanes get the total
 __device__ __forceinline__ double grp_allsum(double v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  double a, b;
+  swap32_d(v, a, b);
+  v = a + b;
+  swap16_d(v, a, b);
+  return a + b;
+}
+// out[k] = v of lane (c, k): every lane gets the values its column holds in all four k-groups
+__device__ __forceinline__ void grp_gather(double v, double (&out)[4]) {
+  double p01, p23;
+  swap32_d(v, p01, p23);
+  swap16_d(p01, out[0], out[1]);
+  swap16_d(p23, out[2], out[3]);
 }
 // 1/sqrt(d): v_rsq_f64 seed (measured max rel. error 5.1e-8 on gfx950, tools/micro/rsq_test.hip) + ONE Newton
 // step -> 3.8e-15; a second step (3.4e-16) buys nothing for a Cholesky pivot and sits on the critical path
@@ -149,7 +175,10 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const dou
 // (xm_{j-1}, xd_{j-1}) is issued at the top of the stage.  Lanes without an entry in an array read a
 // zero buffer through a zero-stride pointer, so no load is predicated and no value needs a select.
 // ------------------------------------------------------------------------------------------------
-template <int XD, int UD, bool FACTOR, bool HXB, bool HUB>
+// DEEP: also the stage's mid/late data (Q_{j-1}, xm, gx, D) is loaded a full stage ahead — lowest per-stage
+// latency (few particles per GPU) at 144 VGPRs / 3 waves per SIMD; !DEEP issues those at the top of their own stage
+// and fits 4 waves per SIMD (128 VGPRs), which wins once there are > 3 waves per SIMD to run.
+template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP>
 __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
@@ -205,7 +234,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   double S[KS], s_row[KS];
   double s_col;
   // "next stage" registers
-  double Fn[KS], Rn = 0.0, umn = 0.0, gun, recn = 0.0;
+  double Fn[KS], Qn[KS], xmn[KS], gxn = 0.0, Dun = 0.0, Dxn = 0.0, Rn = 0.0, umn = 0.0, gun, recn = 0.0;
 
   auto load_row = [&](const double *p, double *dst) {
 #pragma unroll
@@ -235,8 +264,24 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     if (FACTOR) {
       Rn = *pR;
       umn = gu ? ldo(a.um, ou_g) : 0.0;
+      if (DEEP && HUB) { Dun = *pDu; pDu = badd(pDu, sDu); }
     } else {
       recn = *pRec;
+    }
+    if (DEEP && N > 1) {  // state side of stage N-2 (consumed during / at the end of stage N-1)
+      ox_row -= SX;
+      pgx = badd(pgx, sgx);
+      gxn = *pgx;
+      if (FACTOR) {
+        pQ = badd(pQ, sQ);
+        load_row(pQ, Qn);
+        if (HXB) { pDx = badd(pDx, sDx); Dxn = *pDx; }
+#pragma unroll
+        for (int r = 0; r < KS; r++) {
+          const bool rv = !PADX || (L.row0 + r < XD);
+          xmn[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+        }
+      }
     }
   }
 
@@ -253,23 +298,48 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
 #pragma unroll
       for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
     }
-    // ---- same-stage loads (consumed after the G products resp. at the end of the stage) ----------------
     double xm_row[KS], gx_c = 0.0, Du_c = 0.0, Dx_c = 0.0;
-    if (FACTOR && HUB) { Du_c = *pDu; pDu = badd(pDu, sDu); }
-    if (j > 0) {
-      ox_row -= SX;
-      pgx = badd(pgx, sgx);
-      gx_c = *pgx;
-      if (FACTOR) {
-        pQ = badd(pQ, sQ);
-        load_row(pQ, Qc);
-        if (HXB) { pDx = badd(pDx, sDx); Dx_c = *pDx; }
+    if (DEEP) {
+      // ---- rotate the remaining pipeline registers; prefetch the state side of stage j-2 ---------------
+      gx_c = gxn; Du_c = Dun; Dx_c = Dxn;
 #pragma unroll
-        for (int r = 0; r < KS; r++) {
-          const bool rv = !PADX || (L.row0 + r < XD);
-          xm_row[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+      for (int r = 0; r < KS; r++) { xm_row[r] = xmn[r]; Qc[r] = Qn[r]; }
+      if (j > 0 && FACTOR && HUB) { Dun = *pDu; pDu = badd(pDu, sDu); }
+      if (j > 1) {
+        ox_row -= SX;
+        pgx = badd(pgx, sgx);
+        gxn = *pgx;
+        if (FACTOR) {
+          pQ = badd(pQ, sQ);
+          load_row(pQ, Qn);
+          if (HXB) { pDx = badd(pDx, sDx); Dxn = *pDx; }
+#pragma unroll
+          for (int r = 0; r < KS; r++) {
+            const bool rv = !PADX || (L.row0 + r < XD);
+            xmn[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+          }
         }
       }
+    } else {
+      // ---- same-stage loads (consumed after the G products resp. at the end of the stage) --------------
+      if (FACTOR && HUB) { Du_c = *pDu; pDu = badd(pDu, sDu); }
+      if (j > 0) {
+        ox_row -= SX;
+        pgx = badd(pgx, sgx);
+        gx_c = *pgx;
+        if (FACTOR) {
+          pQ = badd(pQ, sQ);
+          load_row(pQ, Qc);
+          if (HXB) { pDx = badd(pDx, sDx); Dx_c = *pDx; }
+#pragma unroll
+          for (int r = 0; r < KS; r++) {
+            const bool rv = !PADX || (L.row0 + r < XD);
+            xm_row[r] = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+          }
+        }
+      }
+    }
+    if (j > 0) {
       // ---- prefetch what stage j-1 needs the moment it starts ------------------------------------------
       pF = badd(pF, sF);
       load_row(pF, Fn);
@@ -345,11 +415,10 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       if (bad && lane == 0) *a.fail = 2;
       // ---- gather the control rows column-wise and substitute in-lane: state columns give K[:, c], the
       //      control columns get unit right-hand sides and give Huu^-1[:, c - XP] -------------------------
+      double rows4[4];
+      grp_gather(H[KS], rows4);  // rows4[k] = H[XP + k][c]
 #pragma unroll
-      for (int k = 0; k < UD; k++) {
-        const double t = __shfl(H[KS], c + 16 * k, 64);  // H[XP + k][c]
-        col[k] = L.cu ? (L.cb == k ? 1.0 : 0.0) : t;
-      }
+      for (int k = 0; k < UD; k++) col[k] = L.cu ? (L.cb == k ? 1.0 : 0.0) : rows4[k];
       chol_solve<UD>(Lc, Ld, col);
       const double Kg = pick<UD>(col, g);
       rec = frec ? Kg : 0.0;
@@ -550,19 +619,23 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
 template <int XD, int UD>
 void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
   const bool xb = a.wx != nullptr, ub = a.wu != nullptr;
+  // > 3 waves per SIMD (1024 SIMDs on MI355X) to run: occupancy 4 beats the deeper pipeline
+  const bool deep = a.M <= 3 * 1024;
   const dim3 grd(a.M), blk(64);
-#define PMPC_BWD(F, XB, UB) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB>), grd, blk, 0, s, a)
+#define PMPC_BWD(F, XB, UB, DP) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB, DP>), grd, blk, 0, s, a)
+#define PMPC_BWD2(F, XB, UB) do { if (deep) PMPC_BWD(F, XB, UB, true); else PMPC_BWD(F, XB, UB, false); } while (0)
   if (factor) {
-    if (xb && ub) PMPC_BWD(true, true, true);
-    else if (xb) PMPC_BWD(true, true, false);
-    else if (ub) PMPC_BWD(true, false, true);
-    else PMPC_BWD(true, false, false);
+    if (xb && ub) PMPC_BWD2(true, true, true);
+    else if (xb) PMPC_BWD2(true, true, false);
+    else if (ub) PMPC_BWD2(true, false, true);
+    else PMPC_BWD2(true, false, false);
   } else {
-    if (xb && ub) PMPC_BWD(false, true, true);
-    else if (xb) PMPC_BWD(false, true, false);
-    else if (ub) PMPC_BWD(false, false, true);
-    else PMPC_BWD(false, false, false);
+    if (xb && ub) PMPC_BWD2(false, true, true);
+    else if (xb) PMPC_BWD2(false, true, false);
+    else if (ub) PMPC_BWD2(false, false, true);
+    else PMPC_BWD2(false, false, false);
   }
+#undef PMPC_BWD2
 #undef PMPC_BWD
 }
 template <int XD, int UD>
