@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--N", type=int, default=50)
     ap.add_argument("--model", default="quadrotor", choices=["quadrotor", "unicycle"])
+    ap.add_argument("--Nc", type=int, default=1, help="consensus horizon (-1 = N, the reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -99,7 +100,7 @@ def main():
     from pmpc_amd import dynamics as dyn
     from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, DeviceSolver, to_device_problem
 
-    M_total, N, Nc = args.M, args.N, 1
+    M_total, N, Nc = args.M, args.N, (args.N if args.Nc < 0 else args.Nc)
     assert M_total % world == 0
     M_loc = M_total // world
     if args.model == "quadrotor":

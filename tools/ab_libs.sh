@@ -2,7 +2,7 @@
 # A/B different builds of libpmpc_hip.so on the same box (rule 24: same device, same process environment)
 cd $GRAFT_REPO_ROOT
 cp pmpc_amd/libpmpc_hip.so /tmp/orig.so
-for rep in 1 2; do
+for rep in 1; do
 for f in libs_tmp/*.so; do
   cp $f pmpc_amd/libpmpc_hip.so
   for m in ${AB_M:-256 4096}; do
