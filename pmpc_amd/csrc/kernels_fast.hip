@@ -1,6 +1,6 @@
 // kernels_fast.hip — register-resident MFMA path of the structured LQ solve (gfx950 / CDNA4).
 //
-// Scope: no slew penalties, consensus horizon Nc <= 1, symmetric cost blocks, and
+// Scope: no slew penalties, symmetric cost blocks, any consensus horizon (Nc > 1: k_cond_fast), and
 // XP + udim <= 16 with udim <= 4, where XP = 4*ceil(xdim/4).  That covers the benchmark
 // configs (unicycle x4 u2, quadrotor x12 u4 — for the quadrotor [fx | fu] is exactly one
 // 12 x 16 tile and the stage Hessian F'SF exactly one 16 x 16 fp64 MFMA tile).
@@ -382,15 +382,32 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     }
 
     if (cons) {
-      // ---- consensus stage (Nc == 1, j == 0): export the per-particle condensed (H_i, g_i) ----------
+      // ---- consensus stage: no minimisation.  Export the per-particle condensed gradient block and the
+      //      diagonal Hessian block Huu; for Nc > 1 keep Y_j = H_ux in the factor record (k_cond_fast builds the
+      //      off-diagonal blocks Y_j Gamma_{j-1} from it) and carry P_{j-1} = H_xx on as the cost-to-go ------------
       if (FACTOR) {
-        // Hc_part[i][p + UD q] = Huu[p][q] lives in lane (XP + q, p), register KS
+        // Hc_part[i][(j UD + p) + nc (j UD + q)] = Huu[p][q] lives in lane (XP + q, p), register KS
         double v = H[KS];
         if (own0 && HUB && umask) v += Du_c;
-        if (L.cu && gu) a.Hc_part[(size_t)i * (UD * UD) + g + UD * L.cb] = v;
+        const int nc = Nc * UD;
+        if (L.cu && gu) a.Hc_part[(size_t)i * nc * nc + (size_t)(j * UD + g) + (size_t)nc * (j * UD + L.cb)] = v;
+        *pRec = (L.cxv && gu) ? H[KS] : 0.0;
+        pRec -= 64;
+#pragma unroll
+        for (int r = 0; r < KS; r++) S[r] = H[r];
       }
-      if (lane < UD) a.gc_part[(size_t)i * UD + lane] = pick<UD>(hu, lane);
-      break;
+      if (lane < UD) a.gc_part[(size_t)i * (Nc * UD) + j * UD + lane] = pick<UD>(hu, lane);
+      if (j == 0) break;
+      double p2 = 0.0;
+      if (FACTOR) {
+#pragma unroll
+        for (int r = 0; r < KS; r++) p2 = fma(Qc[r], xm_row[r], p2);
+        p2 = grp_allsum(p2);
+      }
+      s_col = L.cxv ? h_col + p2 + gx_c : 0.0;
+      col_to_row<KS>(s_col, g, s_row);
+      ou_0 -= SU;
+      continue;
     }
 
     if (FACTOR) {
@@ -503,7 +520,8 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
   const bool fc = L.cu;
   const double *pu = (ROLLOUT && fc) ? Uin + pbase * UD + L.cb : Z;
   const double *pup = (ROLLOUT && fc) ? a.U_prev + pbase * UD + L.cb : Z;
-  const double *pdc = (!ROLLOUT && fc) ? a.duc + L.cb : Z;  // consensus step of stage 0
+  const double *pdc = (!ROLLOUT && fc) ? a.duc + L.cb : Z;  // shared consensus step, stage by stage
+  const int sdc = (!ROLLOUT && fc) ? (int)D8 * UD : 0;
   const int su = (ROLLOUT && fc) ? (int)D8 * UD : 0;
   unsigned ox_row = (unsigned)((pbase * XD + L.row0) * D8);
   unsigned ou_g = (unsigned)((pbase * UD + (gu ? g : 0)) * D8);
@@ -566,6 +584,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
       double du_c;
       if (j < Nc) {
         du_c = *pdc;  // shared consensus step (zero off the control columns)
+        pdc = badd(pdc, sdc);
         if (store_u) {
           double *o = (double *)((char *)a.dU + ou_g);
           const double v = a.duc[j * UD + g];
@@ -616,6 +635,73 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// condensed consensus Hessian, off-diagonal blocks (Nc > 1).  With P_j the no-elimination cost-to-go of the
+// consensus stages (P_{Nc-1} = S of the free stages, P_{j-1} = Q~_{j-1} + A_j' P_j A_j) and
+// Gamma_{j,l} = A_j ... A_{l+1} B_l the sensitivity of x_j to the shared control u_l,
+//   Hc[j][l] = B_j' P_j Gamma_{j,l} = Y_j Gamma_{j-1,l}   (l < j),   Y_j = B_j' P_j A_j = H_ux of stage j,
+// which k_bwd_fast<FACTOR> left in the factor record; the diagonal blocks are its H_uu.  O(Nc^2) small
+// products instead of the O(Nc^3) of forming Phi' M Phi (kernels_generic.hip).  The columns of Gamma are
+// independent, so one wave owns COND_TPW column tiles (16 consensus variables each) of one particle, keeps
+// them in registers in the MFMA B/C layout and walks the stages: 2*KS MFMAs per tile and stage.
+// Output goes to the UPPER triangle Hc_part[i][q + nc (j UD + p)] (q < j UD): 16 lanes store 16 consecutive doubles.
+// ------------------------------------------------------------------------------------------------
+constexpr int COND_TPW = 4;
+template <int XD, int UD>
+__global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
+  typedef Lane<XD, UD> LT;
+  constexpr int KS = LT::KS;
+  const int lane = threadIdx.x;
+  const LT L(lane);
+  const int N = a.N, Nc = a.Nc, nc = Nc * UD, i = blockIdx.x, g = L.g, c = L.c;
+  const size_t pbase = (size_t)i * N;
+  const int t0 = blockIdx.y * COND_TPW;
+  const int jstart = (16 * t0) / UD;  // first stage at which one of this wave's columns starts
+  double *Hc = a.Hc_part + (size_t)i * nc * nc;
+  double Gm[COND_TPW][KS];
+#pragma unroll
+  for (int k = 0; k < COND_TPW; k++)
+#pragma unroll
+    for (int r = 0; r < KS; r++) Gm[k][r] = 0.0;
+  bool kv[KS];  // k index g + 4r is a real state
+#pragma unroll
+  for (int r = 0; r < KS; r++) kv[r] = (KS * g + r) < XD;
+
+  for (int j = jstart; j < Nc; j++) {
+    // A operand of A~_j: lane (c, g), step r <-> fx_j[pi(c)][pi(g + 4r)];  of Y_j: record[(g + 4r) + 16 c], rows c < UD
+    double Aop[KS], Yop[KS];
+    const double *fx = a.fx + (pbase + j) * (XD * XD), *rec = a.K + (pbase + j) * 64;
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      Aop[r] = (j > 0 && L.cxv && kv[r]) ? fx[(KS * g + r) * XD + L.oc] : 0.0;
+      Yop[r] = (j > 0 && c < UD) ? rec[(g + 4 * r) + 16 * c] : 0.0;
+    }
+    const double *fu = a.fu + (pbase + j) * (XD * UD);
+#pragma unroll
+    for (int k = 0; k < COND_TPW; k++) {
+      const int qt = 16 * (t0 + k);
+      if (qt >= nc) continue;  // wave-uniform
+      const int q = qt + c;
+      if (qt < j * UD) {  // some column of this tile started before stage j (wave-uniform)
+        v4d o = {0.0, 0.0, 0.0, 0.0}, n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < KS; r++) o = mfma(Yop[r], Gm[k][r], o);
+#pragma unroll
+        for (int r = 0; r < KS; r++) n = mfma(Aop[r], Gm[k][r], n);
+        if (g < UD && q < j * UD) Hc[(size_t)q + (size_t)nc * (j * UD + g)] = o[0];
+#pragma unroll
+        for (int r = 0; r < KS; r++) Gm[k][r] = n[r];
+      }
+      if (q < nc && q / UD == j) {  // Gamma_{j,j} = B_j
+        const int b = q - j * UD;
+#pragma unroll
+        for (int r = 0; r < KS; r++) Gm[k][r] = kv[r] ? fu[b * XD + KS * g + r] : 0.0;
+      }
+    }
+  }
+}
+
 template <int XD, int UD>
 void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
   const bool xb = a.wx != nullptr, ub = a.wu != nullptr;
@@ -639,6 +725,11 @@ void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
 #undef PMPC_BWD
 }
 template <int XD, int UD>
+void launch_cond_t(const LQArgs &a, hipStream_t s) {
+  const int ntiles = (a.Nc * UD + 15) / 16;
+  hipLaunchKernelGGL((k_cond_fast<XD, UD>), dim3(a.M, (ntiles + COND_TPW - 1) / COND_TPW), dim3(64), 0, s, a);
+}
+template <int XD, int UD>
 void launch_fwd_t(const LQArgs &a, hipStream_t s) {
   hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
 }
@@ -653,7 +744,7 @@ void launch_rollout_t(const LQArgs &a, const double *U, double *X, hipStream_t s
 #define PMPC_FAST_DIMS(X) X(12, 4) X(4, 2) X(2, 1) X(3, 2) X(5, 3) X(6, 2) X(8, 4)
 
 bool lq_fast_supported(const LQArgs &a) {
-  if (a.w != 0 || a.any_slew || a.Nc > 1 || !a.sym_cost) return false;
+  if (a.w != 0 || a.any_slew || !a.sym_cost) return false;
   // vector arrays are addressed with 32-bit byte offsets
   if ((size_t)a.M * a.N * (size_t)(a.x > a.u ? a.x : a.u) * sizeof(double) >= (1ull << 31)) return false;
 #define X(xd, ud) if (a.x == xd && a.u == ud) return true;
@@ -664,6 +755,14 @@ bool lq_fast_supported(const LQArgs &a) {
 
 void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s) {
 #define X(xd, ud) if (a.x == xd && a.u == ud) { launch_bwd_t<xd, ud>(a, factor, s); return; }
+  PMPC_FAST_DIMS(X)
+#undef X
+  abort();
+}
+
+void launch_cond_fast(const LQArgs &a, hipStream_t s) {
+  if (a.Nc <= 1) return;
+#define X(xd, ud) if (a.x == xd && a.u == ud) { launch_cond_t<xd, ud>(a, s); return; }
   PMPC_FAST_DIMS(X)
 #undef X
   abort();

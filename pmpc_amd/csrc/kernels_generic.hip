@@ -425,7 +425,11 @@ __global__ void __launch_bounds__(256) k_cons_solve(const double *Hc, double *Lc
   extern __shared__ double y[];
   const int tid = threadIdx.x, nth = blockDim.x;
   if (factor) {
-    for (int e = tid; e < nc * nc; e += nth) Lc[e] = Hc[e];
+    // the lower triangle of L is built from the UPPER triangle of Hc (the fast path only fills that one)
+    for (int e = tid; e < nc * nc; e += nth) {
+      const int r = e % nc, cc = e / nc;
+      Lc[e] = r >= cc ? Hc[cc + (size_t)nc * r] : 0.0;
+    }
     __syncthreads();
     for (int k = 0; k < nc; k++) {
       if (tid == 0) {
@@ -459,6 +463,165 @@ __global__ void __launch_bounds__(256) k_cons_solve(const double *Hc, double *Lc
     __syncthreads();
     const double yk = y[k];
     for (int r = tid; r < k; r += nth) y[r] -= Lc[k + (size_t)nc * r] * yk;
+    __syncthreads();
+  }
+  for (int e = tid; e < nc; e += nth) duc[e] = y[e];
+}
+
+// ---- blocked variant (nc <= PMPC_CONS_BLOCKED_MAX): right-looking Cholesky with 16-column panels ----------------
+// Per panel: the 16 x 16 diagonal block is factored by ONE wave in registers (lane l = row l, pivots and
+// multipliers broadcast with v_readlane — no barriers), the rows below are solved one per thread against it, and
+// the trailing lower triangle gets its rank-16 update in 4 x 4 register blocks with the panel staged in LDS
+// (k-major, conflict-free).  3 barriers per panel instead of 3 per COLUMN; the two substitutions use the same
+// blocking (wave-level 16 x 16 triangular solve + one matrix-vector update per block: 2 barriers per block).
+__device__ __forceinline__ double rl_d(double v, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256) k_cons_solve_blocked(const double *Hc, double *Lc, const double *gc, double *duc, int nc,
+                                                            int factor, int *fail) {
+  extern __shared__ double sm[];
+  double *P = sm;                      // panel, k-major: P[k * nc + r]
+  double *y = P + (size_t)16 * nc;     // right-hand side / solution
+  double *Dg = y + nc;                 // diagonal block, Dg[l * 17 + c]
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  if (factor) {
+    for (int e = tid; e < nc * nc; e += nth) {
+      const int r = e % nc, cc = e / nc;
+      Lc[e] = r >= cc ? Hc[cc + (size_t)nc * r] : 0.0;  // lower triangle of L from the UPPER triangle of Hc
+    }
+    __syncthreads();
+    for (int kb = 0; kb < nc; kb += 16) {
+      const int bs = min(16, nc - kb), rem = nc - kb - bs;
+      if (tid < 64) {
+        double a[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++)
+          a[cc] = (lane < bs && cc <= lane) ? Lc[(kb + lane) + (size_t)nc * (kb + cc)] : ((cc == lane) ? 1.0 : 0.0);
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+          double d = rl_d(a[p], p);
+          if (!(d > 0.0)) { bad = true; d = 1.0; }
+          const double sd = sqrt(d), rd = 1.0 / sd;
+          a[p] = (lane == p) ? sd : a[p] * rd;
+#pragma unroll
+          for (int cc = p + 1; cc < 16; cc++) {
+            const double t = rl_d(a[p], cc);
+            a[cc] = (lane >= cc) ? fma(-a[p], t, a[cc]) : a[cc];
+          }
+        }
+        if (bad && lane == 0) *fail = 2;
+        if (lane < 16) {
+#pragma unroll
+          for (int cc = 0; cc < 16; cc++) {
+            Dg[lane * 17 + cc] = a[cc];
+            if (lane < bs && cc <= lane) Lc[(kb + lane) + (size_t)nc * (kb + cc)] = a[cc];
+          }
+        }
+      }
+      __syncthreads();
+      for (int r = tid; r < rem; r += nth) {
+        const int R = kb + bs + r;
+        double xv[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) {
+          double v = 0.0;
+          if (cc < bs) {
+            v = Lc[R + (size_t)nc * (kb + cc)];
+#pragma unroll
+            for (int k = 0; k < cc; k++) v = fma(-xv[k], Dg[cc * 17 + k], v);
+            v /= Dg[cc * 17 + cc];
+            Lc[R + (size_t)nc * (kb + cc)] = v;
+          }
+          xv[cc] = v;
+          P[cc * nc + r] = v;
+        }
+      }
+      __syncthreads();
+      const int nb4 = (rem + 3) / 4, total = nb4 * (nb4 + 1) / 2, base = kb + bs;
+      for (int e = tid; e < total; e += nth) {
+        int br = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while (br * (br + 1) / 2 > e) br--;
+        while ((br + 1) * (br + 2) / 2 <= e) br++;
+        const int bc = e - br * (br + 1) / 2, r0 = 4 * br, c0 = 4 * bc;
+        double acc[4][4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) acc[ii][jj] = 0.0;
+        for (int k = 0; k < 16; k++) {
+          double pr[4], pc[4];
+#pragma unroll
+          for (int ii = 0; ii < 4; ii++) {
+            pr[ii] = (r0 + ii < rem) ? P[k * nc + r0 + ii] : 0.0;
+            pc[ii] = (c0 + ii < rem) ? P[k * nc + c0 + ii] : 0.0;
+          }
+#pragma unroll
+          for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) acc[ii][jj] = fma(pr[ii], pc[jj], acc[ii][jj]);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) {
+            const int rr = r0 + ii, cc = c0 + jj;
+            if (rr < rem && cc <= rr) Lc[(base + rr) + (size_t)nc * (base + cc)] -= acc[ii][jj];
+          }
+      }
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < nc; e += nth) y[e] = -gc[e];
+  __syncthreads();
+  for (int kb = 0; kb < nc; kb += 16) {  // L z = b
+    const int bs = min(16, nc - kb), rem = nc - kb - bs;
+    if (tid < 64) {
+      double a[16];
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++)
+        a[cc] = (lane < bs && cc <= lane) ? Lc[(kb + lane) + (size_t)nc * (kb + cc)] : ((cc == lane) ? 1.0 : 0.0);
+      double yl = lane < bs ? y[kb + lane] : 0.0;
+#pragma unroll
+      for (int p = 0; p < 16; p++) {
+        const double zp = rl_d(yl, p) / rl_d(a[p], p);
+        yl = (lane == p) ? zp : ((lane > p) ? fma(-a[p], zp, yl) : yl);
+      }
+      if (lane < bs) y[kb + lane] = yl;
+    }
+    __syncthreads();
+    for (int r = tid; r < rem; r += nth) {
+      const int R = kb + bs + r;
+      double v = y[R];
+      for (int k = 0; k < bs; k++) v = fma(-Lc[R + (size_t)nc * (kb + k)], y[kb + k], v);
+      y[R] = v;
+    }
+    __syncthreads();
+  }
+  for (int kb = ((nc - 1) / 16) * 16; kb >= 0; kb -= 16) {  // L' x = z
+    const int bs = min(16, nc - kb);
+    if (tid < 64) {
+      double b[16];  // lane l holds COLUMN l of the diagonal block
+#pragma unroll
+      for (int cc = 0; cc < 16; cc++)
+        b[cc] = (cc < bs && lane <= cc) ? Lc[(kb + cc) + (size_t)nc * (kb + lane)] : ((cc == lane) ? 1.0 : 0.0);
+      double yl = lane < bs ? y[kb + lane] : 0.0;
+#pragma unroll
+      for (int p = 15; p >= 0; p--) {
+        const double xp = rl_d(yl, p) / rl_d(b[p], p);
+        yl = (lane == p) ? xp : ((lane < p) ? fma(-b[p], xp, yl) : yl);
+      }
+      if (lane < bs) y[kb + lane] = yl;
+    }
+    __syncthreads();
+    for (int r = tid; r < kb; r += nth) {
+      double v = y[r];
+      for (int k = 0; k < bs; k++) v = fma(-Lc[(kb + k) + (size_t)nc * r], y[kb + k], v);
+      y[r] = v;
+    }
     __syncthreads();
   }
   for (int e = tid; e < nc; e += nth) duc[e] = y[e];
@@ -502,7 +665,7 @@ __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, cons
         d = sqrt(d);
         Lc[q + nc * q] = d;
         for (int p = q + 1; p < nc; p++) {
-          double v = H[p + nc * q];
+          double v = H[q + nc * p];  // upper triangle (the only one the fast path fills)
           for (int k = 0; k < q; k++) v -= Lc[p + nc * k] * Lc[q + nc * k];
           Lc[p + nc * q] = v / d;
         }
@@ -571,6 +734,10 @@ void launch_reduce_particles(const double *src, double *tmp, double *dst, int M,
 
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s) {
-  hipLaunchKernelGGL(k_cons_solve, dim3(1), dim3(256), nc * sizeof(double), s, (const double *)Hc, Lc, gc, duc, nc,
-                     factor ? 1 : 0, fail);
+  const size_t lds = ((size_t)17 * nc + 16 * 17) * sizeof(double);
+  if (nc > 16 && lds <= 64 * 1024)
+    hipLaunchKernelGGL(k_cons_solve_blocked, dim3(1), dim3(256), lds, s, (const double *)Hc, Lc, gc, duc, nc, factor ? 1 : 0, fail);
+  else
+    hipLaunchKernelGGL(k_cons_solve, dim3(1), dim3(256), nc * sizeof(double), s, (const double *)Hc, Lc, gc, duc, nc,
+                       factor ? 1 : 0, fail);
 }

@@ -107,6 +107,7 @@ void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, in
 bool lq_fast_supported(const LQArgs &a);
 void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_fast(const LQArgs &a, hipStream_t s);
+void launch_cond_fast(const LQArgs &a, hipStream_t s);  // off-diagonal blocks of the condensed consensus Hessian (Nc > 1)
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_grad_prep(const LQArgs &a, hipStream_t s);
 

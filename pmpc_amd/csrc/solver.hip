@@ -165,6 +165,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
   if (nc > 0) {
     ProfScope ps(c, 3);
     double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
+    if (fast && factor) launch_cond_fast(a, s);
     if (nc * nc + nc <= 32) {
       const bool solve_now = c->world <= 1;
       launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
@@ -456,6 +457,8 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   const double tol = 1e-12;  // complementarity (1e-10 leaves ~3e-7 relative trajectory error on the quadrotor: too close to the 1e-6 bar)
   const int max_iter = 80;
   int status = 1;
+  double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
+                         // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
   // slabs as the fused per-iteration pass sees them (an unbounded slab still takes the step and feeds the
   // gradient pre-pass)
   SlabEx ex, eu;
@@ -481,7 +484,8 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
              h.nu, h.alpha, h.sigma);
     inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
     if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
-    if (h.mu <= tol && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+    if (h.mu > mu_peak) mu_peak = h.mu;
+    if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
     if (it == max_iter) break;
     // predictor (factorisation) ...
     structured_solve(c, a, true, fast, /*prep_done=*/true);

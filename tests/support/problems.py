@@ -62,6 +62,15 @@ CASES = [
     (9, 6, 6, 2, 0, 0.3, 8.0, None, None),
     (4, 7, 8, 4, 1, 0.5, None, None, None),
     (3, 5, 4, 2, 1, None, None, None, 0.4),
+    # consensus horizons > 1 on the register-resident path (condensing kernel): one tile, tiles that straddle
+    # stages (udim 3), several tiles / several waves per particle, full consensus with both boxes
+    (5, 9, 12, 4, 4, 0.4, None, None, None),
+    (5, 9, 12, 4, -1, 0.4, 6.0, None, None),
+    (6, 10, 4, 2, 5, None, 2.5, None, None),
+    (3, 20, 2, 1, -1, 0.5, None, None, None),
+    (4, 12, 5, 3, 7, 0.4, None, None, None),
+    (2, 40, 12, 4, -1, 0.4, None, None, None),
+    (3, 24, 8, 4, 20, None, None, None, None),
 ]
 
 

@@ -285,6 +285,7 @@ def ipm_solve(p: Problem, allreduce=None, allreduce_min=None, allreduce_max=None
         return float(np.sum(wgt * (np.where(ml, tl * ll, 0.0) + np.where(mh, tu * lu_, 0.0))))
 
     nu = 1.0
+    mu_peak = 1.0  # complementarity tolerance relative to the dual scale (solver.hip)
     for it in range(1, max_iter + 1):
         mu = ar(np.array([comp_sum(tlx, llx, tux, lux, mlx, mux) + comp_sum(tlu, llu, tuu, luu, mlu, muu, wu)]))[0] / m_cnt
         # slack residuals
@@ -293,7 +294,8 @@ def ipm_solve(p: Problem, allreduce=None, allreduce_min=None, allreduce_max=None
         res = armax(max(np.max(np.abs(rlx)), np.max(np.abs(rux)), np.max(np.abs(rlu)), np.max(np.abs(ruu))))
         if verbose:
             print(f"ipm it {it:2d} mu {mu:9.3e} res {res:9.3e} nu {nu:9.3e}")
-        if mu <= tol and res <= tol and nu <= 1e-8:
+        mu_peak = max(mu_peak, mu)
+        if mu <= tol * mu_peak and res <= tol and nu <= 1e-8:
             break
         Dx = np.where(mlx, llx / tlx, 0.0) + np.where(mux, lux / tux, 0.0)
         Du = np.where(mlu, llu / tlu, 0.0) + np.where(muu, luu / tuu, 0.0)

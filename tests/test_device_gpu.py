@@ -62,7 +62,7 @@ def _device_solve(solver, prob, Nc, **kw):
     return X.cpu().numpy(), U.cpu().numpy(), status, (f, fx, fu)
 
 
-@pytest.mark.parametrize("Nc", [0, 1])
+@pytest.mark.parametrize("Nc", [0, 1, 7, -1])
 @pytest.mark.parametrize("model", ["unicycle", "quadrotor"])
 def test_fast_path_matches_generic_path(solver, model, Nc):
     """The register-resident MFMA kernels and the LDS generic kernels solve the same Newton systems."""
