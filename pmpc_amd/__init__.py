@@ -6,9 +6,10 @@
 The convex sub-problem of every SCP iteration is solved by hand-written HIP kernels behind the
 reference's own C ABI (`c_lqp_solve` / `c_lcone_solve`, include/pmpc_abi.h).  There is no CPU path.
 """
-from .scp_mpc import AA_method, FILTER_MAP, aff_solve, scp_solve, select_method, smooth_method, solve, solve_problems  # noqa: F401
+from .scp_mpc import AA_method, FILTER_MAP, aff_solve, scp_solve, select_method, smooth_method, solve, solve_problems, tune_scp  # noqa: F401
 from .backend import is_precompiled_backend_available, lcone_solve, lqp_solve  # noqa: F401
 from .problem_struct import Problem  # noqa: F401
+from .problem_matrices import lqp_generate_problem_matrices  # noqa: F401
 
 # keyword-compatible arguments of `solve` (pmpc/__init__.py:5-31)
 SOLVE_KWS = {

@@ -249,3 +249,32 @@ def solve(*args, **kwargs):
 def solve_problems(problems: List[Dict[str, Any]], verbose: bool = False, **kw):
     """pmpc/scp_mpc.py:504-511."""
     return [solve(**dict(p, verbose=verbose)) for p in problems]
+
+
+def tune_scp(*args, sample_nb: int = 14, reg_rng: Tuple[int, int] = (-3, 3), solve_fn: Callable = scp_solve,
+             savefig: Optional[str] = None, **kwargs):
+    """Sweep `reg_x` over `logspace(*reg_rng, sample_nb)` with `reg_u = reg_ratio * reg_x` and return the pair with
+    the smallest final SCP residual (pmpc/scp_mpc.py:460-497).  The residual curve is plotted only when matplotlib
+    is importable (upstream requires it)."""
+    reg_ratio = kwargs.pop("reg_ratio", 1e-1)
+    reg_list = kwargs.pop("reg_list", np.logspace(*reg_rng, sample_nb))
+    res_list = []
+    for reg in reg_list:
+        kwargs["reg_x"], kwargs["reg_u"] = reg, reg * reg_ratio
+        kwargs["verbose"] = False
+        X, U, data = solve_fn(*args, **kwargs)
+        res_list.append(1e2 if data is None else data["hist"][-1]["resid"])
+    try:
+        import matplotlib.pyplot as plt
+    except ImportError:
+        plt = None
+    if plt is not None:
+        plt.figure()
+        plt.loglog(reg_list, res_list)
+        plt.ylabel("final residual"), plt.xlabel("reg_x"), plt.title("reg_u = reg_x * %6.1e" % reg_ratio)
+        plt.tight_layout()
+        plt.grid(True, which="both")
+        if savefig is not None:
+            plt.savefig(savefig, dpi=200)
+    reg_x = float(reg_list[int(np.argmin(res_list))])
+    return reg_x, reg_ratio * reg_x

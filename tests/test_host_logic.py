@@ -189,3 +189,46 @@ def test_problem_builder_matches_reference():
             np.testing.assert_array_equal(da[k], db[k], err_msg=k)
         elif k != "f_fx_fu_fn":
             assert da[k] == db[k], k
+
+
+@pytest.mark.parametrize("case_idx", [0, 3, 5, 7, 8, 9, 10, 13, 14, 28])
+def test_problem_matrices_match_oracle_assembly(case_idx, oracle):
+    """`lqp_generate_problem_matrices` (vectorised numpy, product side) against the line-by-line C restatement of
+    lqp_repr_Pq / lqp_repr_Ab / lqp_repr_Gla: identical P, q, A, b, G, l, u — every slew / consensus / bound branch."""
+    from pmpc_amd import lqp_generate_problem_matrices
+    from tests.support.problems import CASES, rand_problem
+
+    case = CASES[case_idx]
+    M, N, x, u, Nc = case[:5]
+    args, kw = rand_problem(np.random.default_rng(77 + case_idx), M, N, x, u, *case[5:])
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    nan = np.full(1, np.nan)
+    qp = oracle.assemble_abi(
+        x, u, N, M, Nc, f, oracle.to_abi_mat(fx), oracle.to_abi_mat(fu), X_prev, U_prev, oracle.to_abi_mat(Q), oracle.to_abi_mat(R),
+        X_ref, U_ref, kw.get("x_l", nan), kw.get("x_u", nan), kw.get("u_l", nan), kw.get("u_u", nan), kw["reg_x"], kw["reg_u"],
+        kw.get("slew_reg", nan), kw.get("slew_reg0", nan), kw.get("slew_um1", nan))
+    P, q, A, b, G, lo, hi = lqp_generate_problem_matrices(
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, Nc=Nc, reg_x=kw["reg_x"], reg_u=kw["reg_u"],
+        slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"), lx=kw.get("x_l"), ux=kw.get("x_u"),
+        lu=kw.get("u_l"), uu=kw.get("u_u"))
+    assert P.shape == qp.P.shape and A.shape == qp.A.shape and G.shape == qp.G.shape
+    assert abs(P - qp.P).max() <= 1e-12 * max(1.0, abs(qp.P).max())
+    assert abs(A - qp.A).max() == 0.0 and (G.shape[0] == 0 or abs(G - qp.G).max() == 0.0)
+    np.testing.assert_allclose(q, qp.q, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(b, qp.b, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(lo, qp.l)
+    np.testing.assert_array_equal(hi, qp.u)
+
+
+def test_tune_scp_picks_smallest_residual():
+    import pmpc_amd
+
+    calls = []
+
+    def fake_solve(*a, reg_x=None, reg_u=None, **kw):
+        calls.append((reg_x, reg_u))
+        return None, None, dict(hist=[dict(resid=abs(np.log10(reg_x) - 1.0))])
+
+    reg_x, reg_u = pmpc_amd.tune_scp(solve_fn=fake_solve, sample_nb=7, reg_rng=(-3, 3), reg_ratio=0.5)
+    assert np.isclose(reg_x, 10.0) and np.isclose(reg_u, 5.0) and len(calls) == 7
+    assert all(np.isclose(ru, 0.5 * rx) for rx, ru in calls)
