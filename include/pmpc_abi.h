@@ -87,6 +87,9 @@ typedef struct pmpc_problem {
   const double *lx, *ux, *lu, *uu;
   const double *slew_reg, *slew_reg0, *slew_um1;
   double *X_out, *U_out; /* device, (xdim,N,M) / (udim,N,M) */
+  /* optional per-particle cost weights, device (M): minimise sum_i weights_i J_i (the reference's `weights`
+   * setting, PMPC.jl/src/main.jl:96-112, and the building block of the cone objective); NULL = all 1 */
+  const double *weights;
 } pmpc_problem;
 
 typedef struct pmpc_info {
@@ -97,6 +100,7 @@ typedef struct pmpc_info {
   double mu;           /* final complementarity */
   double slack_res;    /* final slack residual (inf-norm) */
   double max_violation;/* bound violation of the equality-only optimum */
+  int outer_solves;    /* cone path: weighted QPs solved (active-set + bisection on the threshold particle) */
 } pmpc_info;
 
 /* Opaque solver context: owns the HIP stream, the workspace cache keyed on
@@ -111,6 +115,16 @@ void pmpc_sync(pmpc_ctx *ctx);                        /* hipStreamSynchronize(pm
 /* Solve with all buffers in HBM.  Asynchronous on pmpc_stream() except for one small
  * device->host read per IPM iteration.  Returns pmpc_info.status. */
 int pmpc_lqp_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, pmpc_info *info, int verbose);
+
+/* Cone-path objective of c_lcone_solve with every buffer in HBM (PMPC.jl/src/main.jl:194-354 through the C
+ * ABI: k = M, no extra_cstrs): min (1+eps) sum_i y_i + (1-eps) M t  s.t.  J_i <= y_i + t, y >= 0, dynamics, boxes,
+ * eps = 1e-3, J_i the particle cost of qp_utils.jl:60-162.  Eliminating (y, t) gives sum_i w_i J_i with w = 1+eps
+ * above the threshold particle(s) — solved as a short sequence of weighted QPs.  smooth_alpha = NaN: hard boxes.
+ * Single rank only (the particle ranking is not exchanged across ranks yet). */
+int pmpc_lcone_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, double smooth_alpha, pmpc_info *info, int verbose);
+
+/* J_out[i] (device, M) = J_i(X, U): per-particle cost of qp_utils.jl:60-162 (1/2 z'Pz + q'z + r), unweighted. */
+int pmpc_particle_costs_device(pmpc_ctx *ctx, const pmpc_problem *prob, const double *X, const double *U, double *J_out);
 
 /* Particle sharding over RCCL (one process per GPU).  unique_id is the 128-byte ncclUniqueId
  * produced by pmpc_comm_unique_id on rank 0 and distributed by the host (torch.distributed).

@@ -60,12 +60,17 @@ static double slew_diag(double s0, double s, size_t j, size_t N) {
 
 /* lqp_repr_Pq: PMPC.jl/src/lqp_utils.jl:2-216 (Hf/hf branches are unreachable from
  * lqp_solve, main.jl:134, and are not restated).  Returns nnz(P).  P is emitted
- * exactly as the reference does: full (both triangles), column by column. */
+ * exactly as the reference does: full (both triangles), column by column.
+ * wts (NULL = none): per-particle cost weights applied as scale_probs_cost! does to each
+ * OCProb before assembly (main.jl:96-112: Q, R, reg_x, reg_u, slew_reg0, slew_reg times w_i;
+ * neither the normalisation by sum(w) nor the extra scaling of slew_um1 is applied here —
+ * the caller passes the multipliers it means). */
+#define WT(i) (wts ? wts[i] : 1.0)
 i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const double *X_prev,
                 const double *U_prev, const double *Q, const double *R, const double *X_ref,
                 const double *U_ref, double reg_x, double reg_u, const double *slew_reg,
                 const double *slew_reg0, const double *slew_um1, i64 *Pp, i64 *Pi, double *Px,
-                double *q) {
+                double *q, const double *wts) {
   size_t Nc = Nc_in >= 0 ? (size_t)Nc_in : N;
   size_t Nf = N - Nc;
   size_t n = Nc * udim + M * (Nf * udim + N * xdim);
@@ -73,7 +78,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
   size_t c = 0;
   Pp[0] = 0;
   double slew_sum = 0.0; /* mapreduce(i -> probs[i].slew_reg, +, 1:M), :20 */
-  for (size_t i = 0; i < M; i++) slew_sum += slew_reg[i];
+  for (size_t i = 0; i < M; i++) slew_sum += WT(i) * slew_reg[i];
 
   for (size_t j = 0; j < Nc; j++) { /* U consensus, :17-61 */
     for (size_t t = 0; t < udim; t++) {
@@ -86,8 +91,8 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
       for (size_t r = 0; r < udim; r++) { /* core cost, :26-46 */
         double val = 0.0;
         for (size_t i = 0; i < M; i++) {
-          val += M4(R, udim, udim, r, t, j, i);
-          if (r == t) val += reg_u + slew_diag(slew_reg0[i], slew_reg[i], j, N);
+          val += WT(i) * M4(R, udim, udim, r, t, j, i);
+          if (r == t) val += WT(i) * (reg_u + slew_diag(slew_reg0[i], slew_reg[i], j, N));
         }
         if (val != 0.0) {
           Pi[k] = (i64)(udim * j + r);
@@ -102,7 +107,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
       } else if (j + 1 < N && slew_sum != 0.0) { /* last consensus -> first free of each particle, :51-57 */
         for (size_t i = 0; i < M; i++) {
           Pi[k] = (i64)(Nc * udim + udim * Nf * i + t);
-          Px[k] = -slew_reg[i];
+          Px[k] = -WT(i) * slew_reg[i];
           k++;
         }
       }
@@ -114,7 +119,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
     for (size_t j = Nc; j < N; j++) {
       for (size_t t = 0; t < udim; t++) {
         i64 k_old = k;
-        double s = slew_reg[i];
+        double s = WT(i) * slew_reg[i];
         if (j > 0 && s != 0.0) { /* slew top half, :67-75 */
           /* previous control is free iff (1-based) j-1 > Nc, i.e. 0-based j > Nc */
           size_t idx = (j > Nc) ? Nc * udim + Nf * udim * i + udim * (j - Nc - 1) + t : udim * (j - 1) + t;
@@ -123,8 +128,8 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
           k++;
         }
         for (size_t r = 0; r < udim; r++) { /* core cost, :76-93 */
-          double val = M4(R, udim, udim, r, t, j, i);
-          if (r == t) val += reg_u + slew_diag(slew_reg0[i], s, j, N);
+          double val = WT(i) * M4(R, udim, udim, r, t, j, i);
+          if (r == t) val += WT(i) * reg_u + slew_diag(WT(i) * slew_reg0[i], s, j, N);
           if (val != 0.0) {
             Pi[k] = (i64)(Nc * udim + Nf * udim * i + udim * (j - Nc) + r);
             Px[k] = val;
@@ -147,7 +152,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
       for (size_t t = 0; t < xdim; t++) {
         i64 k_old = k;
         for (size_t r = 0; r < xdim; r++) {
-          double val = M4(Q, xdim, xdim, r, t, j, i) + (r == t ? reg_x : 0.0); /* :130-131 */
+          double val = WT(i) * (M4(Q, xdim, xdim, r, t, j, i) + (r == t ? reg_x : 0.0)); /* :130-131 */
           if (val != 0.0) {
             Pi[k] = (i64)(offset + N * xdim * i + xdim * j + r);
             Px[k] = val;
@@ -167,7 +172,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
   if (n >= udim) {
     for (size_t r = 0; r < udim; r++) {
       double acc = 0.0;
-      for (size_t i = 0; i < M; i++) acc += -slew_reg0[i] * slew_um1[r + udim * i];
+      for (size_t i = 0; i < M; i++) acc += -WT(i) * slew_reg0[i] * slew_um1[r + udim * i];
       q[r] += acc;
     }
   }
@@ -176,8 +181,8 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
     for (size_t r = 0; r < udim; r++) {
       double val = 0.0;
       for (size_t i = 0; i < M; i++) {
-        val -= reg_u * V3(U_prev, udim, r, j, i);
-        for (size_t t = 0; t < udim; t++) val -= M4(R, udim, udim, r, t, j, i) * V3(U_ref, udim, t, j, i);
+        val -= WT(i) * reg_u * V3(U_prev, udim, r, j, i);
+        for (size_t t = 0; t < udim; t++) val -= WT(i) * M4(R, udim, udim, r, t, j, i) * V3(U_ref, udim, t, j, i);
       }
       q[sidx + r] += val;
     }
@@ -188,7 +193,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
       for (size_t r = 0; r < udim; r++) {
         double val = -reg_u * V3(U_prev, udim, r, j, i);
         for (size_t t = 0; t < udim; t++) val -= M4(R, udim, udim, r, t, j, i) * V3(U_ref, udim, t, j, i);
-        q[sidx + r] = val;
+        q[sidx + r] = WT(i) * val;
       }
     }
   }
@@ -198,7 +203,7 @@ i64 lqp_repr_Pq(size_t xdim, size_t udim, size_t N, size_t M, i64 Nc_in, const d
       for (size_t r = 0; r < xdim; r++) {
         double val = -reg_x * V3(X_prev, xdim, r, j, i);
         for (size_t t = 0; t < xdim; t++) val -= M4(Q, xdim, xdim, r, t, j, i) * V3(X_ref, xdim, t, j, i);
-        q[sidx + r] = val;
+        q[sidx + r] = WT(i) * val;
       }
     }
   }

@@ -111,7 +111,7 @@ class JointQP:
 
 def assemble_abi(
     xdim, udim, N, M, Nc, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
-    slew_reg, slew_reg0, slew_um1,
+    slew_reg, slew_reg0, slew_um1, weights=None,
 ) -> JointQP:
     """All array arguments are float64 buffers in ABI layout (any shape, C-contiguous memory)."""
     lib = _load()
@@ -128,9 +128,10 @@ def assemble_abi(
     n, m_eq, m_in, nnzP, nnzA = (v.value for v in (n, m_eq, m_in, nnzP, nnzA))
 
     Pp, Pi, Px, q = np.zeros(n + 1, np.int64), np.zeros(nnzP, np.int64), np.zeros(nnzP), np.zeros(n)
+    wts = None if weights is None else _f64(weights).reshape(M)
     k = lib.lqp_repr_Pq(*dims, _p(X_prev), _p(U_prev), _p(Q), _p(R), _p(X_ref), _p(U_ref),
                         ctypes.c_double(reg_x), ctypes.c_double(reg_u), _p(sr), _p(sr0), _p(um1),
-                        _p(Pp), _p(Pi), _p(Px), _p(q))
+                        _p(Pp), _p(Pi), _p(Px), _p(q), _p(wts) if wts is not None else None)
     assert 0 <= k <= nnzP
     P = sp.csc_matrix((Px[:k], Pi[:k], Pp), shape=(n, n))
 
@@ -327,21 +328,22 @@ def solve_qp_exact(qp: JointQP, tol=1e-9, verbose=False):
 # entry points
 # -------------------------------------------------------------------------------------------------
 def lqp_solve_abi(xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
-                  reg_x, reg_u, slew_reg, slew_reg0, slew_um1, verbose=False, return_info=False):
+                  reg_x, reg_u, slew_reg, slew_reg0, slew_um1, verbose=False, return_info=False, weights=None):
     """Same argument list as `c_lqp_solve` (PMPC.jl/src/c_interface.jl:77-141) minus the output
     pointers; ABI-layout buffers in, X (M,N,x) / U (M,N,u) out (== the (x,N,M) / (u,N,M) the
     reference copies into X_out / U_out, c_interface.jl:138-139).  x0 is accepted and ignored, as
     in the reference (lqp_utils.jl:293-296)."""
     qp = assemble_abi(xdim, udim, N, M, Nc, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
-                      reg_x, reg_u, slew_reg, slew_reg0, slew_um1)
+                      reg_x, reg_u, slew_reg, slew_reg0, slew_um1, weights=weights)
     z, info = solve_qp_exact(qp, verbose=verbose)
     X, U = split_vars(qp, z)
     return (X, U, info) if return_info else (X, U)
 
 
 def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, x_l=None, x_u=None,
-                 u_l=None, u_u=None, slew_reg=None, slew_reg0=None, slew_um1=None, return_info=False):
-    """py-layout convenience wrapper (batched: x0 (M,x), fx (M,N,x,x) ...)."""
+                 u_l=None, u_u=None, slew_reg=None, slew_reg0=None, slew_um1=None, return_info=False, weights=None):
+    """py-layout convenience wrapper (batched: x0 (M,x), fx (M,N,x,x) ...).  `weights` (M,): per-particle cost
+    multipliers (cf. scale_probs_cost!, main.jl:96-112)."""
     f = _f64(f)
     M, N, xdim = f.shape
     udim = np.shape(fu)[-1]
@@ -353,7 +355,92 @@ def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, re
     return lqp_solve_abi(
         xdim, udim, N, M, Nc, _f64(x0), f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev),
         to_abi_mat(Q), to_abi_mat(R), _f64(X_ref), _f64(U_ref), bx(x_l, nanx), bx(x_u, nanx), bx(u_l, nanu),
-        bx(u_u, nanu), float(reg_x), float(reg_u), sr, sr0, um1, return_info=return_info)
+        bx(u_u, nanu), float(reg_x), float(reg_u), sr, sr0, um1, return_info=return_info, weights=weights)
+
+
+# -------------------------------------------------------------------------------------------------
+# cone path: PMPC.jl/src/main.jl:194-354 through the C ABI (k = M, no extra_cstrs, hard boxes)
+# -------------------------------------------------------------------------------------------------
+COST_ANCHOR_EPS = 1e-3  # main.jl:223
+
+
+def particle_costs_py(X, U, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, slew_reg=None, slew_reg0=None,
+                      slew_um1=None):
+    """J_i = 1/2 z'P_i z + q_i'z + r_i of qp_repr_Pq (PMPC.jl/src/qp_utils.jl:60-162) — the left-hand side of the
+    i-th second-order-cone epigraph (Pqr2Gh, cone_utils.jl:25-61).  py layout; the slew part of r is absent upstream
+    (:140-160), so the slew0 term is 1/2 s0 |u_0|^2 - s0 u_0'u_{-1} without its constant."""
+    X, U = _f64(X), _f64(U)
+    M = X.shape[0]
+    dx, du = X - X_ref, U - U_ref
+    J = 0.5 * np.einsum("mnr,mnrt,mnt->m", dx, Q, dx) + 0.5 * np.einsum("mnr,mnrt,mnt->m", du, R, du)
+    J += 0.5 * reg_x * np.sum((X - X_prev) ** 2, axis=(1, 2)) + 0.5 * reg_u * np.sum((U - U_prev) ** 2, axis=(1, 2))
+    if slew_reg is not None:
+        J += 0.5 * np.broadcast_to(_f64(slew_reg), (M,)) * np.sum((U[:, 1:] - U[:, :-1]) ** 2, axis=(1, 2))
+    if slew_reg0 is not None and slew_um1 is not None:
+        s0 = np.broadcast_to(_f64(slew_reg0), (M,))
+        J += 0.5 * s0 * np.sum(U[:, 0] ** 2, -1) - s0 * np.sum(U[:, 0] * np.broadcast_to(_f64(slew_um1), U[:, 0].shape), -1)
+    return J
+
+
+def cone_objective(J, eps=COST_ANCHOR_EPS):
+    """min over (y >= 0, t) of (1+eps) sum y_i + (1-eps) M t  s.t.  J_i <= y_i + t  (main.jl:224-238, k = M): the cost is
+    piecewise linear and convex in t with breakpoints at the J_i, so the minimum sits on one of them."""
+    J = np.asarray(J, dtype=np.float64)
+    M = J.size
+    return min((1 + eps) * np.sum(np.maximum(J - t, 0.0)) + (1 - eps) * M * t for t in J)
+
+
+def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, return_info=False, **kw):
+    """Exact minimiser of the reference's cone-path problem for M < (1+eps)/(2 eps) ~ 500 particles, where eliminating
+    (y, t) leaves  (1+eps) sum_i J_i - 2 eps M min_i J_i = sum_i w_i J_i  with w = 1+eps except for the cheapest
+    particle(s), which share the deficit 2 eps M.  Search: every single candidate a (weighted exact QP, accepted iff a
+    is the argmin of J at its own solution), then pairs on the kink J_a = J_b (root of the gap in the split theta).
+    The returned certificate is the weighted QP's KKT certificate plus the support condition (down-weighted particles
+    attain min J), i.e. the KKT conditions of the epigraph problem with multipliers lambda_i = w_i."""
+    from scipy.optimize import brentq
+
+    eps = COST_ANCHOR_EPS
+    M = np.shape(f)[0]
+    assert 2 * eps * M < 1 + eps, "threshold rank > 1: the reference's minimiser is not unique"
+    args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
+    ckw = dict(reg_x=reg_x, reg_u=reg_u, slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
+
+    def solve(w):
+        X, U, info = lqp_solve_py(*args, reg_x=reg_x, reg_u=reg_u, Nc=Nc, weights=w, return_info=True, **kw)
+        return X, U, particle_costs_py(X, U, X_prev, U_prev, Q, R, X_ref, U_ref, **ckw), info
+
+    hi = 1 + eps
+    if M == 1:
+        X, U, J, info = solve(np.array([1 - eps]))
+        return (X, U, dict(weights=np.array([1 - eps]), J=J, qp=info)) if return_info else (X, U)
+    X, U, J, _ = solve(np.full(M, hi))
+    order = np.argsort(J)
+    tol = lambda J: 1e-9 * max(1.0, abs(float(np.min(J))))
+    for a in order[: min(M, 4)]:
+        w = np.full(M, hi)
+        w[a] = hi - 2 * eps * M
+        X, U, J, info = solve(w)
+        if J[a] <= np.min(J) + tol(J):  # the down-weighted particle attains the minimum: KKT point of the epigraph problem
+            return (X, U, dict(weights=w, J=J, qp=info, kink=False)) if return_info else (X, U)
+    cand = order[: min(M, 4)]
+    for ia in range(len(cand)):
+        for ib in range(ia + 1, len(cand)):
+            a, b = cand[ia], cand[ib]
+
+            def gap(th):
+                w = np.full(M, hi)
+                w[a], w[b] = hi - 2 * eps * M * th, hi - 2 * eps * M * (1 - th)
+                _, _, Jt, _ = solve(w)
+                return Jt[a] - Jt[b]
+
+            if gap(0.0) < 0.0 < gap(1.0):
+                th = brentq(gap, 0.0, 1.0, xtol=1e-14, rtol=1e-14)
+                w = np.full(M, hi)
+                w[a], w[b] = hi - 2 * eps * M * th, hi - 2 * eps * M * (1 - th)
+                X, U, J, info = solve(w)
+                if min(J[a], J[b]) <= np.min(J) + tol(J):
+                    return (X, U, dict(weights=w, J=J, qp=info, kink=True, theta=th)) if return_info else (X, U)
+    raise RuntimeError("cone oracle: no consistent threshold particle / pair found")
 
 
 def aff_solve(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l,

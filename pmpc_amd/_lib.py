@@ -23,7 +23,7 @@ HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST = 1
 ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
-    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version",
+    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device",
 ]
 
 
@@ -32,14 +32,14 @@ class PmpcProblem(ctypes.Structure):
         [(k, ctypes.c_size_t) for k in ("xdim", "udim", "N", "M")]
         + [("Nc", ctypes.c_longlong), ("flags", ctypes.c_uint), ("reg_x", ctypes.c_double), ("reg_u", ctypes.c_double)]
         + [(k, ctypes.c_void_p) for k in ("x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref",
-                                          "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out")]
+                                          "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out", "weights")]
     )
 
 
 class PmpcInfo(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int), ("ipm_iters", ctypes.c_int), ("structured_solves", ctypes.c_int),
                 ("fast_path", ctypes.c_int), ("mu", ctypes.c_double), ("slack_res", ctypes.c_double),
-                ("max_violation", ctypes.c_double)]
+                ("max_violation", ctypes.c_double), ("outer_solves", ctypes.c_int)]
 
 
 def load():
@@ -67,6 +67,10 @@ def load():
     lib.pmpc_sync.restype = None
     lib.pmpc_lqp_solve_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), ctypes.POINTER(PmpcInfo), ctypes.c_int]
     lib.pmpc_lqp_solve_device.restype = ctypes.c_int
+    lib.pmpc_lcone_solve_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), dbl, ctypes.POINTER(PmpcInfo), ctypes.c_int]
+    lib.pmpc_lcone_solve_device.restype = ctypes.c_int
+    lib.pmpc_particle_costs_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), vp, vp, vp]
+    lib.pmpc_particle_costs_device.restype = ctypes.c_int
     lib.pmpc_comm_unique_id.argtypes = [vp]
     lib.pmpc_comm_unique_id.restype = ctypes.c_int
     lib.pmpc_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]

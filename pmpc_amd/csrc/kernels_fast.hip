@@ -191,6 +191,8 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   const bool own0 = (i == 0 && a.owner);
   const bool gu = g < UD;
   const double *Z = a.zeros;
+  const double pwt = a.pw ? a.pw[i] : 1.0;  // cost weight of this particle (gradient arrays come pre-weighted)
+  const double regx = pwt * a.reg_x, regu = pwt * a.reg_u;
 
   // per-lane pointers at stage N-1 and per-lane byte strides (0 for lanes that read the zero buffer)
   const bool fF = L.cxv || L.cu;
@@ -245,14 +247,14 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     double Q0[KS], part = 0.0;
     if (FACTOR) {
       load_row(pQ, Q0);
-      double dd = a.reg_x;
+      double dd = regx;
       if (HXB) dd += *pDx;
 #pragma unroll
       for (int r = 0; r < KS; r++) {
         const bool rv = !PADX || (L.row0 + r < XD);
         const double xm = rv ? ldo(a.xm, ox_row + (rv ? r * 8u : 0u)) : 0.0;
         part += Q0[r] * xm;
-        S[r] = Q0[r] + (dmask[r] ? dd : 0.0);
+        S[r] = fma(pwt, Q0[r], dmask[r] ? dd : 0.0);
       }
       part = grp_allsum(part);
     }
@@ -369,11 +371,11 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     if (FACTOR) {
       // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) ------------------------------------------------------
       if (j > 0) {
-        const double dd = a.reg_x + Dx_c;
+        const double dd = regx + Dx_c;
 #pragma unroll
-        for (int r = 0; r < KS; r++) H[r] = Qc[r] + (dmask[r] ? dd : 0.0);
+        for (int r = 0; r < KS; r++) H[r] = fma(pwt, Qc[r], dmask[r] ? dd : 0.0);
       }
-      H[KS] = Rc + (umask ? a.reg_u + (cons ? 0.0 : Du_c) : 0.0);
+      H[KS] = fma(pwt, Rc, umask ? regu + (cons ? 0.0 : Du_c) : 0.0);
       v4d G = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
@@ -466,27 +468,74 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   }
 }
 
-// gradient pre-pass of a factor solve: xm = X - X_ref, xd = reg_x (X - X_prev) + wx,
-// um = U - U_ref, ud = reg_u (U - U_prev) + wu (consensus stages: wu only on the owner's particle 0)
+// gradient pre-pass of a factor solve: xm = pw (X - X_ref), xd = pw reg_x (X - X_prev) + wx,
+// um = pw (U - U_ref), ud = pw reg_u (U - U_prev) + wu (consensus stages: wu only on the owner's particle 0)
 __global__ void __launch_bounds__(256) k_grad_prep(LQArgs a) {
   const long long nx = (long long)a.M * a.N * a.x, nu = (long long)a.M * a.N * a.u;
   const long long stride = (long long)gridDim.x * 256;
+  const long long perx = (long long)a.N * a.x, peru = (long long)a.N * a.u;
   for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nx; k += stride) {
     const double X = a.X[k];
-    a.xm[k] = X - a.X_ref[k];
-    a.xd[k] = a.reg_x * (X - a.X_prev[k]) + (a.wx ? a.wx[k] : 0.0);
+    const double pw = a.pw ? a.pw[k / perx] : 1.0;
+    a.xm[k] = pw * (X - a.X_ref[k]);
+    a.xd[k] = pw * a.reg_x * (X - a.X_prev[k]) + (a.wx ? a.wx[k] : 0.0);
   }
   for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nu; k += stride) {
     const double U = a.U[k];
-    a.um[k] = U - a.U_ref[k];
+    const double pw = a.pw ? a.pw[k / peru] : 1.0;
+    a.um[k] = pw * (U - a.U_ref[k]);
     double w = 0.0;
     if (a.wu) {
       const int j = (int)((k / a.u) % a.N);
-      const long long i = k / ((long long)a.u * a.N);
+      const long long i = k / peru;
       if (j >= a.Nc || (i == 0 && a.owner)) w = a.wu[k];
     }
-    a.ud[k] = a.reg_u * (U - a.U_prev[k]) + w;
+    a.ud[k] = pw * a.reg_u * (U - a.U_prev[k]) + w;
   }
+}
+
+// per-particle cost J_i = 1/2 z'P z + q'z + r of the reference's single-particle QP (PMPC.jl/src/qp_utils.jl:60-162):
+//   1/2 sum_j [(x-xr)'Q(x-xr) + reg_x |x-xp|^2 + (u-ur)'R(u-ur) + reg_u |u-up|^2]
+//   + 1/2 s sum_{j>=1} |u_j - u_{j-1}|^2 + 1/2 s0 |u_0|^2 - s0 u_0'u_{-1}      (the slew constant 1/2 s0 |u_{-1}|^2 is
+//   absent from the reference's r, :140-160).  One 256-thread block per particle, coalesced over the Q / R stacks.
+__global__ void __launch_bounds__(256) k_particle_cost(LQArgs a, const double *X, const double *U, double *J) {
+  __shared__ double sh[256];
+  const int i = blockIdx.x, tid = threadIdx.x, x = a.x, u = a.u, N = a.N;
+  const size_t pb = (size_t)i * N;
+  const double *Xi = X + pb * x, *Ui = U + pb * u;
+  const double *Xr = a.X_ref + pb * x, *Ur = a.U_ref + pb * u, *Xp = a.X_prev + pb * x, *Up = a.U_prev + pb * u;
+  double acc = 0.0;
+  const double *Q = a.Q + pb * x * x, *R = a.R + pb * u * u;
+  for (int e = tid; e < N * x * x; e += 256) {
+    const int j = e / (x * x), rc = e - j * x * x, c = rc / x, r = rc - c * x;
+    acc += 0.5 * Q[e] * (Xi[j * x + r] - Xr[j * x + r]) * (Xi[j * x + c] - Xr[j * x + c]);
+  }
+  for (int e = tid; e < N * u * u; e += 256) {
+    const int j = e / (u * u), rc = e - j * u * u, c = rc / u, r = rc - c * u;
+    acc += 0.5 * R[e] * (Ui[j * u + r] - Ur[j * u + r]) * (Ui[j * u + c] - Ur[j * u + c]);
+  }
+  for (int e = tid; e < N * x; e += 256) {
+    const double d = Xi[e] - Xp[e];
+    acc += 0.5 * a.reg_x * d * d;
+  }
+  const double sl = a.slew[i], sl0 = a.slew0[i];
+  for (int e = tid; e < N * u; e += 256) {
+    const double d = Ui[e] - Up[e];
+    acc += 0.5 * a.reg_u * d * d;
+    if (e >= u) {
+      const double dv = Ui[e] - Ui[e - u];
+      acc += 0.5 * sl * dv * dv;
+    } else {
+      acc += 0.5 * sl0 * Ui[e] * Ui[e] - sl0 * Ui[e] * a.um1[(size_t)i * u + e];
+    }
+  }
+  sh[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) J[i] = sh[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -780,6 +829,10 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s) {
   long long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
   hipLaunchKernelGGL(k_grad_prep, dim3((unsigned)b), dim3(256), 0, s, a);
+}
+
+void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s) {
+  hipLaunchKernelGGL(k_particle_cost, dim3(a.M), dim3(256), 0, s, a, X, U, J);
 }
 
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s) {

@@ -88,17 +88,18 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
   const int i = blockIdx.x, lane = threadIdx.x;
   const int x = a.x, u = a.u, n = a.n, w = a.w, N = a.N, Nc = a.Nc, nt = n + u, nc = Nc * u;
   LdsMap L = lds_map(lds, x, u, n);
-  const double sl = a.slew[i], sl0 = a.slew0[i];
+  const double pw = a.pw ? a.pw[i] : 1.0;  // cost weight: scales Q, R, reg and the slew penalties of this particle
+  const double sl = pw * a.slew[i], sl0 = pw * a.slew0[i], regx = pw * a.reg_x, regu = pw * a.reg_u;
 
   // gxs <- effective state gradient of stage jj (smooth part computed here when FACTOR)
   auto state_grad = [&](int jj) {
     if (FACTOR) {
       const double *Qg = a.Q + mofs(i, jj, N, x, x);
-      for (int e = lane; e < x * x; e += WV) L.Qr[e] = Qg[e];
+      for (int e = lane; e < x * x; e += WV) L.Qr[e] = pw * Qg[e];
       __syncthreads();
       if (lane < x) {
         const double *X = a.X + vofs(i, jj, N, x), *Xp = a.X_prev + vofs(i, jj, N, x), *Xr = a.X_ref + vofs(i, jj, N, x);
-        double g = a.reg_x * (X[lane] - Xp[lane]);
+        double g = regx * (X[lane] - Xp[lane]);
         for (int t = 0; t < x; t++) g += symu(L.Qr, x, lane, t) * X[t] - L.Qr[lane + x * t] * Xr[t];
         L.gxs[lane] = g + (a.wx ? a.wx[vofs(i, jj, N, x) + lane] : 0.0);
       }
@@ -111,11 +112,11 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
   auto ctrl_grad = [&](int j) {
     if (FACTOR) {
       const double *Rg = a.R + mofs(i, j, N, u, u);
-      for (int e = lane; e < u * u; e += WV) L.Rr[e] = Rg[e];
+      for (int e = lane; e < u * u; e += WV) L.Rr[e] = pw * Rg[e];
       __syncthreads();
       if (lane < u) {
         const double *U = a.U + vofs(i, j, N, u), *Up = a.U_prev + vofs(i, j, N, u), *Ur = a.U_ref + vofs(i, j, N, u);
-        double g = a.reg_u * (U[lane] - Up[lane]) + slew_diag(sl0, sl, j, N) * U[lane];
+        double g = regu * (U[lane] - Up[lane]) + slew_diag(sl0, sl, j, N) * U[lane];
         for (int t = 0; t < u; t++) g += symu(L.Rr, u, lane, t) * U[t] - L.Rr[lane + u * t] * Ur[t];
         if (j > 0) g -= sl * a.U[vofs(i, j - 1, N, u) + lane];
         if (j + 1 < N) g -= sl * a.U[vofs(i, j + 1, N, u) + lane];
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
       double v = 0.0;
       if (r < x && c < x) {
         v = symu(L.Qr, x, r, c);
-        if (r == c) v += a.reg_x + (a.Dx ? a.Dx[vofs(i, N - 1, N, x) + r] : 0.0);
+        if (r == c) v += regx + (a.Dx ? a.Dx[vofs(i, N - 1, N, x) + r] : 0.0);
       }
       L.S[e] = v;
     }
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
         if (r >= n && c >= n) {
           int rr = r - n, cc = c - n;
           acc += symu(L.Rr, u, rr, cc);
-          if (rr == cc) acc += a.reg_u + slew_diag(sl0, sl, j, N) + (a.Du ? a.Du[vofs(i, j, N, u) + rr] : 0.0);
+          if (rr == cc) acc += regu + slew_diag(sl0, sl, j, N) + (a.Du ? a.Du[vofs(i, j, N, u) + rr] : 0.0);
         }
         if (w && j > 0) {  // slew cross term -s u_j' u_{j-1}
           if (r >= n && c >= x && c < n && r - n == c - x) acc -= sl;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
       for (int e = lane; e < x * x; e += WV) {
         int r = e % x, c = e / x;
         double v = symu(L.Qr, x, r, c);
-        if (r == c) v += a.reg_x + (a.Dx ? a.Dx[vofs(i, j - 1, N, x) + r] : 0.0);
+        if (r == c) v += regx + (a.Dx ? a.Dx[vofs(i, j - 1, N, x) + r] : 0.0);
         L.S[r + n * c] += v;
       }
     }
@@ -308,10 +309,10 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
       const bool last = (j == Nc - 1);
       if (!last) {
         const double *Qg = a.Q + mofs(i, j, N, x, x);
-        for (int e = lane; e < x * x; e += WV) L.Qr[e] = Qg[e];
+        for (int e = lane; e < x * x; e += WV) L.Qr[e] = pw * Qg[e];
       }
       const double *Rg = a.R + mofs(i, j, N, u, u);
-      for (int e = lane; e < u * u; e += WV) L.Rr[e] = Rg[e];
+      for (int e = lane; e < u * u; e += WV) L.Rr[e] = pw * Rg[e];
       __syncthreads();
       for (int e = lane; e < n * nc; e += WV) {
         int r = e % n, c = e / n;
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
           for (int k = 0; k < n; k++) v += L.S[r + n * k] * Pb[k + n * c];
         } else if (r < x) {
           for (int k = 0; k < x; k++) v += symu(L.Qr, x, r, k) * Pb[k + n * c];
-          v += (a.reg_x + (a.Dx ? a.Dx[vofs(i, j, N, x) + r] : 0.0)) * Pb[r + n * c];
+          v += (regx + (a.Dx ? a.Dx[vofs(i, j, N, x) + r] : 0.0)) * Pb[r + n * c];
         }
         T[e] = v;
       }
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
           int rr = r - j * u, cc = c - j * u;
           acc += symu(L.Rr, u, rr, cc);
           if (rr == cc) {
-            acc += a.reg_u + slew_diag(sl0, sl, j, N);
+            acc += regu + slew_diag(sl0, sl, j, N);
             if (i == 0 && a.owner && a.Du) acc += a.Du[vofs(0, j, N, u) + rr];
           }
         }

@@ -280,8 +280,9 @@ __device__ __forceinline__ void advance_slab(const SlabEx &x, int do_update, dou
       s.z[k] = z;
     }
     if (x.gm) {
-      x.gm[k] = z - x.ref[k];
-      x.gd[k] = x.reg * (z - x.prev[k]) + w;
+      const double pw = x.pw ? x.pw[k / x.per] : 1.0;
+      x.gm[k] = pw * (z - x.ref[k]);
+      x.gd[k] = pw * x.reg * (z - x.prev[k]) + w;
     }
   }
 }

@@ -26,6 +26,7 @@ struct LQArgs {
   int w;  // u if slew penalties are active (stage state augmented with the previous control) else 0
   int n;  // x + w
   double reg_x, reg_u;
+  const double *pw;  // per-particle cost weights (null = 1): J = sum_i pw_i J_i (cone path, `weights` setting)
   // ABI inputs
   const double *f, *fx, *fu, *Q, *R, *X_prev, *U_prev, *X_ref, *U_ref;
   const double *slew, *slew0, *um1;  // per particle, never null (zeros when absent)
@@ -34,7 +35,7 @@ struct LQArgs {
   // IPM terms: extra Hessian diagonals / gradient shifts (null when absent)
   const double *Dx, *Du, *wx, *wu;
   // fast path only: gradient pre-pass outputs (launch_grad_prep), same shapes as X / U
-  //   xm = X - X_ref, xd = reg_x (X - X_prev) + wx, um = U - U_ref, ud = reg_u (U - U_prev) + wu (free stages;
+  //   xm = pw (X - X_ref), xd = pw reg_x (X - X_prev) + wx, um = pw (U - U_ref), ud = pw reg_u (U - U_prev) + wu (free stages;
   //   consensus stages: wu only on the owner's particle 0)
   double *xm, *xd, *um, *ud;
   const double *zeros;  // >= 64 readable zero doubles (lanes without an entry load from here, stride 0)
@@ -74,6 +75,8 @@ struct SlabEx {
   const double *ref, *prev;  // X_ref / X_prev (resp. U_ref / U_prev)
   double *gm, *gd;           // fast-path gradient arrays (null on the generic path)
   double reg;
+  const double *pw;          // per-particle cost weights (null = 1)
+  long long per;             // entries per particle (N * d)
 };
 
 // Device-resident IPM scalars.
@@ -110,6 +113,8 @@ void launch_fwd_fast(const LQArgs &a, hipStream_t s);
 void launch_cond_fast(const LQArgs &a, hipStream_t s);  // off-diagonal blocks of the condensed consensus Hessian (Nc > 1)
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_grad_prep(const LQArgs &a, hipStream_t s);
+// J[i] = 1/2 z_i' P_i z_i + q_i' z_i + r_i of PMPC.jl/src/qp_utils.jl:60-162 at (X, U) (unweighted), any dims / slew
+void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s);

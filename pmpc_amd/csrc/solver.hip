@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -68,6 +69,7 @@ struct SlabBufs {
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
+  DevBuf pw, Jc;  // cone path: particle weights / particle costs
   SlabBufs sx, su;
 };
 
@@ -225,7 +227,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   Workspace &w = c->ws;
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
-                   &w.part_max, &w.sc, &w.fail};
+                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -325,6 +327,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   a.owner = (c->rank == 0);
   a.any_slew = (has_slew || has_slew0) ? 1 : 0;
   a.sym_cost = (p->flags & PMPC_SYMMETRIC_COST) ? 1 : 0;
+  a.pw = p->weights;
 
   // ---- workspace ---------------------------------------------------------------------------------
   w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8);
@@ -469,6 +472,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   if (!has_ub) { eu.s.count = (long long)nu; eu.s.d = u; eu.s.N = N; eu.s.Nc = Nc; eu.s.owner = a.owner; eu.s.is_u = 1; eu.s.z = w.U.d(); eu.s.dz = w.dU.d(); }
   ex.bounded = has_xb; eu.bounded = has_ub;
   ex.s.dz2 = w.dX2.d(); eu.s.dz2 = w.dU2.d();
+  ex.pw = eu.pw = p->weights; ex.per = (long long)N * x; eu.per = (long long)N * u;
   ex.ref = p->X_ref; ex.prev = p->X_prev; ex.reg = p->reg_x; ex.gm = fast ? w.xm.d() : nullptr; ex.gd = fast ? w.xd.d() : nullptr;
   eu.ref = p->U_ref; eu.prev = p->U_prev; eu.reg = p->reg_u; eu.gm = fast ? w.um.d() : nullptr; eu.gd = fast ? w.ud.d() : nullptr;
   for (int it = 1; it <= max_iter; it++) {
@@ -511,6 +515,146 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
 }
 
 // -------------------------------------------------------------------------------------------------
+// cone path (c_lcone_solve): the epsilon-anchored epigraph objective as a sequence of weighted QPs
+// -------------------------------------------------------------------------------------------------
+int pmpc_particle_costs_device(pmpc_ctx *c, const pmpc_problem *p, const double *X, const double *U, double *J_out) {
+  HIP_CHECK(hipSetDevice(c->device));
+  Workspace &w = c->ws;
+  const size_t M = p->M, u = p->udim, D8 = sizeof(double);
+  LQArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (int)p->xdim; a.u = (int)u; a.N = (int)p->N; a.M = (int)M;
+  a.reg_x = p->reg_x; a.reg_u = p->reg_u;
+  a.Q = p->Q; a.R = p->R; a.X_prev = p->X_prev; a.U_prev = p->U_prev; a.X_ref = p->X_ref; a.U_ref = p->U_ref;
+  const bool has_slew = p->flags & PMPC_HAS_SLEW, has_slew0 = p->flags & PMPC_HAS_SLEW0;
+  if (w.zslew.bytes < M * D8 || w.zum1.bytes < M * u * D8) {
+    w.zslew.ensure(M * D8); w.zslew0.ensure(M * D8); w.zum1.ensure(M * u * D8);
+    HIP_CHECK(hipMemsetAsync(w.zslew.p, 0, M * D8, c->stream));
+    HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, M * D8, c->stream));
+    HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, M * u * D8, c->stream));
+  }
+  a.slew = has_slew ? p->slew_reg : w.zslew.d();
+  a.slew0 = has_slew0 ? p->slew_reg0 : w.zslew0.d();
+  a.um1 = has_slew0 ? p->slew_um1 : w.zum1.d();
+  launch_particle_cost(a, X, U, J_out, c->stream);
+  return 0;
+}
+
+int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose) {
+  HIP_CHECK(hipSetDevice(c->device));
+  if (c->world > 1) {
+    fprintf(stderr, "pmpc_hip: pmpc_lcone_solve_device is single-rank (the particle ranking is not exchanged over RCCL)\n");
+    return 2;
+  }
+  if (smooth_alpha == smooth_alpha) {
+    static bool warned = false;
+    if (!warned) fprintf(stderr, "pmpc_hip: c_lcone_solve(smooth_alpha=%g): constraint smoothing is not reproduced; hard boxes are used\n", smooth_alpha);
+    warned = true;
+  }
+  Workspace &w = c->ws;
+  hipStream_t s = c->stream;
+  const size_t M = p->M, D8 = sizeof(double);
+  const double eps = 1e-3;  // COST_ANCHOR_EPS, main.jl:223
+  w.pw.ensure(M * D8); w.Jc.ensure(M * D8);
+  std::vector<double> user(M, 1.0), pw(M), J(M);
+  if (p->weights) {
+    HIP_CHECK(hipMemcpyAsync(user.data(), p->weights, M * D8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  pmpc_problem q = *p;
+  q.weights = w.pw.d();
+  pmpc_info inf, last;
+  memset(&last, 0, sizeof(last));
+  int outer = 0, solves_total = 0, ipm_total = 0;
+  // threshold rank of the piecewise-linear epigraph cost in t: the m*-th cheapest particle, m* = ceil(2 eps M / (1+eps))
+  const long long mstar = std::max<long long>(1, (long long)std::ceil(2.0 * eps * (double)M / (1.0 + eps) - 1e-12));
+  const double w_hi = 1.0 + eps, w_thr = (1.0 + eps) * (double)mstar - 2.0 * eps * (double)M, w_floor = 1e-4;
+
+  auto solve_with = [&](const std::vector<double> &rankw) -> int {
+    for (size_t i = 0; i < M; i++) pw[i] = user[i] * rankw[i];
+    HIP_CHECK(hipMemcpyAsync(w.pw.p, pw.data(), M * D8, hipMemcpyHostToDevice, s));
+    const int st = pmpc_lqp_solve_device(c, &q, &inf, verbose > 1);
+    outer++;
+    solves_total += inf.structured_solves;
+    ipm_total += inf.ipm_iters;
+    last = inf;
+    if (st != 0) return st;
+    pmpc_particle_costs_device(c, p, p->X_out, p->U_out, w.Jc.d());
+    HIP_CHECK(hipMemcpyAsync(J.data(), w.Jc.p, M * D8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < M; i++) J[i] *= user[i];  // scale_probs_cost! (main.jl:96-112) acts on the costs themselves
+    return 0;
+  };
+  auto finish = [&](int status) {
+    last.status = status;
+    last.outer_solves = outer;
+    last.structured_solves = solves_total;
+    last.ipm_iters = ipm_total;
+    if (status != 0) fill_nan_outputs(c, p);
+    if (info) *info = last;
+    return status;
+  };
+  // the (m* - 1) cheapest particles carry no weight in the reference's objective (their trajectories are then not
+  // unique); they keep w_floor here so that every particle's sub-problem stays strictly convex
+  auto rank_weights = [&](const std::vector<size_t> &low, std::vector<double> &rw) {
+    std::fill(rw.begin(), rw.end(), w_hi);
+    for (size_t k = 0; k + 1 < low.size(); k++) rw[low[k]] = w_floor;
+    rw[low.back()] = std::max(w_thr, w_floor);
+  };
+  auto cheapest = [&](std::vector<size_t> &low) {  // indices of the m* cheapest particles, ascending cost
+    std::vector<size_t> idx(M);
+    for (size_t i = 0; i < M; i++) idx[i] = i;
+    std::partial_sort(idx.begin(), idx.begin() + mstar, idx.end(), [&](size_t a_, size_t b_) { return J[a_] < J[b_] || (J[a_] == J[b_] && a_ < b_); });
+    low.assign(idx.begin(), idx.begin() + mstar);
+  };
+
+  std::vector<double> rw(M, w_hi);
+  if (M == 1) {  // one particle: weight 1 - eps, same minimiser as the QP
+    rw[0] = 1.0 - eps;
+    return finish(solve_with(rw));
+  }
+  int st = solve_with(rw);  // uniform weights: the QP optimum ranks the particles
+  if (st != 0) return finish(st);
+  std::vector<size_t> low, low_new, low_prev;
+  cheapest(low);
+  bool settled = false;
+  for (int it = 0; it < 12 && !settled; it++) {
+    rank_weights(low, rw);
+    st = solve_with(rw);
+    if (st != 0) return finish(st);
+    cheapest(low_new);
+    if (verbose) printf("pmpc_hip: cone outer %d  threshold particle %zu -> %zu  J_thr %.9e\n", it + 1, low.back(), low_new.back(), J[low_new.back()]);
+    if (low_new == low) { settled = true; break; }
+    if (mstar == 1 && !low_prev.empty() && low_new == low_prev) {
+      // 2-cycle a <-> b: the optimum sits on the kink J_a = J_b; split the 2 eps M deficit theta : (1 - theta)
+      const size_t a_ = low[0], b_ = low_new[0];
+      double lo = 0.0, hi = 1.0;  // theta = 1: a fully down-weighted (then J_a > J_b), theta = 0: b
+      for (int bis = 0; bis < 60; bis++) {
+        const double th = 0.5 * (lo + hi);
+        std::fill(rw.begin(), rw.end(), w_hi);
+        rw[a_] = w_hi - 2.0 * eps * (double)M * th;
+        rw[b_] = w_hi - 2.0 * eps * (double)M * (1.0 - th);
+        st = solve_with(rw);
+        if (st != 0) return finish(st);
+        const double gap = J[a_] - J[b_];
+        if (verbose) printf("pmpc_hip: cone kink bisection %2d  theta %.12f  J_a - J_b %+.3e\n", bis, th, gap);
+        if (std::fabs(gap) <= 1e-11 * std::max(1.0, std::fabs(J[a_]))) break;
+        if (gap > 0.0) hi = th; else lo = th;
+      }
+      const double jmin = std::min(J[a_], J[b_]);
+      settled = true;
+      for (size_t i = 0; i < M; i++)
+        if (i != a_ && i != b_ && J[i] < jmin - 1e-9 * std::max(1.0, std::fabs(jmin))) settled = false;  // a third particle dips below
+      break;
+    }
+    low_prev = low;
+    low = low_new;
+  }
+  if (!settled && verbose) printf("pmpc_hip: cone objective: the threshold set did not settle\n");
+  return finish(settled || mstar > 1 ? 0 : 1);
+}
+
+// -------------------------------------------------------------------------------------------------
 // host-pointer drop-in entry points
 // -------------------------------------------------------------------------------------------------
 static pmpc_ctx *g_ctx = nullptr;
@@ -535,7 +679,8 @@ static bool blocks_symmetric(const double *B, size_t d, size_t nblocks) {
 static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
                        double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R,
                        double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x,
-                       double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose) {
+                       double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, bool cone = false,
+                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN()) {
   const size_t nx = xdim * N * M, nu = udim * N * M;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   auto fail_out = [&]() {  // osqp_solver.jl:65-71 convention
@@ -582,7 +727,9 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
   p.slew_reg = dp(14); p.slew_reg0 = dp(15); p.slew_um1 = dp(16);
   p.X_out = c->stage[17].d(); p.U_out = c->stage[18].d();
   pmpc_info info;
-  pmpc_lqp_solve_device(c, &p, &info, (int)verbose);
+  p.weights = nullptr;
+  if (cone) pmpc_lcone_solve_device(c, &p, smooth_alpha, &info, (int)verbose);
+  else pmpc_lqp_solve_device(c, &p, &info, (int)verbose);
   HIP_CHECK(hipMemcpyAsync(X_out, p.X_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipMemcpyAsync(U_out, p.U_out, nu * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -604,17 +751,11 @@ void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_
                    double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x, double reg_u,
                    double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, double smooth_alpha,
                    char *solver) {
-  // DESIGN.md section 2, "c_lcone_solve": the reference's epsilon-anchored epigraph objective
-  // (PMPC.jl/src/main.jl:204-238) has the QP's minimiser for M = 1; for M > 1 it down-weights the
-  // cheapest particle(s); neither that nor smoothing (smooth_alpha != NaN) is reproduced yet.
-  static bool warned = false;
-  if (smooth_alpha == smooth_alpha && !warned) {
-    fprintf(stderr, "pmpc_hip: c_lcone_solve(smooth_alpha=%g, solver=%s): constraint smoothing is not reproduced; "
-                    "solving the hard-constrained QP\n", smooth_alpha, solver ? solver : "?");
-    warned = true;
-  }
+  // the epsilon-anchored epigraph objective of PMPC.jl/src/main.jl:204-238 (k = M through this ABI); `solver` only
+  // selects the conic back end upstream (ecos / cosmo / mosek / gurobi, :320) — they share one optimum
+  (void)solver;
   host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
-             reg_u, slew_reg, slew_reg0, slew_um1, verbose);
+             reg_u, slew_reg, slew_reg0, slew_um1, verbose, true, smooth_alpha);
 }
 
 }  // extern "C"

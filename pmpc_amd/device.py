@@ -73,14 +73,13 @@ class DeviceSolver:
         self.rank, self.world = rank, world
 
     # ---- solve -----------------------------------------------------------------------------------------
-    def lqp_solve(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
-                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, verbose=False,
-                  force_generic=False, symmetric_cost=False, wait_current_stream=True):
-        """All tensors float64 CUDA, ABI layout: vectors (M,N,d); matrices (M,N,col,row) i.e. the
-        transpose of the py layout.  Returns X (M,N,x), U (M,N,u) (steps 1..N, no x0)."""
+    def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
+                 lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
+                 force_generic=False, symmetric_cost=False):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
+        assert weights is None or weights.shape == (M,)
         if X_out is None:
             X_out = torch.empty((M, N, x), dtype=torch.float64, device=f.device)
         if U_out is None:
@@ -102,13 +101,40 @@ class DeviceSolver:
             xdim=x, udim=u, N=N, M=M, Nc=int(Nc), flags=flags, reg_x=float(reg_x), reg_u=float(reg_u),
             x0=_p(x0), f=_p(f), fx=_p(fx), fu=_p(fu), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q), R=_p(R),
             X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
-            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out))
+            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights))
+        return prob, X_out, U_out
+
+    def lqp_solve(self, *, verbose=False, wait_current_stream=True, **kw):
+        """All tensors float64 CUDA, ABI layout: vectors (M,N,d); matrices (M,N,col,row) i.e. the
+        transpose of the py layout.  Returns X (M,N,x), U (M,N,u) (steps 1..N, no x0).  `weights` (M,): per-particle
+        cost weights (the reference's `weights` setting, PMPC.jl/src/main.jl:96-112)."""
+        prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
         if wait_current_stream:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
         status = self.lib.pmpc_lqp_solve_device(self.h, ctypes.byref(prob), ctypes.byref(info), int(verbose))
         self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
         return X_out, U_out, status
+
+    def lcone_solve(self, *, smooth_alpha=float("nan"), verbose=False, wait_current_stream=True, **kw):
+        """The cone-path objective of `c_lcone_solve` (epsilon-anchored epigraph, PMPC.jl/src/main.jl:194-354) with
+        every buffer in HBM; same tensor conventions as `lqp_solve`."""
+        prob, X_out, U_out = self._problem(**kw)
+        info = _lib.PmpcInfo()
+        if wait_current_stream:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        status = self.lib.pmpc_lcone_solve_device(self.h, ctypes.byref(prob), float(smooth_alpha), ctypes.byref(info), int(verbose))
+        self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
+        return X_out, U_out, status
+
+    def particle_costs(self, X, U, **kw):
+        """J_i(X, U) of PMPC.jl/src/qp_utils.jl:60-162 for every particle (device tensor, (M,))."""
+        prob, _, _ = self._problem(X_out=X, U_out=U, **kw)
+        J = torch.empty((X.shape[0],), dtype=torch.float64, device=X.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self.lib.pmpc_particle_costs_device(self.h, ctypes.byref(prob), _p(X), _p(U), _p(J))
+        self.sync()
+        return J
 
     def linearize(self, model: int, x0, X_prev, U_prev, params, f=None, fx=None, fu=None):
         """f, fx, fu (ABI layout) at X_ = [x0, X_prev[:-1]], U_prev for a built-in model."""

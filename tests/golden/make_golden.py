@@ -2,6 +2,8 @@
 """Generates tests/golden/*.npz.  Runs ONLY in the build container (needs /root/reference).
 
 What is pinned and by what:
+  * cone-path fixtures (`cone_*.npz`): the same problem definitions, minimiser of the reference's
+    epsilon-anchored epigraph objective (oracle.lcone_solve_py) with the particle weights it implies.
   * sub-problem fixtures (`qp_*.npz`): the reference's own example / test problem definitions
     (restated here from the cited lines, numpy-seeded where the reference draws random numbers),
     solved by the oracle (oracle/lqp_oracle.py) whose KKT certificate is stored alongside.
@@ -93,6 +95,18 @@ def random_spd(rng):
     return (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref), kw
 
 
+def cone_pack(args, kw, Nc):
+    """cone-path fixture: the same problem data, minimiser of the epsilon-anchored epigraph objective
+    (PMPC.jl/src/main.jl:194-354 through the C ABI, hard boxes) by oracle.lcone_solve_py"""
+    X, U, info = orc.lcone_solve_py(*args, Nc=Nc, return_info=True, **kw)
+    names = ["x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref"]
+    pack = dict(zip(names, args))
+    pack.update({k: np.asarray(v, float) for k, v in kw.items()})
+    pack.update(Nc=np.array(Nc), X=X, U=U, weights=info["weights"], J=info["J"],
+                cert=np.array([info["qp"]["cert"][k] for k in ("stationarity", "equality", "bound_violation", "complementarity")]))
+    return pack
+
+
 def scp_reference_run(N, reg_x, reg_u, max_it):
     """tests/simple.py:20-29 (N=25, default regs) / tests/remote.py:20-39 (N=30, reg 1/1) through the
     REFERENCE scp_solve, oracle as aff_solve."""
@@ -133,6 +147,10 @@ if __name__ == "__main__":
     args, kw = chain(rng, M=24, N=30)
     for Nc in (0, 1, 3, -1):
         save(f"qp_chain_Nc{Nc if Nc >= 0 else 'N'}.npz", **solve_and_pack(args, kw, Nc))
+    for Nc in (1, -1):
+        save(f"cone_chain_Nc{Nc if Nc >= 0 else 'N'}.npz", **cone_pack(args, kw, Nc))
+    args1, kw1, Nc1 = double_integrator(0.4)
+    save("cone_double_integrator_u04.npz", **cone_pack(args1, kw1, Nc1))
     args, kw = random_spd(np.random.default_rng(2021))
     save("qp_random_spd_ubox.npz", **solve_and_pack(args, kw, -1))
     save("qp_random_spd.npz", **solve_and_pack(args, dict(reg_x=0.0, reg_u=0.0), -1))

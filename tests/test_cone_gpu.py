@@ -1,0 +1,108 @@
+"""Cone path (`c_lcone_solve`, PMPC.jl/src/main.jl:194-354 through the C ABI) on the GPU against the oracle's
+exact minimiser of the same epsilon-anchored epigraph problem, the per-particle cost kernel against numpy, and the
+per-particle `weights` of the device API against the oracle's weighted joint QP."""
+import numpy as np
+import pytest
+
+from tests.support.problems import abi_args, rand_problem
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6  # BASELINE.json north_star: fp64 trajectories within 1e-6 relative
+
+
+def _rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+
+
+def _make_kink(oracle, args, kw, Nc):
+    """Scale the cost blocks (Q, R) of the second-cheapest particle until it ties with the cheapest one under uniform
+    weights: down-weighting either then lifts it above the other, so the cone optimum sits on the kink J_a = J_b and
+    the two share the deficit 2 eps M (the 2-cycle + bisection branch of pmpc_lcone_solve_device)."""
+    from scipy.optimize import brentq
+
+    ckw = dict(reg_x=kw["reg_x"], reg_u=kw["reg_u"], slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
+
+    def costs(a_):
+        X, U = oracle.lqp_solve_py(*a_, Nc=Nc, **kw)
+        return oracle.particle_costs_py(X, U, *a_[4:], **ckw)
+
+    order = np.argsort(costs(args))
+    a, b = order[0], order[1]
+
+    def scaled(c):
+        a_ = [np.array(v, copy=True) for v in args]
+        a_[6][b] *= c
+        a_[7][b] *= c
+        return tuple(a_)
+
+    def gap(c):
+        Jc = costs(scaled(c))
+        return Jc[b] - Jc[a]
+
+    c = brentq(gap, 0.05, 1.0, xtol=1e-12)
+    return scaled(c * (1 + 1e-9)), kw
+
+
+# (M, N, x, u, Nc, u-bound, x-bound, slew, slew0, kink construction)
+CONE_CASES = [
+    (1, 6, 3, 2, 0, 0.3, None, None, None, None),
+    (4, 8, 3, 2, 2, 0.3, None, None, None, None),
+    (120, 6, 2, 1, 1, 0.5, None, None, None, None),
+    (300, 4, 2, 1, -1, 0.5, None, None, None, None),
+    (40, 6, 3, 2, 2, 0.4, 6.0, 0.5, 0.3, None),
+    (60, 6, 4, 2, 1, 1.0, None, None, None, True),
+    (100, 6, 2, 1, -1, 0.3, None, None, None, True),
+    (30, 6, 3, 2, 2, 0.3, None, None, None, True),
+    (25, 7, 12, 4, 3, 0.4, None, None, None, None),
+]
+
+
+@pytest.mark.parametrize("case", CONE_CASES, ids=[f"M{c[0]}N{c[1]}x{c[2]}u{c[3]}Nc{c[4]}" + ("kink" if c[9] else "") + ("slew" if c[7] else "") for c in CONE_CASES])
+def test_c_lcone_solve_matches_cone_oracle(case, oracle):
+    from pmpc_amd import backend
+
+    M, N, x, u, Nc = case[:5]
+    args, kw = rand_problem(np.random.default_rng(4000 + CONE_CASES.index(case)), M, N, x, u, *case[5:9])
+    if case[9]:
+        args, kw = _make_kink(oracle, args, kw, Nc)
+    Xo, Uo, info = oracle.lcone_solve_py(*args, Nc=Nc, return_info=True, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=float("nan"), solver="ecos")
+    assert bool(info.get("kink", False)) == bool(case[9])
+    assert _rel(X, Xo) < TOL and _rel(U, Uo) < TOL, (info["weights"][np.argsort(info["J"])[:3]], info.get("kink"))
+    if M > 1:
+        # the device result minimises the reference's objective: value within round-off of the oracle's
+        ckw = dict(reg_x=kw["reg_x"], reg_u=kw["reg_u"], slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
+        J = oracle.particle_costs_py(X, U, *args[4:], **ckw)
+        assert abs(oracle.cone_objective(J) - oracle.cone_objective(info["J"])) <= 1e-8 * abs(oracle.cone_objective(info["J"]))
+
+
+@pytest.mark.parametrize("dims", [(6, 9, 12, 4, 1, False), (6, 9, 12, 4, 3, False), (5, 8, 3, 2, 2, True), (7, 6, 4, 2, -1, False)])
+def test_weighted_lqp_and_particle_costs(dims, oracle):
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    M, N, x, u, Nc, slew = dims
+    rng = np.random.default_rng(99 + M)
+    args, kw = rand_problem(rng, M, N, x, u, 0.3, None, 0.5 if slew else None, 0.3 if slew else None)
+    wts = 0.2 + rng.random(M)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, weights=wts, **kw)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    s = DeviceSolver(0)
+    common = dict(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref),
+                  U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]),
+                  symmetric_cost=True)
+    if slew:
+        common.update(slew_reg=dev(kw["slew_reg"]), slew_reg0=dev(kw["slew_reg0"]), slew_um1=dev(kw["slew_um1"]))
+    X, U, status = s.lqp_solve(weights=dev(wts), **common)
+    s.sync()
+    assert status == 0 and s.last_info["fast_path"] == (0 if slew else 1)
+    assert _rel(X.cpu().numpy(), Xo) < TOL and _rel(U.cpu().numpy(), Uo) < TOL
+    J = s.particle_costs(X, U, **common).cpu().numpy()
+    Jo = oracle.particle_costs_py(X.cpu().numpy(), U.cpu().numpy(), X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=kw["reg_x"],
+                                  reg_u=kw["reg_u"], slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"),
+                                  slew_um1=kw.get("slew_um1"))
+    np.testing.assert_allclose(J, Jo, rtol=1e-12)
+    s.close()

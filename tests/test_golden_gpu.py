@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from tests.support.problems import abi_args
-from tests.test_oracle_golden import QP_FILES, load_qp
+from tests.test_oracle_golden import CONE_FILES, QP_FILES, load_qp
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
@@ -22,15 +22,14 @@ def test_c_lqp_solve_matches_golden(name):
     assert np.linalg.norm(U - Ug) / max(np.linalg.norm(Ug), 1.0) < 1e-7
 
 
-@pytest.mark.parametrize("name", ["qp_double_integrator_u04.npz", "qp_chain_Nc1.npz"])
-def test_c_lcone_solve_hard_constraints(name):
-    """smooth_alpha = NaN => hard constraints (PMPC.jl/src/main.jl:242-244).  For M = 1 the cone objective has the
-    QP's minimiser; for M > 1 this entry point documents its deviation and returns the QP optimum."""
+@pytest.mark.parametrize("name", CONE_FILES)
+def test_c_lcone_solve_matches_golden(name):
+    """smooth_alpha = NaN => hard constraints (PMPC.jl/src/main.jl:242-244): the epsilon-anchored epigraph objective of
+    the cone path, M = 1 (same minimiser as the QP) and the 24-particle chain (cheapest particle at weight 1+eps-2 eps M)."""
     from pmpc_amd import backend
 
     args, kw, Nc, Xg, Ug, _ = load_qp(name)
-    a = abi_args(args, kw, Nc)
-    X, U = backend.lcone_solve(*a, smooth_alpha=float("nan"), solver="ecos")
+    X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=float("nan"), solver="ecos")
     assert np.linalg.norm(X - Xg) / np.linalg.norm(Xg) < 1e-7 and np.linalg.norm(U - Ug) / max(np.linalg.norm(Ug), 1.0) < 1e-7
 
 

@@ -9,6 +9,7 @@ from tests.support.problems import CASES, rand_problem
 
 GOLD = Path(__file__).resolve().parent / "golden"
 QP_FILES = sorted(p.name for p in GOLD.glob("qp_*.npz"))
+CONE_FILES = sorted(p.name for p in GOLD.glob("cone_*.npz"))
 ARG_NAMES = ["x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref"]
 KW_NAMES = ["reg_x", "reg_u", "u_l", "u_u", "x_l", "x_u", "slew_reg", "slew_reg0", "slew_um1"]
 
@@ -27,6 +28,22 @@ def test_oracle_reproduces_golden(name, oracle):
     np.testing.assert_allclose(Xo, X, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(Uo, U, rtol=1e-9, atol=1e-10)
     assert max(info["cert"].values()) < 1e-8 and cert.max() < 1e-8
+
+
+@pytest.mark.parametrize("name", CONE_FILES)
+def test_cone_oracle_reproduces_golden(name, oracle):
+    """cone path: the fixture's minimiser, and the optimality condition of the epigraph problem — the particles that
+    are not at the full weight 1 + eps attain min_i J_i (multipliers lambda_i = w_i), deficit 2 eps M in total"""
+    args, kw, Nc, X, U, cert = load_qp(name)
+    z = np.load(GOLD / name)
+    Xo, Uo, info = oracle.lcone_solve_py(*args, Nc=Nc, return_info=True, **kw)
+    np.testing.assert_allclose(Xo, X, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(Uo, U, rtol=1e-8, atol=1e-9)
+    M, eps = X.shape[0], oracle.COST_ANCHOR_EPS
+    w, J = z["weights"], z["J"]
+    np.testing.assert_allclose(np.sum(1 + eps - w), 2 * eps * M, rtol=1e-12)
+    assert np.all(J[w < 1 + eps - 1e-12] <= J.min() * (1 + 1e-9)) and cert.max() < 1e-8
+    np.testing.assert_allclose(oracle.cone_objective(J), float(np.sum(w * J)), rtol=1e-9)
 
 
 def test_golden_double_integrator_structure():
