@@ -90,6 +90,9 @@ typedef struct pmpc_problem {
   /* optional per-particle cost weights, device (M): minimise sum_i weights_i J_i (the reference's `weights`
    * setting, PMPC.jl/src/main.jl:96-112, and the building block of the cone objective); NULL = all 1 */
   const double *weights;
+  /* > 0: log-barrier smoothing of the boxes (the cone path's smooth_cstr = "logbarrier", cone_utils.jl:173-232): the
+   * hard boxes are replaced by -barrier_mu * sum log(slack) in the objective, barrier_mu = 1/smooth_alpha; 0 = hard */
+  double barrier_mu;
 } pmpc_problem;
 
 typedef struct pmpc_info {

@@ -324,24 +324,82 @@ def solve_qp_exact(qp: JointQP, tol=1e-9, verbose=False):
     return z, dict(cert=cert, admm=info, active_set_iters=it)
 
 
+
+def solve_barrier_exact(qp: JointQP, mu, tol=1e-11, max_iter=200, verbose=False):
+    """Minimiser of  1/2 z'Pz + q'z - mu sum log(Gz - l) - mu sum log(u - Gz)  s.t.  Az = b  — what the cone path
+    solves when `smooth_cstr = "logbarrier"` replaces every bound row g'z <= h by an exponential-cone epigraph
+    t >= -log(alpha (h - g'z)) / alpha with unit cost on t (make_logbarrier_constraint, cone_utils.jl:173-204;
+    main.jl:246-262), mu = 1/alpha.  Infeasible-start primal-dual Newton at FIXED mu with a fraction-to-boundary
+    step; certificate = residuals of the perturbed KKT system (stationarity, equality, slack, t*lambda = mu)."""
+    P, q, A, b, G, l, u = effective_P(qp.P), qp.q, qp.A, qp.b, qp.G, qp.l, qp.u
+    n, me = P.shape[0], A.shape[0]
+    ml, mh = np.isfinite(l), np.isfinite(u)
+    z, y, _ = _kkt_solve(P, A, sp.csc_matrix((0, n)), -q, b, np.zeros(0))
+    Gz = G @ z
+    tl = np.where(ml, np.maximum(Gz - np.where(ml, l, 0.0), 1.0), 1.0)
+    tu = np.where(mh, np.maximum(np.where(mh, u, 0.0) - Gz, 1.0), 1.0)
+    ll, lu_ = np.where(ml, mu / tl, 0.0), np.where(mh, mu / tu, 0.0)
+    Gt = G.T.tocsc()
+    for it in range(max_iter):
+        Gz = G @ z
+        r_d = P @ z + q + A.T @ y - Gt @ ll + Gt @ lu_
+        r_p = A @ z - b
+        r_tl = np.where(ml, Gz - np.where(ml, l, 0.0) - tl, 0.0)
+        r_tu = np.where(mh, np.where(mh, u, 0.0) - Gz - tu, 0.0)
+        r_cl, r_cu = np.where(ml, tl * ll - mu, 0.0), np.where(mh, tu * lu_ - mu, 0.0)
+        res = max(np.max(np.abs(r_d)) / max(1.0, np.max(np.abs(q))), np.max(np.abs(r_p), initial=0.0), np.max(np.abs(r_tl), initial=0.0),
+                  np.max(np.abs(r_tu), initial=0.0), np.max(np.abs(r_cl), initial=0.0) / mu, np.max(np.abs(r_cu), initial=0.0) / mu)
+        if verbose:
+            print(f"oracle barrier it {it:3d} res {res:9.3e}")
+        if res <= tol:
+            break
+        D = np.where(ml, ll / tl, 0.0) + np.where(mh, lu_ / tu, 0.0)
+        el = np.where(ml, (-r_cl - ll * r_tl) / tl, 0.0)
+        eu = np.where(mh, (-r_cu - lu_ * r_tu) / tu, 0.0)
+        H = (P + Gt @ sp.diags(D) @ G).tocsc()
+        dz, dy, _ = _kkt_solve(H, A, sp.csc_matrix((0, n)), -r_d + Gt @ el - Gt @ eu, -r_p, np.zeros(0))
+        Gdz = G @ dz
+        dtl, dtu = np.where(ml, Gdz + r_tl, 0.0), np.where(mh, -Gdz + r_tu, 0.0)
+        dll = np.where(ml, -(ll / tl) * Gdz + el, 0.0)
+        dlu = np.where(mh, (lu_ / tu) * Gdz + eu, 0.0)
+        a = 1.0
+        for v, dv, m in ((tl, dtl, ml), (tu, dtu, mh), (ll, dll, ml), (lu_, dlu, mh)):
+            neg = m & (dv < 0)
+            if neg.any():
+                a = min(a, 0.995 * float(np.min(-v[neg] / dv[neg])))
+        z, y = z + a * dz, y + a * dy
+        tl, tu, ll, lu_ = tl + a * dtl, tu + a * dtu, ll + a * dll, lu_ + a * dlu
+    else:
+        raise RuntimeError("oracle barrier Newton did not converge")
+    cert = dict(stationarity=float(np.max(np.abs(r_d))), equality=float(np.max(np.abs(r_p), initial=0.0)),
+                bound_violation=float(max(np.max(np.abs(r_tl), initial=0.0), np.max(np.abs(r_tu), initial=0.0))),
+                complementarity=float(max(np.max(np.abs(r_cl), initial=0.0), np.max(np.abs(r_cu), initial=0.0))))
+    return z, dict(cert=cert, newton_iters=it)
+
+
 # -------------------------------------------------------------------------------------------------
 # entry points
 # -------------------------------------------------------------------------------------------------
 def lqp_solve_abi(xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
-                  reg_x, reg_u, slew_reg, slew_reg0, slew_um1, verbose=False, return_info=False, weights=None):
+                  reg_x, reg_u, slew_reg, slew_reg0, slew_um1, verbose=False, return_info=False, weights=None,
+                  barrier_mu=0.0):
     """Same argument list as `c_lqp_solve` (PMPC.jl/src/c_interface.jl:77-141) minus the output
     pointers; ABI-layout buffers in, X (M,N,x) / U (M,N,u) out (== the (x,N,M) / (u,N,M) the
     reference copies into X_out / U_out, c_interface.jl:138-139).  x0 is accepted and ignored, as
     in the reference (lqp_utils.jl:293-296)."""
     qp = assemble_abi(xdim, udim, N, M, Nc, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
                       reg_x, reg_u, slew_reg, slew_reg0, slew_um1, weights=weights)
-    z, info = solve_qp_exact(qp, verbose=verbose)
+    if barrier_mu > 0.0 and qp.G.shape[0] > 0:
+        z, info = solve_barrier_exact(qp, barrier_mu, verbose=verbose)
+    else:
+        z, info = solve_qp_exact(qp, verbose=verbose)
     X, U = split_vars(qp, z)
     return (X, U, info) if return_info else (X, U)
 
 
 def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, x_l=None, x_u=None,
-                 u_l=None, u_u=None, slew_reg=None, slew_reg0=None, slew_um1=None, return_info=False, weights=None):
+                 u_l=None, u_u=None, slew_reg=None, slew_reg0=None, slew_um1=None, return_info=False, weights=None,
+                 barrier_mu=0.0):
     """py-layout convenience wrapper (batched: x0 (M,x), fx (M,N,x,x) ...).  `weights` (M,): per-particle cost
     multipliers (cf. scale_probs_cost!, main.jl:96-112)."""
     f = _f64(f)
@@ -355,7 +413,8 @@ def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, re
     return lqp_solve_abi(
         xdim, udim, N, M, Nc, _f64(x0), f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev),
         to_abi_mat(Q), to_abi_mat(R), _f64(X_ref), _f64(U_ref), bx(x_l, nanx), bx(x_u, nanx), bx(u_l, nanu),
-        bx(u_u, nanu), float(reg_x), float(reg_u), sr, sr0, um1, return_info=return_info, weights=weights)
+        bx(u_u, nanu), float(reg_x), float(reg_u), sr, sr0, um1, return_info=return_info, weights=weights,
+        barrier_mu=barrier_mu)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -390,23 +449,26 @@ def cone_objective(J, eps=COST_ANCHOR_EPS):
     return min((1 + eps) * np.sum(np.maximum(J - t, 0.0)) + (1 - eps) * M * t for t in J)
 
 
-def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, return_info=False, **kw):
+def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, return_info=False,
+                   smooth_alpha=float("nan"), **kw):
     """Exact minimiser of the reference's cone-path problem for M < (1+eps)/(2 eps) ~ 500 particles, where eliminating
     (y, t) leaves  (1+eps) sum_i J_i - 2 eps M min_i J_i = sum_i w_i J_i  with w = 1+eps except for the cheapest
     particle(s), which share the deficit 2 eps M.  Search: every single candidate a (weighted exact QP, accepted iff a
     is the argmin of J at its own solution), then pairs on the kink J_a = J_b (root of the gap in the split theta).
     The returned certificate is the weighted QP's KKT certificate plus the support condition (down-weighted particles
-    attain min J), i.e. the KKT conditions of the epigraph problem with multipliers lambda_i = w_i."""
+    attain min J), i.e. the KKT conditions of the epigraph problem with multipliers lambda_i = w_i.
+    `smooth_alpha` finite: the boxes enter as the log barrier of `solve_barrier_exact` (mu = 1/alpha) instead."""
     from scipy.optimize import brentq
 
     eps = COST_ANCHOR_EPS
+    bmu = 1.0 / smooth_alpha if smooth_alpha == smooth_alpha and smooth_alpha > 0 else 0.0
     M = np.shape(f)[0]
     assert 2 * eps * M < 1 + eps, "threshold rank > 1: the reference's minimiser is not unique"
     args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
     ckw = dict(reg_x=reg_x, reg_u=reg_u, slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
 
     def solve(w):
-        X, U, info = lqp_solve_py(*args, reg_x=reg_x, reg_u=reg_u, Nc=Nc, weights=w, return_info=True, **kw)
+        X, U, info = lqp_solve_py(*args, reg_x=reg_x, reg_u=reg_u, Nc=Nc, weights=w, return_info=True, barrier_mu=bmu, **kw)
         return X, U, particle_costs_py(X, U, X_prev, U_prev, Q, R, X_ref, U_ref, **ckw), info
 
     hi = 1 + eps

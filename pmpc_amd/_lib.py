@@ -33,6 +33,7 @@ class PmpcProblem(ctypes.Structure):
         + [("Nc", ctypes.c_longlong), ("flags", ctypes.c_uint), ("reg_x", ctypes.c_double), ("reg_u", ctypes.c_double)]
         + [(k, ctypes.c_void_p) for k in ("x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref",
                                           "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out", "weights")]
+        + [("barrier_mu", ctypes.c_double)]
     )
 
 

@@ -201,6 +201,8 @@ __global__ void __launch_bounds__(TB) k_ipm_prepare(Slab s, int corrector, const
 __global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal *sc, double *part_s1, double *part_s2) {
   __shared__ double sh[TB];
   const double sigmu = corrector ? sc->sigmu : 0.0;
+  // barrier mode: no second-order correction — its fixed point is t*l = mu_target - dt_aff*dl_aff, not the centre
+  const double so = sc->mu_target > 0.0 ? 0.0 : 1.0;
   double a = 1.0, s1 = 0.0, s2 = 0.0;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
     Elem e = load_elem(s, k, sigmu, corrector != 0, true);
@@ -214,8 +216,8 @@ __global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal 
     }
     const double cl = e.dtl * e.dll, cu = e.dtu * e.dlu;
     if (!corrector) {
-      s.cl[k] = cl;
-      s.cu[k] = cu;
+      s.cl[k] = so * cl;
+      s.cu[k] = so * cu;
     }
     const double wgt = slab_weight(s, k);
     s1 += wgt * ((e.ml ? e.tl * e.dll + e.ll * e.dtl : 0.0) + (e.mu ? e.tu * e.dlu + e.lu * e.dtu : 0.0));
@@ -246,8 +248,8 @@ __global__ void __launch_bounds__(TB) k_ipm_update(Slab s, const IpmScal *sc) {
 // then the predictor preparation of the new iterate (D, w, partial sums of complementarity / count /
 // slack residual) and the gradient pre-pass arrays of the fast Riccati path
 //   gm = z - ref,   gd = reg (z - prev) + w      (consensus stages: w only on the owner's particle 0).
-__device__ __forceinline__ void advance_slab(const SlabEx &x, int do_update, double alpha, double sigmu, double &comp,
-                                             double &cnt, double &res) {
+__device__ __forceinline__ void advance_slab(const SlabEx &x, int do_update, double alpha, double sigmu, double mu_t, double &comp,
+                                             double &cnt, double &res, double &dev) {
   const Slab &s = x.s;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
     double z = s.z[k], w = 0.0;
@@ -274,6 +276,7 @@ __device__ __forceinline__ void advance_slab(const SlabEx &x, int do_update, dou
       comp += wgt * ((ml ? tl * ll : 0.0) + (mu ? tu * lu : 0.0));
       cnt += wgt * ((ml ? 1.0 : 0.0) + (mu ? 1.0 : 0.0));
       res = fmax(res, fmax(fabs(rl), fabs(ru)));
+      if (mu_t > 0.0 && wgt > 0.0) dev = fmax(dev, fmax(ml ? fabs(tl * ll - mu_t) : 0.0, mu ? fabs(tu * lu - mu_t) : 0.0));
       if (s.is_u && s.Nc > 0 && slab_weight(s, k) == 0.0) w = 0.0;  // consensus shift counted once
     } else if (do_update) {
       z += alpha * (s.dz[k] + s.dz2[k]);
@@ -292,14 +295,24 @@ __global__ void __launch_bounds__(TB) k_ipm_advance(SlabEx X, SlabEx U, int do_u
   __shared__ double sh[TB];
   const double alpha = do_update ? sc->alpha : 0.0, sigmu = do_update ? sc->sigmu : 0.0;
   const int B = gridDim.x;
-  double comp = 0.0, cnt = 0.0, res = 0.0;
-  advance_slab(X, do_update, alpha, sigmu, comp, cnt, res);
+  const double mu_t = sc->mu_target;
+  double *part_dev = sc->part_dev;
+  double comp = 0.0, cnt = 0.0, res = 0.0, dev = 0.0;
+  advance_slab(X, do_update, alpha, sigmu, mu_t, comp, cnt, res, dev);
   comp = block_sum(comp, sh); cnt = block_sum(cnt, sh); res = block_max(res, sh);
-  if (threadIdx.x == 0) { part_sum[blockIdx.x] = comp; part_cnt[blockIdx.x] = cnt; part_max[blockIdx.x] = res; }
-  comp = cnt = res = 0.0;
-  advance_slab(U, do_update, alpha, sigmu, comp, cnt, res);
+  if (mu_t > 0.0) dev = block_max(dev, sh);
+  if (threadIdx.x == 0) {
+    part_sum[blockIdx.x] = comp; part_cnt[blockIdx.x] = cnt; part_max[blockIdx.x] = res;
+    if (mu_t > 0.0) part_dev[blockIdx.x] = dev;
+  }
+  comp = cnt = res = dev = 0.0;
+  advance_slab(U, do_update, alpha, sigmu, mu_t, comp, cnt, res, dev);
   comp = block_sum(comp, sh); cnt = block_sum(cnt, sh); res = block_max(res, sh);
-  if (threadIdx.x == 0) { part_sum[B + blockIdx.x] = comp; part_cnt[B + blockIdx.x] = cnt; part_max[B + blockIdx.x] = res; }
+  if (mu_t > 0.0) dev = block_max(dev, sh);
+  if (threadIdx.x == 0) {
+    part_sum[B + blockIdx.x] = comp; part_cnt[B + blockIdx.x] = cnt; part_max[B + blockIdx.x] = res;
+    if (mu_t > 0.0) part_dev[B + blockIdx.x] = dev;
+  }
 }
 
 // 64-lane deterministic reductions of the block partials (fixed order: lane-strided, then butterfly)
@@ -326,7 +339,8 @@ __device__ __forceinline__ double wave_max(const double *p, int nb) {
 //         3 predictor (alpha_aff, mu_aff polynomial, sigma) | 4 corrector (alpha, nu, next mu / residual)
 __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int do_unpack, IpmScal *sc, const int *fail,
                                                      double *xch, int rank, int world, const double *part_sum,
-                                                     const double *part_cnt, const double *part_max, int nb) {
+                                                     const double *part_cnt, const double *part_max, int nb, double mu_target,
+                                                     double *part_dev) {
   const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
   const bool l0 = threadIdx.x == 0;
   if (phase == 0) {
@@ -339,6 +353,9 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
       sc->nu = 1.0;
       sc->iter = 0;
       sc->status = 0;
+      sc->mu_target = mu_target;
+      sc->dev_max = 0.0;
+      sc->part_dev = part_dev;
     }
     return;
   }
@@ -350,6 +367,7 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
       row[4] = wave_sum(part_sum, nb);
       row[5] = wave_sum(part_cnt, nb);
       row[6] = wave_max(part_max, nb);
+      if (sc->mu_target > 0.0) row[7] = wave_max(sc->part_dev, nb);
     } else {
       row[1] = wave_sum(part_sum, nb);
       row[2] = wave_sum(part_cnt, nb);
@@ -381,12 +399,13 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
     } else if (phase == 2) {
       sc->comp_sum = comp; sc->cnt = cnt; sc->res_max = res;
       sc->mu = comp / fmax(cnt, 1.0);
+      sc->dev_max = viol;
     } else if (phase == 3) {  // mu_aff(alpha_aff) = (S0 + a S1 + a^2 S2)/cnt, sigma = (mu_aff/mu)^3
       sc->alpha_aff = amin;
       const double mu_aff = (sc->comp_sum + amin * (s1 + amin * s2)) / fmax(sc->cnt, 1.0);
       const double r3 = mu_aff / sc->mu;
       sc->sigma = r3 * r3 * r3;
-      sc->sigmu = sc->sigma * sc->mu;
+      sc->sigmu = fmax(sc->sigma * sc->mu, sc->mu_target);  // barrier mode: never aim below the target centrality
     } else {  // phase 4: step length of the corrector, then the scalars of the NEXT iterate by the same polynomial
       double a = amin;
       if (a < 1.0) a = fmin(1.0, fmax(0.99, 1.0 - sc->mu) * a);
@@ -451,7 +470,8 @@ void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_update, dim3(grid_for(sl.count) * 4), dim3(TB), 0, s, sl, sc);
 }
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
-                         const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s) {
+                         const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,
+                         double mu_target, double *part_dev) {
   hipLaunchKernelGGL(k_ipm_exchange, dim3(1), dim3(TB), 0, s, phase, pack ? 1 : 0, unpack ? 1 : 0, sc, fail, xch, rank, world,
-                     part_sum, part_cnt, part_max, nblocks);
+                     part_sum, part_cnt, part_max, nblocks, mu_target, part_dev);
 }

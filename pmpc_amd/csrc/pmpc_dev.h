@@ -91,6 +91,10 @@ struct IpmScal {
   unsigned long long pad1;
   double mu, sigma, sigmu, alpha_aff, alpha, nu;
   int iter, status;
+  // log-barrier smoothing (cone path, smooth_alpha): stop AT centrality mu_target instead of driving mu to 0
+  double mu_target;  // 0 = hard constraints
+  double dev_max;    // max_k |t_k l_k - mu_target| of the current iterate (all-reduced: max)
+  double *part_dev;  // [2 * PMPC_RED_BLOCKS] block partials of dev_max
 };
 
 #define PMPC_RED_BLOCKS 1024
@@ -133,7 +137,8 @@ void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const I
 void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s);
 // phases: 0 reset | 1 violation | 2 IPM start | 3 predictor | 4 corrector (see kernels_ipm.hip)
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
-                         const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s);
+                         const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,
+                         double mu_target = 0.0, double *part_dev = nullptr);  // the last two: phase 0 only
 
 // ---- dynamics.hip -------------------------------------------------------------------------------
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,

@@ -70,6 +70,7 @@ struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc;  // cone path: particle weights / particle costs
+  DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
   SlabBufs sx, su;
 };
 
@@ -227,7 +228,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   Workspace &w = c->ws;
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
-                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc};
+                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -380,7 +381,13 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   IpmScal *sc = (IpmScal *)w.sc.p;
 
   // ---- 1. equality-only optimum: one Newton step from a dynamics-consistent base point -----------
-  launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s);
+  const double mu_target = (p->barrier_mu > 0.0 && (has_xb || has_ub)) ? p->barrier_mu : 0.0;
+  if (mu_target > 0.0 && w.part_dev.bytes == 0) {
+    w.part_dev.ensure(2 * PMPC_RED_BLOCKS * D8);
+    HIP_CHECK(hipMemsetAsync(w.part_dev.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
+  }
+  launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
+                      mu_target, w.part_dev.d());
   launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
   if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
   else launch_rollout(a, w.U.d(), w.X.d(), s);
@@ -445,7 +452,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   inf.max_violation = c->sc_host->viol_max;
   if (*c->fail_host || !(c->sc_host->viol_max == c->sc_host->viol_max)) return finish(2);
   if (verbose) printf("pmpc_hip: equality-only optimum, max bound violation %.3e\n", c->sc_host->viol_max);
-  if (c->sc_host->viol_max <= 0.0) return finish(0);
+  if (c->sc_host->viol_max <= 0.0 && mu_target == 0.0) return finish(0);  // (a barrier acts on feasible points too)
 
   // ---- 2. Mehrotra predictor-corrector on the boxes ----------------------------------------------
   if (has_ub) {
@@ -478,18 +485,20 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   for (int it = 1; it <= max_iter; it++) {
     // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
     launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
-    if (it == 1) {  // later iterates get mu / residual from the corrector's step polynomial (phase 4)
-      exchange(c, 2);
+    if (it == 1 || mu_target > 0.0) {  // later iterates get mu / residual from the corrector's step polynomial (phase 4);
+      exchange(c, 2);                    // barrier mode re-measures them together with the centrality deviation
       read_scalars(c);
     }
     const IpmScal &h = *c->sc_host;
     if (verbose)
-      printf("pmpc_hip: ipm it %2d  mu %9.3e  slack_res %9.3e  nu %9.3e  alpha %6.4f  sigma %8.2e\n", it, h.mu, h.res_max,
-             h.nu, h.alpha, h.sigma);
+      printf("pmpc_hip: ipm it %2d  mu %9.3e  slack_res %9.3e  nu %9.3e  alpha %6.4f  sigma %8.2e  dev %8.2e\n", it, h.mu, h.res_max,
+             h.nu, h.alpha, h.sigma, h.dev_max);
     inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
     if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
     if (h.mu > mu_peak) mu_peak = h.mu;
-    if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+    if (mu_target > 0.0) {  // centred AT mu_target: every complementarity product equals it
+      if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+    } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
     if (it == max_iter) break;
     // predictor (factorisation) ...
     structured_solve(c, a, true, fast, /*prep_done=*/true);
@@ -546,11 +555,6 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
     fprintf(stderr, "pmpc_hip: pmpc_lcone_solve_device is single-rank (the particle ranking is not exchanged over RCCL)\n");
     return 2;
   }
-  if (smooth_alpha == smooth_alpha) {
-    static bool warned = false;
-    if (!warned) fprintf(stderr, "pmpc_hip: c_lcone_solve(smooth_alpha=%g): constraint smoothing is not reproduced; hard boxes are used\n", smooth_alpha);
-    warned = true;
-  }
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
   const size_t M = p->M, D8 = sizeof(double);
@@ -563,6 +567,8 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
   }
   pmpc_problem q = *p;
   q.weights = w.pw.d();
+  // smooth_cstr = "logbarrier" (main.jl:246-262): -1/alpha sum log(alpha slack) replaces the hard boxes
+  q.barrier_mu = (smooth_alpha == smooth_alpha && smooth_alpha > 0.0) ? 1.0 / smooth_alpha : 0.0;
   pmpc_info inf, last;
   memset(&last, 0, sizeof(last));
   int outer = 0, solves_total = 0, ipm_total = 0;
@@ -728,6 +734,7 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
   p.X_out = c->stage[17].d(); p.U_out = c->stage[18].d();
   pmpc_info info;
   p.weights = nullptr;
+  p.barrier_mu = 0.0;
   if (cone) pmpc_lcone_solve_device(c, &p, smooth_alpha, &info, (int)verbose);
   else pmpc_lqp_solve_device(c, &p, &info, (int)verbose);
   HIP_CHECK(hipMemcpyAsync(X_out, p.X_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -75,7 +75,7 @@ class DeviceSolver:
     # ---- solve -----------------------------------------------------------------------------------------
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
-                 force_generic=False, symmetric_cost=False):
+                 barrier_mu=0.0, force_generic=False, symmetric_cost=False):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
@@ -101,7 +101,7 @@ class DeviceSolver:
             xdim=x, udim=u, N=N, M=M, Nc=int(Nc), flags=flags, reg_x=float(reg_x), reg_u=float(reg_u),
             x0=_p(x0), f=_p(f), fx=_p(fx), fu=_p(fu), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q), R=_p(R),
             X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
-            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights))
+            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu))
         return prob, X_out, U_out
 
     def lqp_solve(self, *, verbose=False, wait_current_stream=True, **kw):

@@ -76,6 +76,25 @@ def test_c_lcone_solve_matches_cone_oracle(case, oracle):
         assert abs(oracle.cone_objective(J) - oracle.cone_objective(info["J"])) <= 1e-8 * abs(oracle.cone_objective(info["J"]))
 
 
+@pytest.mark.parametrize("alpha", [1e1, 1e3])
+@pytest.mark.parametrize("idx", [0, 1, 2, 4, 6, 8])
+def test_c_lcone_solve_logbarrier_smoothing(idx, alpha, oracle):
+    """smooth_alpha finite => smooth_cstr = "logbarrier" (PMPC.jl/src/main.jl:240-262): every box row becomes
+    -1/alpha log(alpha slack) in the objective; device: the interior-point iteration stops AT mu = 1/alpha."""
+    from pmpc_amd import backend
+
+    case = CONE_CASES[idx]
+    M, N, x, u, Nc = case[:5]
+    args, kw = rand_problem(np.random.default_rng(4000 + idx), M, N, x, u, *case[5:9])
+    if case[9]:
+        args, kw = _make_kink(oracle, args, kw, Nc)
+    Xo, Uo, info = oracle.lcone_solve_py(*args, Nc=Nc, return_info=True, smooth_alpha=alpha, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=alpha, solver="ecos")
+    assert _rel(X, Xo) < TOL and _rel(U, Uo) < TOL
+    Xh, Uh = oracle.lcone_solve_py(*args, Nc=Nc, **kw)
+    assert _rel(U, Uh) > 1e-5  # and it is not the hard-constrained optimum
+
+
 @pytest.mark.parametrize("dims", [(6, 9, 12, 4, 1, False), (6, 9, 12, 4, 3, False), (5, 8, 3, 2, 2, True), (7, 6, 4, 2, -1, False)])
 def test_weighted_lqp_and_particle_costs(dims, oracle):
     import torch
