@@ -55,9 +55,11 @@ void c_lqp_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t 
                  long long verbose);
 
 /* replaces PMPC.jl/src/c_interface.jl:146-214 (prototype: module.cpp:17-23).
- * smooth_alpha = NaN => hard constraints (PMPC.jl/src/main.jl:242-244).  `solver` is accepted
- * for signature compatibility ("ecos" | "cosmo" | "mosek" | "gurobi"); see DESIGN.md for the
- * documented deviation of this entry point from the reference's epsilon-anchored cone objective (M > 1). */
+ * Minimises the reference's epsilon-anchored epigraph objective (main.jl:204-238, k = M) — see
+ * pmpc_lcone_solve_device below.  smooth_alpha = NaN => hard boxes (main.jl:242-244); finite => the boxes enter as
+ * -1/alpha sum log(alpha slack) (smooth_cstr = "logbarrier", main.jl:246-262).  `solver` ("ecos" | "cosmo" | "mosek" |
+ * "gurobi") only selects the conic back end upstream; all share one optimum (DESIGN.md section 2 notes the one
+ * exception, the reference's exponential-cone row order under "ecos", which is not reproduced). */
 void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
                    double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
                    double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,

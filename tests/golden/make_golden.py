@@ -12,8 +12,11 @@ What is pinned and by what:
     run with `pmpc.scp_mpc.aff_solve` replaced by the oracle (the loop looks it up as a module
     global, scp_mpc.py:370; Julia itself cannot run here).  Stored: final X, U and every `hist` row.
 
-The reference holds no numeric golden vectors for this path: these files pin the
-oracle + host loop against the reference's loop, not against Julia/OSQP output.
+  * `ref_notebook_cpu_table.npz`: the only numeric output of the reference's own solver stack on this path — the
+    50-row (obj, resid) table stored in examples/gpu_solver.ipynb (Julia + ECOS run by the authors, 4 digits).
+
+Apart from that table the reference holds no numeric golden vectors for this path: the other
+files pin the oracle + host loop against the reference's loop, not against Julia/OSQP output.
 """
 import sys
 from pathlib import Path
@@ -138,8 +141,28 @@ def scp_reference_run(N, reg_x, reg_u, max_it):
     return dict(X=X, U=U, hist=hist, N=np.array(N), reg_x=np.array(hist[0, 3]), reg_u=np.array(hist[0, 4]), max_it=np.array(max_it))
 
 
+def notebook_table():
+    """The one numeric output of the REFERENCE ITSELF that this path has: the table
+    printed by `pmpc.solve` in examples/gpu_solver.ipynb, cell "CPU version for a quick check" (50 SCP iterations,
+    4 significant digits): unicycle with eps = 1e-3 (the notebook's `car`), N = 20, M = 1, Q = I, R = 1e-2 I, x0 = 1,
+    refs 0, |u| <= 1, reg_x = 3, reg_u = 1, default solver "ecos" => the cone path.  The rows are data transcribed by
+    this function from the notebook's stored output; columns it, obj, resid, reg_x, reg_u."""
+    import json
+    import re
+
+    nb = json.load(open(REF / "examples" / "gpu_solver.ipynb"))
+    cell = next(c for c in nb["cells"] if c["cell_type"] == "code" and "X2, U2, data = pmpc.solve(**cpu_args, **cpu_opts)" in "".join(c["source"]))
+    text = "".join("".join(o.get("text", [])) for o in cell["outputs"] if "text" in o)
+    rows = [[float(v) for v in line.strip("| \n").split("|")] for line in text.splitlines() if re.match(r"\|\s*\d{4}", line)]
+    rows = np.array(rows)[:, [0, 2, 3, 4, 5]]
+    assert rows.shape == (50, 5)
+    return dict(table=rows, N=np.array(20), reg_x=np.array(3.0), reg_u=np.array(1.0), car_eps=np.array(1e-3), u_lim=np.array(1.0),
+                R_diag=np.array(1e-2), params=np.array([1.0, 1.0, 0.3]))
+
+
 if __name__ == "__main__":
     orc.build()
+    save("ref_notebook_cpu_table.npz", **notebook_table())
     for name, ul in (("qp_double_integrator_u04.npz", 0.4), ("qp_double_integrator_u1.npz", 1.0)):
         args, kw, Nc = double_integrator(ul)
         save(name, **solve_and_pack(args, kw, Nc))

@@ -65,3 +65,15 @@ def test_failure_convention_nan_outputs():
     args[7] = -np.tile(np.eye(2), (2, 5, 1, 1))  # R = -I, reg_u = 0.1  ->  Huu indefinite
     X, U = backend.lqp_solve(*abi_args(tuple(args), kw, 0))
     assert np.all(np.isnan(X)) and np.all(np.isnan(U))
+
+
+@pytest.mark.parametrize("solver", ["ecos", "osqp"])
+def test_scp_on_gpu_reproduces_reference_notebook_table(solver):
+    """The HIP back end through `pmpc_amd.solve` against the table the reference's own Julia + ECOS stack printed
+    (examples/gpu_solver.ipynb, 50 SCP iterations, 4 digits) — cone path ("ecos", as in the notebook) and QP path."""
+    import pmpc_amd
+    from tests.support import notebook_problem as nbp
+
+    args, kw, table = nbp.load()
+    X, U, data = pmpc_amd.solve(*args, solver_settings=dict(solver=solver), **kw)
+    nbp.check_rows(data["hist"], table)

@@ -232,3 +232,22 @@ def test_tune_scp_picks_smallest_residual():
     reg_x, reg_u = pmpc_amd.tune_scp(solve_fn=fake_solve, sample_nb=7, reg_rng=(-3, 3), reg_ratio=0.5)
     assert np.isclose(reg_x, 10.0) and np.isclose(reg_u, 5.0) and len(calls) == 7
     assert all(np.isclose(ru, 0.5 * rx) for rx, ru in calls)
+
+
+def test_oracle_and_host_loop_reproduce_reference_notebook_table(oracle, monkeypatch):
+    """PIN against the reference's own solver stack: the 50-row table printed by `pmpc.solve` (Julia + ECOS) in
+    examples/gpu_solver.ipynb is reproduced to its 4 printed digits by this repository's SCP loop + numpy unicycle +
+    the oracle's exact cone-path solve (M = 1: the minimiser of the QP)."""
+    import pmpc_amd.scp_mpc as scp
+    from tests.support import notebook_problem as nbp
+
+    args, kw, table = nbp.load()
+
+    def oracle_aff_solve(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l, u_u,
+                         solver_settings=None, **_):
+        X, U = oracle.lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=reg_x, reg_u=reg_u, Nc=-1, u_l=u_l, u_u=u_u)
+        return np.concatenate([x0[:, None, :], X], 1), U, dict()
+
+    monkeypatch.setattr(scp, "aff_solve", oracle_aff_solve)
+    X, U, data = scp.scp_solve(*args, solver_settings=dict(solver="ecos"), **kw)
+    nbp.check_rows(data["hist"], table)
