@@ -8,11 +8,13 @@
  *     z = [ U_cons (Nc*udim) ; U_free particle-major (M*Nf*udim) ; X particle-major (M*N*xdim) ]
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
- * this file.  PARITY UNPINNED: the reference's own tests hold no numeric golden
- * vector for this path (PMPC.jl/test/runtests.jl:33-41 asserts !isnan only) and
- * Julia/OSQP cannot run in the build container, so this restatement is pinned
- * only by its own KKT certificate (see lqp_oracle.py) and by the reference's
- * Python SCP loop run over it (tests/golden/).
+ * this file.  PARITY PINNED ONLY WEAKLY: the reference's own tests hold no numeric
+ * golden vector for this path (PMPC.jl/test/runtests.jl:33-41 asserts !isnan only) and
+ * Julia/OSQP cannot run in the build container.  The one reference-produced output that
+ * exists — the 50-row (obj, resid) table stored in examples/gpu_solver.ipynb, 4 digits,
+ * M = 1, u-box — is reproduced through this assembly (tests/test_host_logic.py);
+ * consensus (M > 1), slew and state-bound branches stay UNPINNED: they are held only by
+ * the KKT certificate (lqp_oracle.py) and the reference's Python SCP loop run over it.
  *
  * Every function cites the reference lines it follows.  Indices are 0-based here
  * (the reference is 1-based Julia); array layouts are the C-ABI layouts of
