@@ -15,3 +15,7 @@ find $out -name '*.csv' | head -20
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M 1024 > $out/bench_C.log 2>&1
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M 256 --N 30 --model unicycle > $out/bench_B.log 2>&1
 grep -h '^{' $out/bench_C.log $out/bench_B.log | cut -c1-200
+# secondary: the reference's default consensus horizon Nc = N (full consensus) on B and on the quadrotor
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --M 256 --N 30 --model unicycle --Nc -1 > $out/bench_B_NcN.log 2>&1
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --M 4096 --Nc -1 > $out/bench_D_NcN.log 2>&1
+grep -h '^{' $out/bench_B_NcN.log $out/bench_D_NcN.log | cut -c1-200

@@ -48,7 +48,11 @@ print(json.dumps(out, indent=1))
 
 stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))[0]
 (dst / f"{tag}_kernel_stats.csv").write_text(open(stats).read())
-for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f"{tag}_bench_under_rocprof.json")):
+for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f"{tag}_bench_under_rocprof.json"),
+                  ("bench_C.log", f"{tag}_bench_C.json"), ("bench_B.log", f"{tag}_bench_B.json"),
+                  ("bench_B_NcN.log", f"{tag}_bench_B_NcN.json"), ("bench_D_NcN.log", f"{tag}_bench_D_NcN.json")):
+    if not (src / log).exists():
+        continue
     lines = [l for l in open(src / log) if l.startswith("{")]
     if lines:
         (dst / name).write_text(lines[-1])
