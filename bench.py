@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="HIP events around every launch class, not only the dominant kernel")
     ap.add_argument("--ignore-status", action="store_true", help="timing experiments with deliberately wrong kernels")
     return ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
     torch.cuda.synchronize()
     run(args.warmup)
     solver.sync()
-    solver.profile(True)
+    solver.profile(2 if args.profile_all else 1)
     solver.profile_read()
     if world > 1:
         dist.barrier()
@@ -208,7 +209,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "backward Riccati factor sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * avg_s, "launches": int(n_f),
-                         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()}},
+                         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.model, M_total, N, Nc)

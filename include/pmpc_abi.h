@@ -146,9 +146,11 @@ int pmpc_comm_world(pmpc_ctx *ctx);
 int pmpc_linearize_device(pmpc_ctx *ctx, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu);
 
-/* Live kernel timing for bench.py: HIP events on pmpc_stream() around each launch class
- * (0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve). */
-void pmpc_profile_enable(pmpc_ctx *ctx, int on);
+/* Live kernel timing for bench.py: HIP events on pmpc_stream() around the launches of a class
+ * (0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve).
+ * level 0 = off, 1 = class 0 only (the dominant kernel; what bench.py's roofline needs), 2 = every class
+ * (each event pair costs a few microseconds of launch gap). */
+void pmpc_profile_enable(pmpc_ctx *ctx, int level);
 void pmpc_profile_read(pmpc_ctx *ctx, double *ms4, long long *n4);
 
 /* version / build probe used by the loader and the tests */

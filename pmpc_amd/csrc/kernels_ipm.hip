@@ -340,7 +340,8 @@ __device__ __forceinline__ double wave_max(const double *p, int nb) {
 __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int do_unpack, IpmScal *sc, const int *fail,
                                                      double *xch, int rank, int world, const double *part_sum,
                                                      const double *part_cnt, const double *part_max, int nb, double mu_target,
-                                                     double *part_dev) {
+                                                     double *part_dev, IpmScal *mirror, unsigned long long *mirror_seq,
+                                                     unsigned long long seq) {
   const unsigned long long one_bits = (unsigned long long)__double_as_longlong(1.0);
   const bool l0 = threadIdx.x == 0;
   if (phase == 0) {
@@ -416,6 +417,11 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
       sc->mu = sc->comp_sum / fmax(sc->cnt, 1.0);
       sc->res_max *= (1.0 - a);
     }
+    if (mirror) {  // zero-copy publication to host-coherent memory: the host polls `seq` instead of a blit + stream sync
+      *mirror = *sc;
+      __threadfence_system();
+      *(volatile unsigned long long *)mirror_seq = seq;
+    }
   }
 }
 
@@ -471,7 +477,8 @@ void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
 }
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
                          const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,
-                         double mu_target, double *part_dev) {
+                         double mu_target, double *part_dev, IpmScal *mirror, unsigned long long *mirror_seq,
+                         unsigned long long seq) {
   hipLaunchKernelGGL(k_ipm_exchange, dim3(1), dim3(TB), 0, s, phase, pack ? 1 : 0, unpack ? 1 : 0, sc, fail, xch, rank, world,
-                     part_sum, part_cnt, part_max, nblocks, mu_target, part_dev);
+                     part_sum, part_cnt, part_max, nblocks, mu_target, part_dev, mirror, mirror_seq, seq);
 }

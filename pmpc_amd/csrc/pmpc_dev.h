@@ -138,7 +138,8 @@ void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s);
 // phases: 0 reset | 1 violation | 2 IPM start | 3 predictor | 4 corrector (see kernels_ipm.hip)
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
                          const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,
-                         double mu_target = 0.0, double *part_dev = nullptr);  // the last two: phase 0 only
+                         double mu_target = 0.0, double *part_dev = nullptr,  // these two: phase 0 only
+                         IpmScal *mirror = nullptr, unsigned long long *mirror_seq = nullptr, unsigned long long seq = 0);
 
 // ---- dynamics.hip -------------------------------------------------------------------------------
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,

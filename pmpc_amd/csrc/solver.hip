@@ -83,13 +83,17 @@ struct ProfCat {
 };
 
 struct pmpc_ctx {
-  bool prof = false;
+  int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
   ProfCat cat[4];  // 0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve
   int device = 0;
   hipStream_t stream = nullptr;
   Workspace ws;
-  IpmScal *sc_host = nullptr;  // pinned
-  int *fail_host = nullptr;    // pinned
+  IpmScal *sc_host = nullptr;  // host snapshot of the device scalars
+  int *fail_host = nullptr;
+  // host-coherent mapped mirror the exchange kernel publishes into (zero-copy; the host polls `seq`)
+  struct ScMirror { IpmScal sc; unsigned long long seq; };
+  ScMirror *mirror = nullptr, *mirror_dev = nullptr;
+  unsigned long long seq = 0;
   // RCCL
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
@@ -112,8 +116,9 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
   pmpc_ctx *c;
   int k;
   std::pair<hipEvent_t, hipEvent_t> ev;
-  ProfScope(pmpc_ctx *c_, int k_) : c(c_), k(k_) {
-    if (!c->prof) return;
+  bool on;
+  ProfScope(pmpc_ctx *c_, int k_) : c(c_), k(k_), on(c_->prof >= 2 || (c_->prof == 1 && k_ == 0)) {
+    if (!on) return;
     ProfCat &pc = c->cat[k];
     if (pc.pool.empty()) {
       HIP_CHECK(hipEventCreate(&ev.first));
@@ -125,15 +130,30 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
     HIP_CHECK(hipEventRecord(ev.first, c->stream));
   }
   ~ProfScope() {
-    if (!c->prof) return;
+    if (!on) return;
     HIP_CHECK(hipEventRecord(ev.second, c->stream));
     c->cat[k].pending.push_back(ev);
   }
 };
 
 void read_scalars(pmpc_ctx *c) {  // sc->status carries the (cross-rank) failure flag of the last exchange
-  HIP_CHECK(hipMemcpyAsync(c->sc_host, c->ws.sc.p, sizeof(IpmScal), hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  // the last exchange kernel published the scalars + its sequence number into host-coherent memory: poll for it
+  // (a blit kernel + stream sync costs ~25 us of idle GPU per IPM iteration); fall back to a stream sync after ~2 s
+  volatile unsigned long long *seq = &c->mirror->seq;
+  bool seen = false;
+  for (long long spin = 0; spin < (1LL << 31); spin++) {
+    if (*seq == c->seq) { seen = true; break; }
+    __builtin_ia32_pause();
+  }
+  if (!seen) {
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (*seq != c->seq) {
+      fprintf(stderr, "pmpc_hip: scalar exchange was never published\n");
+      abort();
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  memcpy(c->sc_host, (const void *)&c->mirror->sc, sizeof(IpmScal));
   *c->fail_host = c->sc_host->status;
 }
 
@@ -142,16 +162,17 @@ void exchange(pmpc_ctx *c, int phase) {
   Workspace &w = c->ws;
   IpmScal *sc = (IpmScal *)w.sc.p;
   const int B2 = 2 * PMPC_RED_BLOCKS;
+  c->seq++;
   if (c->world <= 1) {
     launch_ipm_exchange(phase, true, true, sc, (const int *)w.fail.p, w.xch.d(), 0, 1, w.part_sum.d(), w.part_cnt.d(),
-                        w.part_max.d(), B2, c->stream);
+                        w.part_max.d(), B2, c->stream, 0.0, nullptr, &c->mirror_dev->sc, &c->mirror_dev->seq, c->seq);
     return;
   }
   launch_ipm_exchange(phase, true, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, w.part_sum.d(),
                       w.part_cnt.d(), w.part_max.d(), B2, c->stream);
   allreduce(c, w.xch.p, (size_t)c->world * 8, ncclFloat64, ncclSum);
   launch_ipm_exchange(phase, false, true, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, w.part_sum.d(),
-                      w.part_cnt.d(), w.part_max.d(), B2, c->stream);
+                      w.part_cnt.d(), w.part_max.d(), B2, c->stream, 0.0, nullptr, &c->mirror_dev->sc, &c->mirror_dev->seq, c->seq);
 }
 
 // one structured Newton solve: backward (factor or vector-only) -> reduce -> all-reduce -> dense solve -> forward
@@ -214,8 +235,11 @@ int pmpc_create(pmpc_ctx **out, int device) {
   c->device = device;
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIP_CHECK(hipHostMalloc((void **)&c->sc_host, sizeof(IpmScal)));
-  HIP_CHECK(hipHostMalloc((void **)&c->fail_host, sizeof(int)));
+  c->sc_host = (IpmScal *)calloc(1, sizeof(IpmScal));
+  c->fail_host = (int *)calloc(1, sizeof(int));
+  HIP_CHECK(hipHostMalloc((void **)&c->mirror, sizeof(pmpc_ctx::ScMirror), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(c->mirror, 0, sizeof(pmpc_ctx::ScMirror));
+  HIP_CHECK(hipHostGetDevicePointer((void **)&c->mirror_dev, c->mirror, 0));
   *out = c;
   return 0;
 }
@@ -233,8 +257,9 @@ void pmpc_destroy(pmpc_ctx *c) {
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
   for (DevBuf &b : c->stage) b.release();
-  (void)hipHostFree(c->sc_host);
-  (void)hipHostFree(c->fail_host);
+  (void)hipHostFree(c->mirror);
+  free(c->sc_host);
+  free(c->fail_host);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -242,7 +267,7 @@ void pmpc_destroy(pmpc_ctx *c) {
 void *pmpc_stream(pmpc_ctx *c) { return (void *)c->stream; }
 void pmpc_sync(pmpc_ctx *c) { HIP_CHECK(hipStreamSynchronize(c->stream)); }
 
-void pmpc_profile_enable(pmpc_ctx *c, int on) { c->prof = on != 0; }
+void pmpc_profile_enable(pmpc_ctx *c, int level) { c->prof = level < 0 ? 0 : level; }
 
 // Sums of HIP-event durations (ms) and launch counts per kernel class since the last read:
 // 0 backward+factor, 1 backward vector-only, 2 forward sweep, 3 consensus reduce + dense solve.

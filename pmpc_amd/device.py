@@ -151,8 +151,9 @@ class DeviceSolver:
     def sync(self):
         self.lib.pmpc_sync(self.h)
 
-    def profile(self, on: bool):
-        self.lib.pmpc_profile_enable(self.h, int(on))
+    def profile(self, level):
+        """0 / False: off; 1 / True: HIP events around the dominant kernel (factor sweep) only; 2: every launch class."""
+        self.lib.pmpc_profile_enable(self.h, int(level))
 
     def profile_read(self):
         """{class: (sum_ms, launches)} of HIP-event timings on the solver stream since the last read."""
