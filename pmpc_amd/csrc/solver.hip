@@ -507,9 +507,11 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   ex.pw = eu.pw = p->weights; ex.per = (long long)N * x; eu.per = (long long)N * u;
   ex.ref = p->X_ref; ex.prev = p->X_prev; ex.reg = p->reg_x; ex.gm = fast ? w.xm.d() : nullptr; ex.gd = fast ? w.xd.d() : nullptr;
   eu.ref = p->U_ref; eu.prev = p->U_prev; eu.reg = p->reg_u; eu.gm = fast ? w.um.d() : nullptr; eu.gd = fast ? w.ud.d() : nullptr;
+  bool advanced = false;  // this iteration's elementwise pass is already in flight (launched behind the last exchange)
   for (int it = 1; it <= max_iter; it++) {
     // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
-    launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+    if (!advanced) launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+    advanced = false;
     if (it == 1 || mu_target > 0.0) {  // later iterates get mu / residual from the corrector's step polynomial (phase 4);
       exchange(c, 2);                    // barrier mode re-measures them together with the centrality deviation
       read_scalars(c);
@@ -542,6 +544,13 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     if (has_ub) launch_ipm_step(su, 1, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
     sx.dz2 = su.dz2 = nullptr;
     exchange(c, 4);
+    if (mu_target == 0.0) {
+      // phase 4 already predicts the next iterate's scalars (step polynomial) and publishes them: enqueue the next
+      // elementwise pass BEHIND it before polling — it has to run whether or not that iterate turns out to be converged
+      // (it applies the step), and it keeps the GPU busy while the host decides and enqueues the next factor sweep
+      launch_ipm_advance(ex, eu, 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+      advanced = true;
+    }
     read_scalars(c);
   }
   if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
