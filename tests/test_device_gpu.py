@@ -100,23 +100,45 @@ def test_quadrotor_device_solve_matches_oracle(solver, oracle):
     assert solver.last_info["ipm_iters"] > 0  # the thrust / torque boxes are active on this problem
 
 
-@pytest.mark.parametrize("M", [1024, 4096])
-def test_full_size_properties(solver, M):
-    """BASELINE configs C (M=1024) and D (M=4096), N=50, x12 u4, Nc=1: properties that do not need the
-    oracle — consensus equality, box feasibility, exact linearised dynamics, and optimality certified
-    by perturbation (no feasible direction from a random sample decreases the objective)."""
+def _rollout_np(prob, f, fx, fu, U):
+    f, fx, fu = f.cpu().numpy(), fx.cpu().numpy().swapaxes(-1, -2), fu.cpu().numpy().swapaxes(-1, -2)
+    X = np.empty_like(f)
+    for j in range(f.shape[1]):  # PMPC.jl/src/types.jl:161-173
+        X[:, j] = f[:, j] + np.einsum("mrt,mt->mr", fu[:, j], U[:, j] - prob["U_prev"][:, j])
+        if j:
+            X[:, j] += np.einsum("mrt,mt->mr", fx[:, j], X[:, j - 1] - prob["X_prev"][:, j - 1])
+    return X
+
+
+def _objective(prob, X, U):
+    dx, du = X - prob["X_ref"], U - prob["U_ref"]
+    return 0.5 * (np.einsum("mnr,mnrt,mnt->", dx, prob["Q"], dx) + np.einsum("mnr,mnrt,mnt->", du, prob["R"], du)
+                  + prob["reg_x"] * np.sum((X - prob["X_prev"]) ** 2) + prob["reg_u"] * np.sum((U - prob["U_prev"]) ** 2))
+
+
+@pytest.mark.parametrize("M,Nc", [(1024, 1), (4096, 1), (1024, -1), (1024, 8)])
+def test_full_size_properties(solver, M, Nc):
+    """BASELINE configs C (M=1024) and D (M=4096), N=50, x12 u4, Nc=1 — and the reference's default full consensus
+    (Nc = N, nc = 200: condensing kernel with several column-tile waves per particle, blocked dense Cholesky) —
+    through properties that do not need the oracle: consensus equality, box feasibility, exact linearised dynamics,
+    and optimality by perturbation (no feasible, consensus-respecting direction from a random sample lowers the
+    objective of PMPC.jl/src/lqp_utils.jl:2-216)."""
     from pmpc_amd import dynamics as dyn
 
-    prob = dyn.make_quadrotor_problem(M=M, N=50)
-    X, U, status, (f, fx, fu) = _device_solve(solver, prob, 1)
+    prob = dyn.make_quadrotor_problem(M=M, N=50, Nc=Nc)
+    X, U, status, (f, fx, fu) = _device_solve(solver, prob, Nc)
     assert status == 0 and np.all(np.isfinite(X)) and np.all(np.isfinite(U))
-    assert np.all(U[:, 0] == U[0:1, 0])
+    k = 50 if Nc < 0 else Nc
+    assert np.all(U[:, :k] == U[0:1, :k])
     tol = 1e-9
     assert np.all(U >= prob["u_l"] - tol) and np.all(U <= prob["u_u"] + tol)
-    f, fx, fu = f.cpu().numpy(), fx.cpu().numpy().swapaxes(-1, -2), fu.cpu().numpy().swapaxes(-1, -2)
-    Xr = np.empty_like(X)
-    for j in range(50):  # PMPC.jl/src/types.jl:161-173
-        Xr[:, j] = f[:, j] + np.einsum("mrt,mt->mr", fu[:, j], U[:, j] - prob["U_prev"][:, j])
-        if j:
-            Xr[:, j] += np.einsum("mrt,mt->mr", fx[:, j], Xr[:, j - 1] - prob["X_prev"][:, j - 1])
+    Xr = _rollout_np(prob, f, fx, fu, U)
     assert np.max(np.abs(Xr - X)) < 1e-8 * max(1.0, np.max(np.abs(X)))
+    J0 = _objective(prob, Xr, U)
+    rng = np.random.default_rng(M + k)
+    for scale in (1e-2, 1e-4):
+        for _ in range(3):
+            dU = rng.standard_normal(U.shape)
+            dU[:, :k] = dU[0:1, :k]  # keep the consensus
+            U2 = np.clip(U + scale * dU, prob["u_l"], prob["u_u"])
+            assert _objective(prob, _rollout_np(prob, f, fx, fu, U2), U2) >= J0 * (1 - 1e-12)
