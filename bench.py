@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--N", type=int, default=50)
     ap.add_argument("--model", default="quadrotor", choices=["quadrotor", "unicycle"])
     ap.add_argument("--Nc", type=int, default=1, help="consensus horizon (-1 = N, the reference default)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --M particles PER GPU instead of in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -101,7 +102,7 @@ def main():
     from pmpc_amd import dynamics as dyn
     from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, DeviceSolver, to_device_problem
 
-    M_total, N, Nc = args.M, args.N, (args.N if args.Nc < 0 else args.Nc)
+    M_total, N, Nc = (args.M * world if args.weak else args.M), args.N, (args.N if args.Nc < 0 else args.Nc)
     assert M_total % world == 0
     M_loc = M_total // world
     if args.model == "quadrotor":
@@ -197,7 +198,7 @@ def main():
         out = {
             "metric": "SCP iterations/sec (M particles x N horizon)", "value": value, "unit": "SCP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                    "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
                                    if args.model == "quadrotor" and M_total == 4096 else
