@@ -246,9 +246,35 @@ def solve(*args, **kwargs):
     return scp_solve(*args, **kwargs)
 
 
-def solve_problems(problems: List[Dict[str, Any]], verbose: bool = False, **kw):
-    """pmpc/scp_mpc.py:504-511."""
-    return [solve(**dict(p, verbose=verbose)) for p in problems]
+_BATCH_ARRAY_KEYS = ("Q", "R", "x0", "X_ref", "U_ref", "X_prev", "U_prev", "x_l", "x_u", "u_l", "u_u", "u_slew")
+
+
+def solve_problems(problems: List[Dict[str, Any]], verbose: bool = False, batched: bool = False, split: bool = True, **kw):
+    """pmpc/scp_mpc.py:504-511: one `solve` per problem dictionary.
+
+    `batched=True` is the independent-problem mode the reference offers through other means
+    (pmpc/experimental/remote_like_interface.py:35-106 stacks the list and runs ONE `scp_solve`; pmpc/remote.py farms the
+    list out): the problems — same dimensions, the first one's batch-capable `f_fx_fu_fn`, scalar options of the first —
+    are stacked along the particle axis with consensus horizon `Nc = 0`, so every SCP iteration is one launch of the same
+    kernels over all of them.  All problems then take the same number of SCP iterations (the loop stops on the largest
+    residual).  `split=True` returns a list of `(X, U, data)`, else the stacked arrays."""
+    if not batched:
+        return [solve(**dict(p, verbose=verbose)) for p in problems]
+    assert len(problems) > 0
+    first = problems[0]
+    stacked: Dict[str, Any] = {k: v for k, v in first.items() if k not in _BATCH_ARRAY_KEYS}
+    for k in _BATCH_ARRAY_KEYS:
+        present = [k in p and p[k] is not None for p in problems]
+        if any(present):
+            assert all(present), f"`{k}` must be given for every problem or for none"
+            stacked[k] = np.stack([to_numpy_f64(p[k]) for p in problems], 0)
+    stacked["solver_settings"] = dict(copy(first.get("solver_settings") or {}), Nc=0)
+    stacked["verbose"] = verbose
+    f_fx_fu_fn, Q, R, x0 = (stacked.pop(k) for k in ("f_fx_fu_fn", "Q", "R", "x0"))
+    X, U, data = solve(f_fx_fu_fn, Q, R, x0, **stacked, **kw)
+    if not split or X is None:
+        return X, U, data
+    return [(X[i], U[i], data) for i in range(X.shape[0])]
 
 
 def tune_scp(*args, sample_nb: int = 14, reg_rng: Tuple[int, int] = (-3, 3), solve_fn: Callable = scp_solve,

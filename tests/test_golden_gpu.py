@@ -77,3 +77,29 @@ def test_scp_on_gpu_reproduces_reference_notebook_table(solver):
     args, kw, table = nbp.load()
     X, U, data = pmpc_amd.solve(*args, solver_settings=dict(solver=solver), **kw)
     nbp.check_rows(data["hist"], table)
+
+
+def test_batched_independent_problems_match_sequential_solves():
+    """`solve_problems(batched=True)`: K unrelated problems as K particles with Nc = 0 give the
+    trajectories of K separate `solve` calls run for the same number of SCP iterations."""
+    import pmpc_amd
+    from pmpc_amd import dynamics as dyn
+
+    N, xdim, udim, K = 15, 4, 2, 7
+    rng = np.random.default_rng(11)
+    params = np.array([1.0, 1.0, 0.3])
+
+    def f_fx_fu_fn(X, U):
+        return dyn.unicycle(X, U, params)
+
+    base = dict(f_fx_fu_fn=f_fx_fu_fn, Q=np.tile(np.eye(xdim), (N, 1, 1)), R=np.tile(1e-2 * np.eye(udim), (N, 1, 1)),
+                u_l=-np.ones((N, udim)), u_u=np.ones((N, udim)), reg_x=1.0, reg_u=1.0, max_it=6, res_tol=0.0,
+                solver_settings=dict(solver="osqp"))
+    problems = [dict(base, x0=np.ones(xdim) + 0.3 * rng.standard_normal(xdim), X_ref=0.2 * rng.standard_normal((N, xdim)),
+                     U_ref=np.zeros((N, udim))) for _ in range(K)]
+    seq = pmpc_amd.solve_problems(problems)
+    bat = pmpc_amd.solve_problems(problems, batched=True)
+    assert len(bat) == K
+    for (Xs, Us, _), (Xb, Ub, _) in zip(seq, bat):
+        assert Xs.shape == Xb.shape == (N + 1, xdim)
+        assert np.linalg.norm(Xs - Xb) / np.linalg.norm(Xs) < 1e-7 and np.linalg.norm(Us - Ub) / max(np.linalg.norm(Us), 1.0) < 1e-7
