@@ -96,10 +96,6 @@ __device__ __forceinline__ double block_min(double v, double *sh) {
 __global__ void __launch_bounds__(TB) k_axpy(double *y, const double *x, double alpha, long long n) {
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) y[k] += alpha * x[k];
 }
-__global__ void __launch_bounds__(TB) k_axpy_alpha(double *y, const double *x, const IpmScal *sc, long long n) {
-  const double alpha = sc->alpha;
-  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) y[k] += alpha * x[k];
-}
 __global__ void __launch_bounds__(TB) k_fill(double *y, double v, long long n) {
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) y[k] = v;
 }
@@ -234,15 +230,6 @@ __global__ void __launch_bounds__(TB) k_ipm_step(Slab s, int corrector, IpmScal 
   }
 }
 
-__global__ void __launch_bounds__(TB) k_ipm_update(Slab s, const IpmScal *sc) {
-  const double a = sc->alpha, sigmu = sc->sigmu;
-  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
-    Elem e = load_elem(s, k, sigmu, true, true);
-    s.z[k] += a * (s.dz[k] + (s.dz2 ? s.dz2[k] : 0.0));
-    if (e.ml) { s.tl[k] = e.tl + a * e.dtl; s.ll[k] = e.ll + a * e.dll; }
-    if (e.mu) { s.tu[k] = e.tu + a * e.dtu; s.lu[k] = e.lu + a * e.dlu; }
-  }
-}
 
 // One pass per IPM iteration over BOTH slabs: (optionally) take the previous step z,t,l += alpha*d,
 // then the predictor preparation of the new iterate (D, w, partial sums of complementarity / count /
@@ -257,7 +244,7 @@ __device__ __forceinline__ void advance_slab(const SlabEx &x, int do_update, dou
       const double lo = s.lo[k], hi = s.hi[k];
       const bool ml = isfinite(lo), mu = isfinite(hi);
       double tl = s.tl[k], tu = s.tu[k], ll = s.ll[k], lu = s.lu[k];
-      if (do_update) {  // corrector step, exactly as k_ipm_update
+      if (do_update) {  // take the corrector step: z, t, lambda += alpha * d (d rebuilt from the stored step dz + dz2)
         const double dz = s.dz[k] + s.dz2[k];
         const double rl = ml ? z - lo - tl : 0.0, ru = mu ? hi - z - tu : 0.0;
         const double wl = ml ? (sigmu - s.cl[k] - ll * rl) / tl : 0.0, wu = mu ? (sigmu - s.cu[k] - lu * ru) / tu : 0.0;
@@ -437,9 +424,6 @@ inline int grid_for(long long n) {
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s) {
   hipLaunchKernelGGL(k_axpy, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, xv, alpha, n);
 }
-void launch_axpy_alpha(double *y, const double *xv, const IpmScal *sc, long long n, hipStream_t s) {
-  hipLaunchKernelGGL(k_axpy_alpha, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, xv, sc, n);
-}
 void launch_fill(double *y, double v, long long n, hipStream_t s) {
   hipLaunchKernelGGL(k_fill, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, v, n);
 }
@@ -471,9 +455,6 @@ void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, double *part_s1
 void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_advance, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, X, U, do_update, sc, part_sum, part_cnt, part_max);
-}
-void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s) {
-  hipLaunchKernelGGL(k_ipm_update, dim3(grid_for(sl.count) * 4), dim3(TB), 0, s, sl, sc);
 }
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
                          const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,

@@ -123,7 +123,6 @@ void launch_particle_cost(const LQArgs &a, const double *X, const double *U, dou
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s);
 void launch_fill(double *y, double v, long long n, hipStream_t s);
-void launch_axpy_alpha(double *y, const double *xv, const IpmScal *sc, long long n, hipStream_t s);
 void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hipStream_t s);
 void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc, hipStream_t s);
 void launch_violation(const Slab &sl, double *part_max, hipStream_t s);
@@ -134,7 +133,6 @@ void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double
 void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, double *part_s1, double *part_s2, hipStream_t s);
 void launch_ipm_advance(const SlabEx &X, const SlabEx &U, int do_update, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s);
-void launch_ipm_update(const Slab &sl, const IpmScal *sc, hipStream_t s);
 // phases: 0 reset | 1 violation | 2 IPM start | 3 predictor | 4 corrector (see kernels_ipm.hip)
 void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const int *fail, double *xch, int rank, int world,
                          const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,
