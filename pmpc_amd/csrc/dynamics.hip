@@ -7,17 +7,27 @@
 // model 0: unicycle of the reference's tests/dubins_car.py:48-90 (closed-form Jacobians; the
 //          reference uses torch.autograd, :11-30).  params (3,M) = [v_scale, w_scale, T].
 // model 1: synthetic quadrotor of SURVEY.md §8(d) (not in the reference). params (4,M) = [m,Jx,Jy,Jz].
-// Host (numpy) specifications: pmpc_amd/dynamics.py.  One thread per (particle, stage); stores are
-// 8-byte scattered within the thread's own 1152-byte block (HBM write-combining in L2).
+// Host (numpy) specifications: pmpc_amd/dynamics.py.  One thread evaluates one (particle, stage) into an LDS record
+// [f | fx | fu]; the workgroup then streams its records out: consecutive (particle, stage) units are consecutive
+// in all three stacks, so every store instruction writes 64 consecutive doubles (8-byte stores scattered inside each
+// thread's own 1152-byte block reached 1.9 TB/s; the staged version is write-bandwidth bound).
 #include "pmpc_dev.h"
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_lin_unicycle(int N, int M, const double *x0, const double *X_prev,
-                                                      const double *U_prev, const double *params, double *f, double *fx,
-                                                      double *fu) {
-  const long long idx = blockIdx.x * 256LL + threadIdx.x;
-  if (idx >= (long long)M * N) return;
+struct Unicycle {
+  static constexpr int X = 4, U = 2, UNITS = 64;
+  static __device__ __forceinline__ void eval(long long idx, int N, const double *x0, const double *X_prev, const double *U_prev,
+                                              const double *params, double *fo, double *A, double *B);
+};
+struct Quadrotor {
+  static constexpr int X = 12, U = 4, UNITS = 32;  // 32 records of 204 doubles = 52 KB of LDS
+  static __device__ __forceinline__ void eval(long long idx, int N, const double *x0, const double *X_prev, const double *U_prev,
+                                              const double *params, double *fo, double *A, double *B);
+};
+
+__device__ __forceinline__ void Unicycle::eval(long long idx, int N, const double *x0, const double *X_prev, const double *U_prev,
+                                               const double *params, double *fo, double *A, double *B) {
   const int i = (int)(idx / N), j = (int)(idx % N);
   const double *xs = j == 0 ? x0 + 4 * (size_t)i : X_prev + (idx - 1) * 4;
   const double *us = U_prev + idx * 2, *p = params + 3 * (size_t)i;
@@ -33,7 +43,6 @@ __global__ void __launch_bounds__(256) k_lin_unicycle(int N, int M, const double
   const double iu2 = 1.0 / u2, iu22 = iu2 * iu2;
   const double n1 = u2 * sa * v0 + T * u1 * u2 * sa + u1 * ca - s0 * u2 * v0 - c0 * u1;
   const double n2 = -(u2 * ca * v0 - u1 * sa + T * u1 * u2 * ca) + c0 * u2 * v0 - s0 * u1;
-  double *fo = f + idx * 4, *A = fx + idx * 16, *B = fu + idx * 8;
   fo[0] = px + n1 * iu22; fo[1] = py + n2 * iu22; fo[2] = v0 + T * u1; fo[3] = a;
   for (int k = 0; k < 16; k++) A[k] = 0.0;
   for (int k = 0; k < 8; k++) B[k] = 0.0;
@@ -54,11 +63,8 @@ __global__ void __launch_bounds__(256) k_lin_unicycle(int N, int M, const double
   B[3 + 4 * 1] = T * (-ws);
 }
 
-__global__ void __launch_bounds__(256) k_lin_quadrotor(int N, int M, const double *x0, const double *X_prev,
-                                                       const double *U_prev, const double *params, double *f, double *fx,
-                                                       double *fu) {
-  const long long idx = blockIdx.x * 256LL + threadIdx.x;
-  if (idx >= (long long)M * N) return;
+__device__ __forceinline__ void Quadrotor::eval(long long idx, int N, const double *x0, const double *X_prev, const double *U_prev,
+                                                const double *params, double *fo, double *A, double *B) {
   const int i = (int)(idx / N), j = (int)(idx % N);
   const double *xs = j == 0 ? x0 + 12 * (size_t)i : X_prev + (idx - 1) * 12;
   const double *us = U_prev + idx * 4, *p = params + 4 * (size_t)i;
@@ -72,7 +78,6 @@ __global__ void __launch_bounds__(256) k_lin_quadrotor(int N, int M, const doubl
   const double icth = 1.0 / cth, tth = sth * icth, sec2 = icth * icth;
   const double bx = cps * sth * cph + sps * sph, by = sps * sth * cph - cps * sph, bz = cth * cph;
   const double a = T / m;
-  double *fo = f + idx * 12, *A = fx + idx * 144, *B = fu + idx * 48;
   fo[0] = xs[0] + dt * xs[3]; fo[1] = xs[1] + dt * xs[4]; fo[2] = xs[2] + dt * xs[5];
   fo[3] = xs[3] + dt * a * bx; fo[4] = xs[4] + dt * a * by; fo[5] = xs[5] + dt * (a * bz - g);
   fo[6] = ph + dt * (wx + sph * tth * wy + cph * tth * wz);
@@ -107,12 +112,39 @@ __global__ void __launch_bounds__(256) k_lin_quadrotor(int N, int M, const doubl
 #undef BE
 }
 
+template <class Model>
+__global__ void __launch_bounds__(64) k_linearize(int N, long long tot, const double *x0, const double *X_prev, const double *U_prev,
+                                                  const double *params, double *f, double *fx, double *fu) {
+  constexpr int X = Model::X, U = Model::U, UNITS = Model::UNITS;
+  constexpr int REC = X + X * X + X * U, LD = REC | 1;  // odd record stride: conflict-free LDS stores
+  extern __shared__ double rec[];
+  const int t = threadIdx.x;
+  const long long first = (long long)blockIdx.x * UNITS;
+  if (t < UNITS && first + t < tot) {
+    double *mine = rec + t * LD;
+    Model::eval(first + t, N, x0, X_prev, U_prev, params, mine, mine + X, mine + X + X * X);
+  }
+  __syncthreads();
+  const int n = (int)((tot - first) < UNITS ? (tot - first) : UNITS);
+  for (int e = t; e < n * X; e += 64) f[first * X + e] = rec[(e / X) * LD + e % X];
+  for (int e = t; e < n * X * X; e += 64) fx[first * (X * X) + e] = rec[(e / (X * X)) * LD + X + e % (X * X)];
+  for (int e = t; e < n * X * U; e += 64) fu[first * (X * U) + e] = rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
+}
+
+template <class Model>
+void launch_model(int N, int M, const double *x0, const double *X_prev, const double *U_prev, const double *params, double *f,
+                  double *fx, double *fu, hipStream_t s) {
+  const long long tot = (long long)M * N;
+  constexpr int REC = Model::X + Model::X * Model::X + Model::X * Model::U, LD = REC | 1;
+  const unsigned grid = (unsigned)((tot + Model::UNITS - 1) / Model::UNITS);
+  hipLaunchKernelGGL((k_linearize<Model>), dim3(grid), dim3(64), Model::UNITS * LD * sizeof(double), s, N, tot, x0, X_prev, U_prev,
+                     params, f, fx, fu);
+}
+
 }  // namespace
 
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                       const double *params, double *f, double *fx, double *fu, hipStream_t s) {
-  const long long tot = (long long)M * N;
-  dim3 grid((unsigned)((tot + 255) / 256));
-  if (model == 0) hipLaunchKernelGGL(k_lin_unicycle, grid, dim3(256), 0, s, N, M, x0, X_prev, U_prev, params, f, fx, fu);
-  else hipLaunchKernelGGL(k_lin_quadrotor, grid, dim3(256), 0, s, N, M, x0, X_prev, U_prev, params, f, fx, fu);
+  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, s);
+  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, s);
 }
