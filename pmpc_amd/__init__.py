@@ -11,6 +11,13 @@ from .backend import is_precompiled_backend_available, lcone_solve, lqp_solve  #
 from .problem_struct import Problem  # noqa: F401
 from .problem_matrices import lqp_generate_problem_matrices  # noqa: F401
 
+
+def scp_solve_device(*args, **kw):
+    """Device-resident SCP loop (torch tensors in HBM end to end); see pmpc_amd/scp_device.py."""
+    from .scp_device import scp_solve_device as _impl
+
+    return _impl(*args, **kw)
+
 # keyword-compatible arguments of `solve` (pmpc/__init__.py:5-31)
 SOLVE_KWS = {
     "X_ref", "U_ref", "X_prev", "U_prev", "x_l", "x_u", "u_l", "u_u", "verbose", "debug", "max_it", "time_limit",

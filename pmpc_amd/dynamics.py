@@ -75,6 +75,40 @@ def unicycle(x, u, p, eps=1e-6):
     return f, fx, fu
 
 
+def unicycle_torch(x, u, p, eps=1e-6):
+    """`unicycle` on torch tensors of any device (same closed form, same outputs) — an example of an `f_fx_fu_fn` for
+    the device-resident loop `solve(..., device="cuda")`."""
+    import torch
+
+    vs, ws, T = p[..., 0], p[..., 1], p[..., 2]
+    u1, u2 = vs * u[..., 0], -ws * u[..., 1]
+    u1 = u1 + torch.where(u1 >= 0.0, eps, -eps)
+    u2 = u2 + torch.where(u2 >= 0.0, eps, -eps)
+    px, py, v0, th0 = x[..., 0], x[..., 1], x[..., 2], x[..., 3]
+    a = T * u2 + th0
+    sa, ca, s0, c0 = torch.sin(a), torch.cos(a), torch.sin(th0), torch.cos(th0)
+    iu2 = 1.0 / u2
+    iu22 = iu2 * iu2
+    n1 = u2 * sa * v0 + T * u1 * u2 * sa + u1 * ca - s0 * u2 * v0 - c0 * u1
+    n2 = -(u2 * ca * v0 - u1 * sa + T * u1 * u2 * ca) + c0 * u2 * v0 - s0 * u1
+    f = torch.stack([px + n1 * iu22, py + n2 * iu22, v0 + T * u1, a], -1)
+    fx = torch.zeros(x.shape[:-1] + (4, 4), dtype=x.dtype, device=x.device)
+    fu = torch.zeros(x.shape[:-1] + (4, 2), dtype=x.dtype, device=x.device)
+    fx[..., 0, 0] = fx[..., 1, 1] = fx[..., 2, 2] = fx[..., 3, 3] = 1.0
+    fx[..., 0, 2] = (u2 * sa - s0 * u2) * iu22
+    fx[..., 0, 3] = (u2 * ca * v0 + T * u1 * u2 * ca - u1 * sa - c0 * u2 * v0 + s0 * u1) * iu22
+    fx[..., 1, 2] = (-u2 * ca + c0 * u2) * iu22
+    fx[..., 1, 3] = (-(-u2 * sa * v0 - u1 * ca - T * u1 * u2 * sa) - s0 * u2 * v0 - c0 * u1) * iu22
+    dn1_du1, dn2_du1 = T * u2 * sa + ca - c0, sa - T * u2 * ca - s0
+    dn1_du2 = sa * v0 + u2 * ca * T * v0 + T * u1 * sa + T * u1 * u2 * ca * T - u1 * sa * T - s0 * v0
+    dn2_du2 = -(ca * v0 - u2 * sa * T * v0 - u1 * ca * T + T * u1 * ca - T * T * u1 * u2 * sa) + c0 * v0
+    fu[..., 0, 0], fu[..., 1, 0], fu[..., 2, 0] = dn1_du1 * iu22 * vs, dn2_du1 * iu22 * vs, T * vs
+    fu[..., 0, 1] = (dn1_du2 * iu22 - 2.0 * n1 * iu22 * iu2) * (-ws)
+    fu[..., 1, 1] = (dn2_du2 * iu22 - 2.0 * n2 * iu22 * iu2) * (-ws)
+    fu[..., 3, 1] = T * (-ws)
+    return f, fx, fu
+
+
 # -------------------------------------------------------------------------------------------------
 # synthetic quadrotor (SURVEY.md §8d)
 # -------------------------------------------------------------------------------------------------

@@ -111,7 +111,16 @@ def scp_solve(
     **extra_kw,
 ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], Optional[Dict[str, Any]]]:
     """SCP solution of a nonlinear-dynamics / quadratic-cost control problem
-    (semantics of pmpc/scp_mpc.py:205-442; defaults identical)."""
+    (semantics of pmpc/scp_mpc.py:205-442; defaults identical).  `device="cuda"` (extra keyword, cf. the `device` option
+    of the reference's pmpc/experimental solver) runs the whole loop on the GPU with torch tensors: pmpc_amd/scp_device.py."""
+    if extra_kw.get("device") is not None:
+        from .scp_device import scp_solve_device
+
+        return scp_solve_device(f_fx_fu_fn, Q, R, x0, X_ref=X_ref, U_ref=U_ref, X_prev=X_prev, U_prev=U_prev, x_l=x_l, x_u=x_u,
+                                u_l=u_l, u_u=u_u, verbose=verbose, debug=debug, max_it=max_it, time_limit=time_limit, res_tol=res_tol,
+                                reg_x=reg_x, reg_u=reg_u, slew_rate=slew_rate, u0_slew=u0_slew, lin_cost_fn=lin_cost_fn,
+                                cost_fn=cost_fn, extra_cstrs_fns=extra_cstrs_fns, solver_settings=solver_settings,
+                                solver_state=solver_state, filter_method=filter_method, return_min_viol=return_min_viol, **extra_kw)
     if cost_fn is not None:
         raise ValueError("cost_fn is deprecated, use lin_cost_fn instead.")
     t_start = time.time()

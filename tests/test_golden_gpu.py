@@ -103,3 +103,34 @@ def test_batched_independent_problems_match_sequential_solves():
     for (Xs, Us, _), (Xb, Ub, _) in zip(seq, bat):
         assert Xs.shape == Xb.shape == (N + 1, xdim)
         assert np.linalg.norm(Xs - Xb) / np.linalg.norm(Xs) < 1e-7 and np.linalg.norm(Us - Ub) / max(np.linalg.norm(Us), 1.0) < 1e-7
+
+
+@pytest.mark.parametrize("mode", ["torch_callable", "builtin_model", "cone"])
+def test_device_resident_scp_loop_matches_host_loop(mode):
+    """`solve(..., device="cuda")` (pmpc_amd/scp_device.py: torch tensors in HBM end to end) against the host loop
+    (numpy callable through the C ABI): same hist rows and trajectories, consensus problem with M = 6 particles."""
+    import torch
+
+    import pmpc_amd
+    from pmpc_amd import dynamics as dyn
+
+    M, N, xdim, udim = 6, 20, 4, 2
+    rng = np.random.default_rng(5)
+    P = np.stack([1.0 + 0.1 * rng.standard_normal(M), 1.0 + 0.1 * rng.standard_normal(M), np.full(M, 0.3)], -1)
+    Pt = torch.tensor(P, device="cuda")
+    Q, R = np.tile(np.eye(xdim), (M, N, 1, 1)), np.tile(1e-2 * np.eye(udim), (M, N, 1, 1))
+    x0 = 1.0 + 0.05 * rng.standard_normal((M, xdim))
+    kw = dict(u_l=-np.ones((M, N, udim)), u_u=np.ones((M, N, udim)), reg_x=1.0, reg_u=1.0, max_it=8, res_tol=0.0, verbose=False,
+              solver_settings=dict(solver="ecos" if mode == "cone" else "osqp", Nc=2))
+    Xh, Uh, dh = pmpc_amd.solve(lambda X, U: dyn.unicycle(X, U, P[:, None, :]), Q, R, x0, **kw)
+    if mode == "builtin_model":
+        Xd, Ud, dd = pmpc_amd.solve(None, Q, R, x0, device="cuda", builtin_model="unicycle", params=P, **kw)
+    else:
+        Xd, Ud, dd = pmpc_amd.solve(lambda X, U: dyn.unicycle_torch(X, U, Pt[:, None, :]), Q, R, x0, device="cuda", **kw)
+    assert Xd.shape == (M, N + 1, xdim) and len(dd["hist"]) == len(dh["hist"]) == 8
+    # the two loops evaluate the unicycle with different sin/cos implementations (numpy / torch-ROCm / HIP); its closed
+    # form divides an O(u2^2) difference by u2^2 with u2 ~ eps at U = 0, which amplifies those last-bit differences to
+    # ~1e-6 per linearisation — hence 1e-4 here (layout or plumbing mistakes would show up as O(1))
+    assert np.linalg.norm(Xd - Xh) / np.linalg.norm(Xh) < 1e-4 and np.linalg.norm(Ud - Uh) / np.linalg.norm(Uh) < 1e-4
+    for a, b in zip(dd["hist"], dh["hist"]):
+        assert abs(a["obj"] - b["obj"]) <= 1e-4 * abs(b["obj"]) and abs(a["resid"] - b["resid"]) <= 1e-3 * max(b["resid"], 1e-3)
