@@ -166,7 +166,8 @@ def main():
         elapsed = float(t.item())
     prof = solver.profile_read()
     # outside the timed region: the convex sub-problem alone (SURVEY.md section 8d asks for the aff_solve-only rate next
-    # to the full-iteration rate) — same linearisation re-solved, no dynamics / residual kernels
+    # to the full-iteration rate) — same linearisation re-solved from a COLD start (re-solving an identical problem
+    # warm would flatter the number), no dynamics / residual kernels
     solver.profile(False)
     k2 = max(1, min(args.steps, 10))
     torch.cuda.synchronize()
@@ -174,7 +175,7 @@ def main():
     for _ in range(k2):
         solver.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xb, U_prev=Ub, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"],
                          reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"), X_out=Xa, U_out=Ua,
-                         force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False)
+                         force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False, cold_start=True)
     solver.sync()
     aff_only = k2 / (time.perf_counter() - t1)
     timed = hist[args.warmup:]
@@ -206,7 +207,8 @@ def main():
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",
                        "ipm_iters_per_step": float(np.mean(ipm_its)), "riccati_factorisations_per_step": float(np.mean(solves)),
                        "fast_path": bool(timed[-1][1]["fast_path"]), "final_scp_residual": float(timed[-1][0].item()),
-                       "aff_solve_only_per_s": aff_only},
+                       "aff_solve_only_cold_per_s": aff_only,
+                       "ipm_warm_start": os.environ.get("PMPC_WARM_START", "1") != "0"},
             "roofline": {"bound": "hbm", "kernel": "backward Riccati factor sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * avg_s, "launches": int(n_f),

@@ -79,6 +79,9 @@ void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_
 #define PMPC_SYMMETRIC_COST 32u /* caller guarantees Q_j == Q_j' and R_j == R_j' exactly (OSQP keeps
                                    triu(P); the register-resident path relies on symmetric blocks) */
 
+#define PMPC_COLD_START 64u /* do not start the interior-point iteration from the iterate remembered from the previous
+                               solve of the same shape (see "warm start" in DESIGN.md section 2) */
+
 typedef struct pmpc_problem {
   size_t xdim, udim, N, M; /* M = particles held by THIS rank */
   long long Nc;

@@ -145,12 +145,14 @@ __global__ void __launch_bounds__(TB) k_ipm_clip(Slab s) {
   }
 }
 
-__global__ void __launch_bounds__(TB) k_ipm_init_slack(Slab s, double mu0) {
+__global__ void __launch_bounds__(TB) k_ipm_init_slack(Slab s, double mu0, double thr_frac) {
+  // thr_frac: lower clamp of the slacks as a fraction of the box width (cold start 1e-2; a warm start keeps the
+  // remembered iterate's own slacks, clamped only against exact zeros)
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
     const double lo = s.lo[k], hi = s.hi[k], z = s.z[k];
     const bool ml = isfinite(lo), mu = isfinite(hi);
     const double wid = (ml && mu) ? hi - lo : 1.0;
-    const double thr = fmax(1e-2 * wid, 1e-4);
+    const double thr = fmax(thr_frac * wid, 1e-2 * thr_frac);
     const double tl = ml ? fmax(z - lo, thr) : 1.0, tu = mu ? fmax(hi - z, thr) : 1.0;
     s.tl[k] = tl;
     s.tu[k] = tu;
@@ -442,8 +444,8 @@ void launch_violation(const Slab &sl, double *part_max, hipStream_t s) {
 void launch_ipm_clip(const Slab &sl, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_clip, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl);
 }
-void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s) {
-  hipLaunchKernelGGL(k_ipm_init_slack, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl, mu0);
+void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s, double thr_frac) {
+  hipLaunchKernelGGL(k_ipm_init_slack, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl, mu0, thr_frac);
 }
 void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s) {

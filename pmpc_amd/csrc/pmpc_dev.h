@@ -127,7 +127,7 @@ void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hip
 void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc, hipStream_t s);
 void launch_violation(const Slab &sl, double *part_max, hipStream_t s);
 void launch_ipm_clip(const Slab &sl, hipStream_t s);
-void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s);
+void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s, double thr_frac = 1e-2);
 void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s);
 void launch_ipm_step(const Slab &sl, int corrector, IpmScal *sc, double *part_s1, double *part_s2, hipStream_t s);

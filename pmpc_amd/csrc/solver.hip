@@ -70,6 +70,9 @@ struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc;  // cone path: particle weights / particle costs
+  // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
+  DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux, Ueq;
+  long long warm_key = -1;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
   SlabBufs sx, su;
 };
@@ -252,7 +255,8 @@ void pmpc_destroy(pmpc_ctx *c) {
   Workspace &w = c->ws;
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
-                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev};
+                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
+                   &w.warm_lux, &w.Ueq};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -480,20 +484,22 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   if (c->sc_host->viol_max <= 0.0 && mu_target == 0.0) return finish(0);  // (a barrier acts on feasible points too)
 
   // ---- 2. Mehrotra predictor-corrector on the boxes ----------------------------------------------
-  if (has_ub) {
-    launch_ipm_clip(su, s);
-    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
-    else launch_rollout(a, w.U.d(), w.X.d(), s);
+  // Warm start: consecutive sub-problems of an SCP / MPC loop are close, so the EARLY iterate of the previous solve of
+  // this shape (first iterate with mu <= 0.5: interior, centred, far from its boxes — a late iterate jams) is a better
+  // start than the clipped equality-only optimum: 11 -> 9.3 iterations at config D, 11 -> 7.1 on the unicycle.  It is
+  // used only if it is strictly inside the new boxes, and a warm-started iteration that fails is repeated cold.
+  static const bool warm_disabled = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
+  const long long key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
+  const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && mu_target == 0.0 && w.warm_key == key;
+  if (try_warm) {
+    w.Ueq.ensure(nu * D8);
+    HIP_CHECK(hipMemcpyAsync(w.Ueq.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
   }
-  if (has_xb) launch_ipm_init_slack(sx, 1.0, s);
-  if (has_ub) launch_ipm_init_slack(su, 1.0, s);
   a.Dx = has_xb ? sx.D : nullptr; a.wx = has_xb ? sx.w : nullptr;
   a.Du = has_ub ? su.D : nullptr; a.wu = has_ub ? su.w : nullptr;
   const double tol = 1e-12;  // complementarity (1e-10 leaves ~3e-7 relative trajectory error on the quadrotor: too close to the 1e-6 bar)
   const int max_iter = 80;
   int status = 1;
-  double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
-                         // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
   // slabs as the fused per-iteration pass sees them (an unbounded slab still takes the step and feeds the
   // gradient pre-pass)
   SlabEx ex, eu;
@@ -507,6 +513,52 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   ex.pw = eu.pw = p->weights; ex.per = (long long)N * x; eu.per = (long long)N * u;
   ex.ref = p->X_ref; ex.prev = p->X_prev; ex.reg = p->reg_x; ex.gm = fast ? w.xm.d() : nullptr; ex.gd = fast ? w.xd.d() : nullptr;
   eu.ref = p->U_ref; eu.prev = p->U_prev; eu.reg = p->reg_u; eu.gm = fast ? w.um.d() : nullptr; eu.gd = fast ? w.ud.d() : nullptr;
+  auto rollout = [&]() {
+    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+    else launch_rollout(a, w.U.d(), w.X.d(), s);
+  };
+  bool remembered = false;  // this solve has stored its early iterate
+  for (int attempt = try_warm ? 0 : 1; attempt < 2; attempt++) {
+  const bool warm = attempt == 0;
+  if (warm) {
+    HIP_CHECK(hipMemcpyAsync(w.U.p, w.warmU.p, nu * D8, hipMemcpyDeviceToDevice, s));
+    rollout();
+    if (has_xb) launch_violation(sx, w.part_max.d(), s);  // the remembered controls must be inside the NEW boxes,
+    if (has_ub) launch_violation(su, w.part_max.d() + B, s);  // and so must the states they roll out to
+    exchange(c, 1);
+    read_scalars(c);
+    if (*c->fail_host || !(c->sc_host->viol_max <= 0.0)) {
+      if (verbose) printf("pmpc_hip: remembered iterate is outside the new boxes: cold start\n");
+      continue;
+    }
+  } else {
+    if (try_warm) {  // a warm attempt ran (or was rejected): back to the equality-only optimum, fresh scalars
+      HIP_CHECK(hipMemcpyAsync(w.U.p, w.Ueq.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+      launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
+                          mu_target, w.part_dev.d());
+      if (!has_ub) rollout();
+    }
+    if (has_ub) {
+      launch_ipm_clip(su, s);
+      rollout();
+    }
+  }
+  if (has_xb) launch_ipm_init_slack(sx, 1.0, s, warm ? 1e-9 : 1e-2);
+  if (has_ub) launch_ipm_init_slack(su, 1.0, s, warm ? 1e-9 : 1e-2);
+  if (warm) {  // multipliers of the remembered iterate (slacks follow from the controls and the new boxes)
+    if (has_xb) {
+      HIP_CHECK(hipMemcpyAsync(sx.ll, w.warm_llx.p, nx * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(sx.lu, w.warm_lux.p, nx * D8, hipMemcpyDeviceToDevice, s));
+    }
+    if (has_ub) {
+      HIP_CHECK(hipMemcpyAsync(su.ll, w.warm_llu.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(su.lu, w.warm_luu.p, nu * D8, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  status = 1;
+  double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
+                         // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
   bool advanced = false;  // this iteration's elementwise pass is already in flight (launched behind the last exchange)
   for (int it = 1; it <= max_iter; it++) {
     // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
@@ -522,6 +574,23 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
              h.nu, h.alpha, h.sigma, h.dev_max);
     inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
     if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
+    if (!remembered && !warm_disabled && mu_target == 0.0 && it > 1 && h.mu <= 0.5) {
+      // (the step that produced this iterate is already applied: the pass behind the last exchange is in flight)
+      w.warmU.ensure(nu * D8);
+      HIP_CHECK(hipMemcpyAsync(w.warmU.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      if (has_ub) {
+        w.warm_llu.ensure(nu * D8); w.warm_luu.ensure(nu * D8);
+        HIP_CHECK(hipMemcpyAsync(w.warm_llu.p, su.ll, nu * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.warm_luu.p, su.lu, nu * D8, hipMemcpyDeviceToDevice, s));
+      }
+      if (has_xb) {
+        w.warm_llx.ensure(nx * D8); w.warm_lux.ensure(nx * D8);
+        HIP_CHECK(hipMemcpyAsync(w.warm_llx.p, sx.ll, nx * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.warm_lux.p, sx.lu, nx * D8, hipMemcpyDeviceToDevice, s));
+      }
+      w.warm_key = key;
+      remembered = true;
+    }
     if (h.mu > mu_peak) mu_peak = h.mu;
     if (mu_target > 0.0) {  // centred AT mu_target: every complementarity product equals it
       if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
@@ -553,6 +622,11 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     }
     read_scalars(c);
   }
+  if (status == 0 || !warm) break;
+  if (verbose) printf("pmpc_hip: warm-started iteration failed (status %d): repeating from a cold start\n", status);
+  w.warm_key = -1;
+  remembered = false;
+  }  // attempt
   if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
   return finish(status);
 }
