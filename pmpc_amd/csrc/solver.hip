@@ -71,7 +71,7 @@ struct Workspace {
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc;  // cone path: particle weights / particle costs
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
-  DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux, Ueq;
+  DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
   SlabBufs sx, su;
@@ -256,7 +256,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
-                   &w.warm_lux, &w.Ueq};
+                   &w.warm_lux};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -417,14 +417,16 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   }
   launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
                       mu_target, w.part_dev.d());
-  launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
-  if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
-  else launch_rollout(a, w.U.d(), w.X.d(), s);
-  a.Dx = a.Du = a.wx = a.wu = nullptr;
-  structured_solve(c, a, true, fast);
-  inf.structured_solves = 1;
-  launch_axpy(w.X.d(), w.dX.d(), 1.0, (long long)nx, s);
-  launch_axpy(w.U.d(), w.dU.d(), 1.0, (long long)nu, s);
+  auto equality_solve = [&]() {
+    launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
+    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+    else launch_rollout(a, w.U.d(), w.X.d(), s);
+    a.Dx = a.Du = a.wx = a.wu = nullptr;
+    structured_solve(c, a, true, fast);
+    inf.structured_solves++;
+    launch_axpy(w.X.d(), w.dX.d(), 1.0, (long long)nx, s);
+    launch_axpy(w.U.d(), w.dU.d(), 1.0, (long long)nu, s);
+  };
 
   auto finish = [&](int status) {
     inf.status = status;
@@ -468,35 +470,38 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   }
   const int B = PMPC_RED_BLOCKS;
 
-  if (!has_xb && !has_ub) {
-    exchange(c, 1);  // only for the failure flag
+  // returns 0: the equality-only optimum satisfies every box (done), 1: boxes violated (interior-point phase), 2: failure
+  auto equality_phase = [&]() -> int {
+    equality_solve();
+    if (has_xb) launch_violation(sx, w.part_max.d(), s);
+    if (has_ub) launch_violation(su, w.part_max.d() + B, s);
+    exchange(c, 1);  // (without boxes: only for the failure flag)
     read_scalars(c);
-    if (*c->fail_host) return finish(2);
-    return finish(0);
+    inf.max_violation = c->sc_host->viol_max;
+    if (*c->fail_host || !(c->sc_host->viol_max == c->sc_host->viol_max)) return 2;
+    if (verbose) printf("pmpc_hip: equality-only optimum, max bound violation %.3e\n", c->sc_host->viol_max);
+    if (!has_xb && !has_ub) return 0;
+    if (c->sc_host->viol_max <= 0.0 && mu_target == 0.0) return 0;  // (a barrier acts on feasible points too)
+    return 1;
+  };
+  // Warm start (see below): when the previous solve of this shape ended in the interior-point phase, go there directly —
+  // the equality-only solve (one factorisation + forward sweep) would only tell us that the boxes are active again; it
+  // is done later if the warm attempt is rejected or fails
+  static const bool warm_disabled = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
+  const long long key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
+  const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && mu_target == 0.0 && (has_xb || has_ub) && w.warm_key == key;
+  bool eq_done = false;
+  if (!try_warm) {
+    const int r = equality_phase();
+    eq_done = true;
+    if (r != 1) return finish(r);
   }
-  if (has_xb) launch_violation(sx, w.part_max.d(), s);
-  if (has_ub) launch_violation(su, w.part_max.d() + B, s);
-  exchange(c, 1);
-  read_scalars(c);
-  inf.max_violation = c->sc_host->viol_max;
-  if (*c->fail_host || !(c->sc_host->viol_max == c->sc_host->viol_max)) return finish(2);
-  if (verbose) printf("pmpc_hip: equality-only optimum, max bound violation %.3e\n", c->sc_host->viol_max);
-  if (c->sc_host->viol_max <= 0.0 && mu_target == 0.0) return finish(0);  // (a barrier acts on feasible points too)
 
   // ---- 2. Mehrotra predictor-corrector on the boxes ----------------------------------------------
   // Warm start: consecutive sub-problems of an SCP / MPC loop are close, so the EARLY iterate of the previous solve of
   // this shape (first iterate with mu <= 0.5: interior, centred, far from its boxes — a late iterate jams) is a better
   // start than the clipped equality-only optimum: 11 -> 9.3 iterations at config D, 11 -> 7.1 on the unicycle.  It is
   // used only if it is strictly inside the new boxes, and a warm-started iteration that fails is repeated cold.
-  static const bool warm_disabled = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
-  const long long key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
-  const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && mu_target == 0.0 && w.warm_key == key;
-  if (try_warm) {
-    w.Ueq.ensure(nu * D8);
-    HIP_CHECK(hipMemcpyAsync(w.Ueq.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
-  }
-  a.Dx = has_xb ? sx.D : nullptr; a.wx = has_xb ? sx.w : nullptr;
-  a.Du = has_ub ? su.D : nullptr; a.wu = has_ub ? su.w : nullptr;
   const double tol = 1e-12;  // complementarity (1e-10 leaves ~3e-7 relative trajectory error on the quadrotor: too close to the 1e-6 bar)
   const int max_iter = 80;
   int status = 1;
@@ -532,18 +537,21 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
       continue;
     }
   } else {
-    if (try_warm) {  // a warm attempt ran (or was rejected): back to the equality-only optimum, fresh scalars
-      HIP_CHECK(hipMemcpyAsync(w.U.p, w.Ueq.p, nu * D8, hipMemcpyDeviceToDevice, s));
+    if (!eq_done) {  // a warm attempt ran (or was rejected): fresh scalars, then the equality-only optimum after all
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
       launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
                           mu_target, w.part_dev.d());
-      if (!has_ub) rollout();
+      const int r = equality_phase();
+      eq_done = true;
+      if (r != 1) return finish(r);
     }
     if (has_ub) {
       launch_ipm_clip(su, s);
       rollout();
     }
   }
+  a.Dx = has_xb ? sx.D : nullptr; a.wx = has_xb ? sx.w : nullptr;
+  a.Du = has_ub ? su.D : nullptr; a.wu = has_ub ? su.w : nullptr;
   if (has_xb) launch_ipm_init_slack(sx, 1.0, s, warm ? 1e-9 : 1e-2);
   if (has_ub) launch_ipm_init_slack(su, 1.0, s, warm ? 1e-9 : 1e-2);
   if (warm) {  // multipliers of the remembered iterate (slacks follow from the controls and the new boxes)
