@@ -125,3 +125,45 @@ def test_weighted_lqp_and_particle_costs(dims, oracle):
                                   slew_um1=kw.get("slew_um1"))
     np.testing.assert_allclose(J, Jo, rtol=1e-12)
     s.close()
+
+
+def test_warm_start_paths_give_the_cold_start_optimum(oracle):
+    """The interior-point warm start across calls: from a related problem, from an UNRELATED one
+    of the same shape, rejected because the remembered controls violate tighter boxes, and switched off — always the
+    oracle's optimum."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    M, N, x, u, Nc = 9, 12, 4, 2, 1
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    s = DeviceSolver(0)
+
+    def solve(args, kw, **extra):
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+        X, U, status = s.lqp_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref),
+                                   U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]),
+                                   symmetric_cost=True, **extra)
+        s.sync()
+        assert status == 0
+        return X.cpu().numpy(), U.cpu().numpy(), dict(s.last_info)
+
+    def check(args, kw, **extra):
+        Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+        X, U, info = solve(args, kw, **extra)
+        assert _rel(X, Xo) < 1e-7 and _rel(U, Uo) < 1e-7
+        return info
+
+    argsA, kwA = rand_problem(np.random.default_rng(1), M, N, x, u, 0.4)
+    check(argsA, kwA)                                   # cold (nothing remembered for this shape yet)
+    argsA2 = tuple(a + 0.02 * np.random.default_rng(2).standard_normal(a.shape) if k in (1, 4, 5) else a for k, a in enumerate(argsA))
+    warm = check(argsA2, kwA)                           # related problem: warm
+    cold = check(argsA2, kwA, cold_start=True)
+    assert warm["structured_solves"] <= cold["structured_solves"]
+    argsB, kwB = rand_problem(np.random.default_rng(3), M, N, x, u, 0.4)
+    check(argsB, kwB)                                   # unrelated problem of the same shape: warm from A2's iterate
+    kwT = dict(kwB, u_l=-0.05 * np.ones((M, N, u)), u_u=0.05 * np.ones((M, N, u)))
+    check(argsB, kwT)                                   # remembered controls lie outside the tighter boxes: rejected, cold
+    check(argsB, kwT)                                   # and warm again
+    s.close()
