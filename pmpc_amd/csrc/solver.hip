@@ -490,10 +490,8 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   static const bool warm_disabled = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
   const long long key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
   const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && mu_target == 0.0 && (has_xb || has_ub) && w.warm_key == key;
-  bool eq_done = false;
   if (!try_warm) {
     const int r = equality_phase();
-    eq_done = true;
     if (r != 1) return finish(r);
   }
 
@@ -504,7 +502,6 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
   // used only if it is strictly inside the new boxes, and a warm-started iteration that fails is repeated cold.
   const double tol = 1e-12;  // complementarity (1e-10 leaves ~3e-7 relative trajectory error on the quadrotor: too close to the 1e-6 bar)
   const int max_iter = 80;
-  int status = 1;
   // slabs as the fused per-iteration pass sees them (an unbounded slab still takes the step and feeds the
   // gradient pre-pass)
   SlabEx ex, eu;
@@ -523,118 +520,119 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     else launch_rollout(a, w.U.d(), w.X.d(), s);
   };
   bool remembered = false;  // this solve has stored its early iterate
-  for (int attempt = try_warm ? 0 : 1; attempt < 2; attempt++) {
-  const bool warm = attempt == 0;
-  if (warm) {
-    HIP_CHECK(hipMemcpyAsync(w.U.p, w.warmU.p, nu * D8, hipMemcpyDeviceToDevice, s));
-    rollout();
-    if (has_xb) launch_violation(sx, w.part_max.d(), s);  // the remembered controls must be inside the NEW boxes,
-    if (has_ub) launch_violation(su, w.part_max.d() + B, s);  // and so must the states they roll out to
-    exchange(c, 1);
-    read_scalars(c);
-    if (*c->fail_host || !(c->sc_host->viol_max <= 0.0)) {
-      if (verbose) printf("pmpc_hip: remembered iterate is outside the new boxes: cold start\n");
-      continue;
-    }
-  } else {
-    if (!eq_done) {  // a warm attempt ran (or was rejected): fresh scalars, then the equality-only optimum after all
-      HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
-      launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
-                          mu_target, w.part_dev.d());
-      const int r = equality_phase();
-      eq_done = true;
-      if (r != 1) return finish(r);
-    }
-    if (has_ub) {
+  // one interior-point run from a warm (remembered iterate) or cold (clipped equality-only optimum) start; returns the
+  // status (0 converged, 1 not converged, 2 numerical failure) or -1: the remembered iterate does not fit the new boxes
+  auto interior_point = [&](const bool warm) -> int {
+    if (warm) {
+      HIP_CHECK(hipMemcpyAsync(w.U.p, w.warmU.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      rollout();
+      if (has_xb) launch_violation(sx, w.part_max.d(), s);  // the remembered controls must be inside the NEW boxes,
+      if (has_ub) launch_violation(su, w.part_max.d() + B, s);  // and so must the states they roll out to
+      exchange(c, 1);
+      read_scalars(c);
+      if (*c->fail_host || !(c->sc_host->viol_max <= 0.0)) {
+        if (verbose) printf("pmpc_hip: remembered iterate is outside the new boxes: cold start\n");
+        return -1;
+      }
+    } else if (has_ub) {
       launch_ipm_clip(su, s);
       rollout();
     }
-  }
-  a.Dx = has_xb ? sx.D : nullptr; a.wx = has_xb ? sx.w : nullptr;
-  a.Du = has_ub ? su.D : nullptr; a.wu = has_ub ? su.w : nullptr;
-  if (has_xb) launch_ipm_init_slack(sx, 1.0, s, warm ? 1e-9 : 1e-2);
-  if (has_ub) launch_ipm_init_slack(su, 1.0, s, warm ? 1e-9 : 1e-2);
-  if (warm) {  // multipliers of the remembered iterate (slacks follow from the controls and the new boxes)
-    if (has_xb) {
-      HIP_CHECK(hipMemcpyAsync(sx.ll, w.warm_llx.p, nx * D8, hipMemcpyDeviceToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(sx.lu, w.warm_lux.p, nx * D8, hipMemcpyDeviceToDevice, s));
+    a.Dx = has_xb ? sx.D : nullptr; a.wx = has_xb ? sx.w : nullptr;
+    a.Du = has_ub ? su.D : nullptr; a.wu = has_ub ? su.w : nullptr;
+    if (has_xb) launch_ipm_init_slack(sx, 1.0, s, warm ? 1e-9 : 1e-2);
+    if (has_ub) launch_ipm_init_slack(su, 1.0, s, warm ? 1e-9 : 1e-2);
+    if (warm) {  // multipliers of the remembered iterate (slacks follow from the controls and the new boxes)
+      if (has_xb) {
+        HIP_CHECK(hipMemcpyAsync(sx.ll, w.warm_llx.p, nx * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(sx.lu, w.warm_lux.p, nx * D8, hipMemcpyDeviceToDevice, s));
+      }
+      if (has_ub) {
+        HIP_CHECK(hipMemcpyAsync(su.ll, w.warm_llu.p, nu * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(su.lu, w.warm_luu.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      }
     }
-    if (has_ub) {
-      HIP_CHECK(hipMemcpyAsync(su.ll, w.warm_llu.p, nu * D8, hipMemcpyDeviceToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(su.lu, w.warm_luu.p, nu * D8, hipMemcpyDeviceToDevice, s));
-    }
-  }
-  status = 1;
-  double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
-                         // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
-  bool advanced = false;  // this iteration's elementwise pass is already in flight (launched behind the last exchange)
-  for (int it = 1; it <= max_iter; it++) {
-    // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
-    if (!advanced) launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
-    advanced = false;
-    if (it == 1 || mu_target > 0.0) {  // later iterates get mu / residual from the corrector's step polynomial (phase 4);
-      exchange(c, 2);                    // barrier mode re-measures them together with the centrality deviation
+    int status = 1;
+    double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
+                           // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
+    bool advanced = false;  // this iteration's elementwise pass is already in flight (launched behind the last exchange)
+    for (int it = 1; it <= max_iter; it++) {
+      // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
+      if (!advanced) launch_ipm_advance(ex, eu, it > 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+      advanced = false;
+      if (it == 1 || mu_target > 0.0) {  // later iterates get mu / residual from the corrector's step polynomial (phase 4);
+        exchange(c, 2);                    // barrier mode re-measures them together with the centrality deviation
+        read_scalars(c);
+      }
+      const IpmScal &h = *c->sc_host;
+      if (verbose)
+        printf("pmpc_hip: ipm it %2d  mu %9.3e  slack_res %9.3e  nu %9.3e  alpha %6.4f  sigma %8.2e  dev %8.2e\n", it, h.mu, h.res_max,
+               h.nu, h.alpha, h.sigma, h.dev_max);
+      inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
+      if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
+      if (!remembered && !warm_disabled && mu_target == 0.0 && it > 1 && h.mu <= 0.5) {
+        // (the step that produced this iterate is already applied: the pass behind the last exchange is in flight)
+        w.warmU.ensure(nu * D8);
+        HIP_CHECK(hipMemcpyAsync(w.warmU.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+        if (has_ub) {
+          w.warm_llu.ensure(nu * D8); w.warm_luu.ensure(nu * D8);
+          HIP_CHECK(hipMemcpyAsync(w.warm_llu.p, su.ll, nu * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.warm_luu.p, su.lu, nu * D8, hipMemcpyDeviceToDevice, s));
+        }
+        if (has_xb) {
+          w.warm_llx.ensure(nx * D8); w.warm_lux.ensure(nx * D8);
+          HIP_CHECK(hipMemcpyAsync(w.warm_llx.p, sx.ll, nx * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.warm_lux.p, sx.lu, nx * D8, hipMemcpyDeviceToDevice, s));
+        }
+        w.warm_key = key;
+        remembered = true;
+      }
+      if (h.mu > mu_peak) mu_peak = h.mu;
+      if (mu_target > 0.0) {  // centred AT mu_target: every complementarity product equals it
+        if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+      } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+      if (it == max_iter) break;
+      // predictor (factorisation) ...
+      structured_solve(c, a, true, fast, /*prep_done=*/true);
+      inf.structured_solves++;
+      if (has_xb) launch_ipm_step(sx, 0, sc, w.part_sum.d(), w.part_cnt.d(), s);
+      if (has_ub) launch_ipm_step(su, 0, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
+      exchange(c, 3);
+      // ... corrector (vector sweeps only, same factorisation; solves for the difference step)
+      if (has_xb) launch_ipm_prepare(sx, 1, sc, nullptr, nullptr, nullptr, s);
+      if (has_ub) launch_ipm_prepare(su, 1, sc, nullptr, nullptr, nullptr, s);
+      a.dX = w.dX2.d(); a.dU = w.dU2.d();  // the sweeps never read-modify-write: step = dz + dz2
+      structured_solve(c, a, false, fast);
+      a.dX = w.dX.d(); a.dU = w.dU.d();
+      sx.dz2 = w.dX2.d(); su.dz2 = w.dU2.d();
+      if (has_xb) launch_ipm_step(sx, 1, sc, w.part_sum.d(), w.part_cnt.d(), s);
+      if (has_ub) launch_ipm_step(su, 1, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
+      sx.dz2 = su.dz2 = nullptr;
+      exchange(c, 4);
+      if (mu_target == 0.0) {
+        // phase 4 already predicts the next iterate's scalars (step polynomial) and publishes them: enqueue the next
+        // elementwise pass BEHIND it before polling — it has to run whether or not that iterate turns out to be converged
+        // (it applies the step), and it keeps the GPU busy while the host decides and enqueues the next factor sweep
+        launch_ipm_advance(ex, eu, 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+        advanced = true;
+      }
       read_scalars(c);
     }
-    const IpmScal &h = *c->sc_host;
-    if (verbose)
-      printf("pmpc_hip: ipm it %2d  mu %9.3e  slack_res %9.3e  nu %9.3e  alpha %6.4f  sigma %8.2e  dev %8.2e\n", it, h.mu, h.res_max,
-             h.nu, h.alpha, h.sigma, h.dev_max);
-    inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
-    if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
-    if (!remembered && !warm_disabled && mu_target == 0.0 && it > 1 && h.mu <= 0.5) {
-      // (the step that produced this iterate is already applied: the pass behind the last exchange is in flight)
-      w.warmU.ensure(nu * D8);
-      HIP_CHECK(hipMemcpyAsync(w.warmU.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
-      if (has_ub) {
-        w.warm_llu.ensure(nu * D8); w.warm_luu.ensure(nu * D8);
-        HIP_CHECK(hipMemcpyAsync(w.warm_llu.p, su.ll, nu * D8, hipMemcpyDeviceToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(w.warm_luu.p, su.lu, nu * D8, hipMemcpyDeviceToDevice, s));
-      }
-      if (has_xb) {
-        w.warm_llx.ensure(nx * D8); w.warm_lux.ensure(nx * D8);
-        HIP_CHECK(hipMemcpyAsync(w.warm_llx.p, sx.ll, nx * D8, hipMemcpyDeviceToDevice, s));
-        HIP_CHECK(hipMemcpyAsync(w.warm_lux.p, sx.lu, nx * D8, hipMemcpyDeviceToDevice, s));
-      }
-      w.warm_key = key;
-      remembered = true;
-    }
-    if (h.mu > mu_peak) mu_peak = h.mu;
-    if (mu_target > 0.0) {  // centred AT mu_target: every complementarity product equals it
-      if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
-    } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
-    if (it == max_iter) break;
-    // predictor (factorisation) ...
-    structured_solve(c, a, true, fast, /*prep_done=*/true);
-    inf.structured_solves++;
-    if (has_xb) launch_ipm_step(sx, 0, sc, w.part_sum.d(), w.part_cnt.d(), s);
-    if (has_ub) launch_ipm_step(su, 0, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
-    exchange(c, 3);
-    // ... corrector (vector sweeps only, same factorisation; solves for the difference step)
-    if (has_xb) launch_ipm_prepare(sx, 1, sc, nullptr, nullptr, nullptr, s);
-    if (has_ub) launch_ipm_prepare(su, 1, sc, nullptr, nullptr, nullptr, s);
-    a.dX = w.dX2.d(); a.dU = w.dU2.d();  // the sweeps never read-modify-write: step = dz + dz2
-    structured_solve(c, a, false, fast);
-    a.dX = w.dX.d(); a.dU = w.dU.d();
-    sx.dz2 = w.dX2.d(); su.dz2 = w.dU2.d();
-    if (has_xb) launch_ipm_step(sx, 1, sc, w.part_sum.d(), w.part_cnt.d(), s);
-    if (has_ub) launch_ipm_step(su, 1, sc, w.part_sum.d() + B, w.part_cnt.d() + B, s);
-    sx.dz2 = su.dz2 = nullptr;
-    exchange(c, 4);
-    if (mu_target == 0.0) {
-      // phase 4 already predicts the next iterate's scalars (step polynomial) and publishes them: enqueue the next
-      // elementwise pass BEHIND it before polling — it has to run whether or not that iterate turns out to be converged
-      // (it applies the step), and it keeps the GPU busy while the host decides and enqueues the next factor sweep
-      launch_ipm_advance(ex, eu, 1, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
-      advanced = true;
-    }
-    read_scalars(c);
+    return status;
+  };
+
+  int status = try_warm ? interior_point(true) : interior_point(false);
+  if (try_warm && status != 0) {  // rejected or failed: fresh scalars, the equality-only optimum after all, cold start
+    if (verbose && status > 0) printf("pmpc_hip: warm-started iteration failed (status %d): repeating from a cold start\n", status);
+    w.warm_key = -1;
+    remembered = false;
+    HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+    launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
+                        mu_target, w.part_dev.d());
+    const int r = equality_phase();
+    if (r != 1) return finish(r);
+    status = interior_point(false);
   }
-  if (status == 0 || !warm) break;
-  if (verbose) printf("pmpc_hip: warm-started iteration failed (status %d): repeating from a cold start\n", status);
-  w.warm_key = -1;
-  remembered = false;
-  }  // attempt
   if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
   return finish(status);
 }
