@@ -202,7 +202,7 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                    "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
-                                   if args.model == "quadrotor" and M_total == 4096 else
+                                   if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 else
                                    f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u",
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",
                        "ipm_iters_per_step": float(np.mean(ipm_its)), "riccati_factorisations_per_step": float(np.mean(solves)),
