@@ -98,6 +98,15 @@ typedef struct pmpc_problem {
   /* > 0: log-barrier smoothing of the boxes (the cone path's smooth_cstr = "logbarrier", cone_utils.jl:173-232): the
    * hard boxes are replaced by -barrier_mu * sum log(slack) in the objective, barrier_mu = 1/smooth_alpha; 0 = hard */
   double barrier_mu;
+  /* optional second-order cone on the controls of EVERY (particle, stage):  || W u + w0 ||_2 <= v'u + v0  — the
+   * structured case of the reference's pyjulia-only `extra_cstrs` (README.md:219-239; config E's thrust cones, SURVEY.md
+   * section 8d), which cannot cross its C ABI.  soc_q = rows of W (0 = no cone); all four are DEVICE pointers, W (q x udim)
+   * row-major.  soc_u_interior (device, udim): a control strictly inside the boxes and the cone (e.g. hover); the
+   * path-following method starts from it on every stage.  Used by pmpc_lsoc_solve_device only. */
+  size_t soc_q;
+  const double *soc_W, *soc_w0, *soc_v;
+  double soc_v0;
+  const double *soc_u_interior;
 } pmpc_problem;
 
 typedef struct pmpc_info {
@@ -130,6 +139,12 @@ int pmpc_lqp_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, pmpc_info *in
  * above the threshold particle(s) — solved as a short sequence of weighted QPs.  smooth_alpha = NaN: hard boxes.
  * Single rank only (the particle ranking is not exchanged across ranks yet). */
 int pmpc_lcone_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, double smooth_alpha, pmpc_info *info, int verbose);
+
+/* The QP of pmpc_lqp_solve_device plus the stage-wise control cones of pmpc_problem.soc_* (control boxes allowed, state
+ * boxes / weights / slew not): feasible primal-dual path following with Nesterov-Todd scaling on the same Riccati
+ * kernels, complementarity driven to 1e-12.  Returns status (0 ok, 1 not converged, 2 numerical failure, 3 infeasible
+ * start: soc_u_interior is not strictly inside the boxes and the cone). */
+int pmpc_lsoc_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, pmpc_info *info, int verbose);
 
 /* J_out[i] (device, M) = J_i(X, U): per-particle cost of qp_utils.jl:60-162 (1/2 z'Pz + q'z + r), unweighted. */
 int pmpc_particle_costs_device(pmpc_ctx *ctx, const pmpc_problem *prob, const double *X, const double *U, double *J_out);

@@ -555,3 +555,83 @@ def reference_shaped_solve_abi(*abi_args, eps=1e-3):
     t2 = time.perf_counter()
     X, U = split_vars(qp, z)
     return X, U, dict(assemble_s=t1 - t0, solve_s=t2 - t1, total_s=time.perf_counter() - t0, **info)
+
+
+# -------------------------------------------------------------------------------------------------
+# stage-wise second-order cones on the controls (config E's thrust cones; extension beyond the reference's C ABI)
+# -------------------------------------------------------------------------------------------------
+def lsoc_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, u_l=None, u_u=None, soc_W=None,
+                  soc_w0=None, soc_v=None, soc_v0=0.0, u_interior=None, mu_final=1e-13, return_info=False):
+    """The joint QP of `lqp_solve_py` with, on every (particle, stage), the cone ||W u + w0||_2 <= v'u + v0 on that
+    stage's controls (consensus stages: once, on the shared control) — the structured case of the reference's
+    `extra_cstrs` SOC tuples (README.md:219-239, PMPC.jl/src/main.jl:293-316).  Independent of the device code in its
+    linear algebra: primal log-barrier path following on the SPARSE JOINT KKT system, mu -> `mu_final`, Newton to a
+    decrement below 1e-12 at every mu.  Returns X (M,N,x), U (M,N,u)."""
+    f = _f64(f)
+    M, N, xdim = f.shape
+    udim = np.shape(fu)[-1]
+    nan = np.full(1, np.nan)
+    bx = lambda z: nan if z is None else np.broadcast_to(_f64(z), (M, N, udim)).copy()
+    qp = assemble_abi(xdim, udim, N, M, Nc, f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev), to_abi_mat(Q), to_abi_mat(R),
+                      _f64(X_ref), _f64(U_ref), nan, nan, bx(u_l), bx(u_u), float(reg_x), float(reg_u), nan, nan, nan)
+    P, q, A, b, G, l, u = effective_P(qp.P), qp.q, qp.A, qp.b, qp.G, qp.l, qp.u
+    n = P.shape[0]
+    Ncc = qp.Nc
+    Nf = N - Ncc
+    ncu = Ncc * udim + M * Nf * udim  # control variables come first (lqp_utils.jl:12-15)
+    W, w0, v = _f64(soc_W).reshape(-1, udim), _f64(soc_w0).reshape(-1), _f64(soc_v).reshape(udim)
+    cones = np.arange(ncu).reshape(-1, udim)  # one cone per control block: Ncc shared blocks, then M*Nf free ones
+    z = np.zeros(n)
+    z[:ncu] = np.tile(_f64(u_interior).reshape(udim), ncu // udim)
+    z[ncu:] = spla.spsolve(A[:, ncu:].tocsc(), b - A[:, :ncu] @ z[:ncu])
+    Gt = G.T.tocsc()
+    ml, mh = np.isfinite(l), np.isfinite(u)
+    S = W.T @ W
+    vvT = np.outer(v, v)
+
+    def barrier(z):
+        Gz = G @ z
+        sl, su = np.where(ml, Gz - np.where(ml, l, 0.0), 1.0), np.where(mh, np.where(mh, u, 0.0) - Gz, 1.0)
+        Uc = z[cones]                      # (ncones, udim)
+        a = Uc @ v + soc_v0
+        bb = Uc @ W.T + w0
+        d = a * a - np.sum(bb * bb, -1)
+        if np.any(sl <= 0) or np.any(su <= 0) or np.any(a <= 0) or np.any(d <= 0):
+            return None
+        c = a[:, None] * v[None, :] - bb @ W            # (ncones, udim): grad psi / 2
+        g = Gt @ (-np.where(ml, 1.0 / sl, 0.0) + np.where(mh, 1.0 / su, 0.0))
+        np.add.at(g, cones.ravel(), (-2.0 * c / d[:, None]).ravel())
+        Hd = Gt @ sp.diags(np.where(ml, 1.0 / sl ** 2, 0.0) + np.where(mh, 1.0 / su ** 2, 0.0)) @ G
+        blocks = 4.0 * c[:, :, None] * c[:, None, :] / (d * d)[:, None, None] - 2.0 * (vvT - S)[None] / d[:, None, None]
+        rows = np.repeat(cones, udim, axis=1).ravel()
+        cols = np.tile(cones, (1, udim)).ravel()
+        Hc = sp.coo_matrix((blocks.ravel(), (rows, cols)), shape=(n, n)).tocsc()
+        val = -np.sum(np.log(sl[ml])) - np.sum(np.log(su[mh])) - np.sum(np.log(d))
+        return val, g, (Hd + Hc).tocsc()
+
+    mu, newton = 1.0, 0
+    while True:
+        for _ in range(100):
+            val, g, H = barrier(z)
+            grad = P @ z + q + mu * g
+            dz, dy, _ = _kkt_solve((P + mu * H).tocsc(), A, sp.csc_matrix((0, n)), -grad, np.zeros(A.shape[0]), np.zeros(0))
+            dec = float(-grad @ dz)
+            if dec <= 1e-12 * max(1.0, mu):
+                break
+            t = 1.0
+            m0 = 0.5 * z @ (P @ z) + q @ z + mu * val
+            while True:
+                zt = z + t * dz
+                bt = barrier(zt)
+                if bt is not None and 0.5 * zt @ (P @ zt) + q @ zt + mu * bt[0] <= m0 - 1e-4 * t * dec:
+                    break
+                t *= 0.5
+                if t < 1e-14:
+                    raise RuntimeError("cone oracle: line search failed")
+            z = zt
+            newton += 1
+        if mu <= mu_final:
+            break
+        mu = max(0.2 * mu, mu_final)
+    X, U = split_vars(qp, z)
+    return (X, U, dict(newton=newton, mu=mu)) if return_info else (X, U)

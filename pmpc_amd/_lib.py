@@ -23,7 +23,7 @@ HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, CO
 ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
-    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device",
+    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device",
 ]
 
 
@@ -33,7 +33,8 @@ class PmpcProblem(ctypes.Structure):
         + [("Nc", ctypes.c_longlong), ("flags", ctypes.c_uint), ("reg_x", ctypes.c_double), ("reg_u", ctypes.c_double)]
         + [(k, ctypes.c_void_p) for k in ("x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref",
                                           "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out", "weights")]
-        + [("barrier_mu", ctypes.c_double)]
+        + [("barrier_mu", ctypes.c_double), ("soc_q", ctypes.c_size_t), ("soc_W", ctypes.c_void_p), ("soc_w0", ctypes.c_void_p),
+           ("soc_v", ctypes.c_void_p), ("soc_v0", ctypes.c_double), ("soc_u_interior", ctypes.c_void_p)]
     )
 
 
@@ -70,6 +71,8 @@ def load():
     lib.pmpc_lqp_solve_device.restype = ctypes.c_int
     lib.pmpc_lcone_solve_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), dbl, ctypes.POINTER(PmpcInfo), ctypes.c_int]
     lib.pmpc_lcone_solve_device.restype = ctypes.c_int
+    lib.pmpc_lsoc_solve_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), ctypes.POINTER(PmpcInfo), ctypes.c_int]
+    lib.pmpc_lsoc_solve_device.restype = ctypes.c_int
     lib.pmpc_particle_costs_device.argtypes = [vp, ctypes.POINTER(PmpcProblem), vp, vp, vp]
     lib.pmpc_particle_costs_device.restype = ctypes.c_int
     lib.pmpc_comm_unique_id.argtypes = [vp]

@@ -209,9 +209,11 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   const bool fgu = L.cu && (FACTOR || HUB);
   const double *pgu = fgu ? gu_src + (pbase + N - 1) * UD + L.cb : Z;
   const int sgu = fgu ? -(int)D8 * UD : 0;
-  const bool fDu = L.cu && FACTOR && HUB && g == L.cb;
-  const double *pDu = fDu ? a.Du + (pbase + N - 1) * UD + L.cb : Z;
-  const int sDu = fDu ? -(int)D8 * UD : 0;
+  // Du: one diagonal entry per control (lanes (XP + b, b)), or — du_full — a full u x u block laid out like R
+  const bool fDu = L.cu && FACTOR && HUB && (a.du_full ? gu : g == L.cb);
+  const int eDu = a.du_full ? UD * UD : UD;
+  const double *pDu = fDu ? a.Du + (pbase + N - 1) * eDu + (a.du_full ? g + UD * L.cb : L.cb) : Z;
+  const int sDu = fDu ? -(int)D8 * eDu : 0;
   // state-side gradient (xd resp. wx) and Dx on the diagonal lanes
   const double *gx_src = FACTOR ? a.xd : a.wx;
   const bool fgx = L.cxv && (FACTOR || HXB);
@@ -375,7 +377,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
 #pragma unroll
         for (int r = 0; r < KS; r++) H[r] = fma(pwt, Qc[r], dmask[r] ? dd : 0.0);
       }
-      H[KS] = fma(pwt, Rc, umask ? regu + (cons ? 0.0 : Du_c) : 0.0);
+      H[KS] = fma(pwt, Rc, (umask ? regu : 0.0) + (cons ? 0.0 : Du_c));  // Du_c is zero on lanes without an entry
       v4d G = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
@@ -390,7 +392,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       if (FACTOR) {
         // Hc_part[i][(j UD + p) + nc (j UD + q)] = Huu[p][q] lives in lane (XP + q, p), register KS
         double v = H[KS];
-        if (own0 && HUB && umask) v += Du_c;
+        if (own0 && HUB) v += Du_c;
         const int nc = Nc * UD;
         if (L.cu && gu) a.Hc_part[(size_t)i * nc * nc + (size_t)(j * UD + g) + (size_t)nc * (j * UD + L.cb)] = v;
         *pRec = (L.cxv && gu) ? H[KS] : 0.0;

@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
         if (r >= n && c >= n) {
           int rr = r - n, cc = c - n;
           acc += symu(L.Rr, u, rr, cc);
-          if (rr == cc) acc += regu + slew_diag(sl0, sl, j, N) + (a.Du ? a.Du[vofs(i, j, N, u) + rr] : 0.0);
+          if (rr == cc) acc += regu + slew_diag(sl0, sl, j, N) + ((a.Du && !a.du_full) ? a.Du[vofs(i, j, N, u) + rr] : 0.0);
+          if (a.Du && a.du_full) acc += a.Du[mofs(i, j, N, u, u) + rr + u * cc];
         }
         if (w && j > 0) {  // slew cross term -s u_j' u_{j-1}
           if (r >= n && c >= x && c < n && r - n == c - x) acc -= sl;
@@ -333,9 +334,10 @@ __global__ void __launch_bounds__(WV) k_bwd_generic(LQArgs a) {
         if (r / u == j && c / u == j) {
           int rr = r - j * u, cc = c - j * u;
           acc += symu(L.Rr, u, rr, cc);
+          if (i == 0 && a.owner && a.Du && a.du_full) acc += a.Du[mofs(0, j, N, u, u) + rr + u * cc];
           if (rr == cc) {
             acc += regu + slew_diag(sl0, sl, j, N);
-            if (i == 0 && a.owner && a.Du) acc += a.Du[vofs(0, j, N, u) + rr];
+            if (i == 0 && a.owner && a.Du && !a.du_full) acc += a.Du[vofs(0, j, N, u) + rr];
           }
         }
         if (j > 0 && (r % u) == (c % u) && ((r / u == j && c / u == j - 1) || (r / u == j - 1 && c / u == j))) acc -= sl;

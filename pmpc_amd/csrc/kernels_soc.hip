@@ -1,0 +1,267 @@
+// kernels_soc.hip — elementwise kernels of the stage-wise second-order-cone extension (config E's thrust cones).
+//
+// The reference reaches user cones only through its pyjulia-only `extra_cstrs` tuples over the joint variable vector
+// (README.md:219-239, PMPC.jl/src/main.jl:293-316); they cannot cross its C ABI.  The extension
+// here covers the structured case those tuples are used for in MPC practice — one cone per (particle, stage) on that
+// stage's controls,   || W u + w0 ||_2 <= v'u + v0,   shared W, w0, v, v0 —  next to the control boxes.
+//
+// Method: feasible primal-dual path following with Nesterov-Todd scaling.  Per stage the constraints are
+//     s = A u + c in K,   K = R+ (each finite box side: u - lo, hi - u)  x  Q^{q+1} (s = (v'u + v0, W u + w0)),
+// with duals z in K and s o z = mu e.  Eliminating dz = sigma mu s^-1 - z - W_nt^-2 ds (ds = A du) from the Newton system
+// leaves the SAME structured LQ solve with
+//     control Hessian  += A' W_nt^-2 A            gradient shift  wu = -sigma mu A' s^-1,
+// where for a box side W_nt^-2 = z/s and for the cone W_nt^-2 = (2 (J wb)(J wb)' - J) / eta^2 (wb the NT scaling point, eta^2 =
+// sqrt(s'Js / z'Jz), J = diag(1, -I)).  Both ride on the Riccati kernels' interior-point inputs: the Hessian block goes in as
+// a FULL u x u `Du` (LQArgs.du_full; the box path uses a diagonal there), the shift as `wu`.  (Folding the block into the cost
+// block R instead would make the kernels form R_eff (u - u_ref) and cancel 1e12-sized terms against the shift.)  The slacks are variables of their own (s += alpha ds, residual rp = A u + c - s
+// carried in the Newton system: ds = A du + rp, wu += A' W_nt^-2 rp): recomputing hi - u at slack ~ mu/z ~ 1e-11 would tie
+// their positivity to the last bits of u and stall the iteration near mu = 1e-10.  The step length keeps s, z inside K.
+// Consensus stages carry ONE shared control: its constraints are counted once, on the owner rank's particle 0.
+#include "pmpc_dev.h"
+
+namespace {
+
+constexpr int TB = 256, UMAX = 8, QMAX = 4;
+
+__device__ __forceinline__ bool soc_counts(const SocArgs &a, int i, int j) { return j >= a.Nc || (i == 0 && a.owner); }
+
+// cone slack s = (v'u + v0, W u + w0) of one stage
+__device__ __forceinline__ void cone_slack(const SocArgs &a, const double *u, double *s) {
+  double s0 = a.v0;
+  for (int r = 0; r < a.u; r++) s0 += a.v[r] * u[r];
+  s[0] = s0;
+  for (int p = 0; p < a.q; p++) {
+    double bp = a.w0[p];
+    for (int r = 0; r < a.u; r++) bp += a.W[p * a.u + r] * u[r];
+    s[1 + p] = bp;
+  }
+}
+__device__ __forceinline__ double jdot(const double *x, const double *y, int q) {  // x'Jy
+  double d = x[0] * y[0];
+  for (int p = 1; p <= q; p++) d -= x[p] * y[p];
+  return d;
+}
+// largest t in (0, cap] with x + t d strictly inside Q (x inside)
+__device__ __forceinline__ double cone_ratio(const double *x, const double *d, int q, double cap) {
+  double al = cap;
+  if (d[0] < 0.0) al = fmin(al, x[0] / -d[0]);
+  const double A0 = jdot(x, x, q), A1 = 2.0 * jdot(x, d, q), A2 = jdot(d, d, q);
+  if (A2 < 0.0 || A1 < 0.0) {
+    const double disc = A1 * A1 - 4.0 * A2 * A0;
+    if (disc >= 0.0) {
+      const double sq = sqrt(disc), t1 = 2.0 * A0 / (-A1 + sq), t2 = 2.0 * A0 / (-A1 - sq);
+      if (t1 > 0.0) al = fmin(al, t1);
+      if (t2 > 0.0) al = fmin(al, t2);
+    }
+  }
+  return al;
+}
+
+// MODE 0: s = A u + c, z = mu s^-1 (centred start);  MODE 1: Hadd, wu from (U, s, z);  sums s'z and counts either way
+template <int MODE>
+__global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum, double *part_cnt) {
+  __shared__ double sh[TB];
+  const long long tot = (long long)a.M * a.N;
+  double comp = 0.0, cnt = 0.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
+    const int i = (int)(k / a.N), j = (int)(k % a.N), u = a.u, q = a.q;
+    const double *U = a.U + k * u;
+    double *Ha = a.Hadd + k * u * u, *wu = a.wu + k * u;
+    if (!soc_counts(a, i, j)) {
+      if (MODE == 1) {
+        for (int e = 0; e < u * u; e++) Ha[e] = 0.0;
+        for (int r = 0; r < u; r++) wu[r] = 0.0;
+      }
+      continue;
+    }
+    double uu[UMAX], g[UMAX], H[UMAX][UMAX];
+    for (int r = 0; r < u; r++) {
+      uu[r] = U[r];
+      g[r] = 0.0;
+      for (int t = 0; t < u; t++) H[r][t] = 0.0;
+    }
+    bool ok = true;
+    if (a.lo) {
+      for (int r = 0; r < u; r++) {
+        const double lo = a.lo[k * u + r], hi = a.hi[k * u + r];
+        if (isfinite(lo)) {
+          if (MODE == 0) { a.sl[k * u + r] = uu[r] - lo; a.zl[k * u + r] = a.mu / (uu[r] - lo); }
+          const double s = a.sl[k * u + r], z = a.zl[k * u + r], rp = (uu[r] - lo) - s, d = z / s;
+          ok &= (s > 0.0) && (z > 0.0);
+          comp += s * z; cnt += 1.0;
+          g[r] += -a.sigmu / s + d * rp; H[r][r] += d;   // A = +e_r
+        }
+        if (isfinite(hi)) {
+          if (MODE == 0) { a.su[k * u + r] = hi - uu[r]; a.zu[k * u + r] = a.mu / (hi - uu[r]); }
+          const double s = a.su[k * u + r], z = a.zu[k * u + r], rp = (hi - uu[r]) - s, d = z / s;
+          ok &= (s > 0.0) && (z > 0.0);
+          comp += s * z; cnt += 1.0;
+          g[r] -= -a.sigmu / s + d * rp; H[r][r] += d;   // A = -e_r
+        }
+      }
+    }
+    if (q > 0) {
+      double s[1 + QMAX], z[1 + QMAX], wb[1 + QMAX], rp[1 + QMAX];
+      double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
+      cone_slack(a, uu, rp);  // A u + c
+      if (MODE == 0) {  // s = A u + c,  z = mu s^-1 = mu J s / (s'Js)
+        const double ss0 = jdot(rp, rp, q);
+        for (int p = 0; p <= q; p++) sc[p] = rp[p];
+        zc[0] = a.mu * rp[0] / ss0;
+        for (int p = 1; p <= q; p++) zc[p] = -a.mu * rp[p] / ss0;
+      }
+      for (int p = 0; p <= q; p++) { s[p] = sc[p]; rp[p] -= s[p]; z[p] = zc[p]; }
+      const double ss = jdot(s, s, q);
+      ok &= (s[0] > 0.0) && (ss > 0.0);
+      const double zz = jdot(z, z, q);
+      ok &= (z[0] > 0.0) && (zz > 0.0);
+      double sz = 0.0;
+      for (int p = 0; p <= q; p++) sz += s[p] * z[p];
+      comp += sz; cnt += 1.0;
+      // NT scaling point: sb = s/sqrt(ss), zb = z/sqrt(zz), gam = sqrt((1 + sb'zb)/2), wb = (sb + J zb)/(2 gam)
+      const double rs = 1.0 / sqrt(ss), rz = 1.0 / sqrt(zz);
+      double dotb = 0.0;
+      for (int p = 0; p <= q; p++) dotb += s[p] * z[p] * rs * rz;
+      const double gam = sqrt(0.5 * (1.0 + dotb)), ig = 0.5 / gam;
+      wb[0] = (s[0] * rs + z[0] * rz) * ig;
+      for (int p = 1; p <= q; p++) wb[p] = (s[p] * rs - z[p] * rz) * ig;
+      const double ieta2 = sqrt(zz / ss);  // 1 / eta^2
+      // W^-2 = ieta2 (2 (J wb)(J wb)' - J);  rows of A: a_0 = v, a_p = W[p-1, :]
+      // s^-1 = J s / ss
+      double Jw[1 + QMAX], sinv[1 + QMAX];
+      Jw[0] = wb[0]; sinv[0] = s[0] / ss;
+      for (int p = 1; p <= q; p++) { Jw[p] = -wb[p]; sinv[p] = -s[p] / ss; }
+      // W^-2 rp = ieta2 (2 (Jwb)(Jwb)'rp - J rp)
+      double jwrp = 0.0, w2rp[1 + QMAX];
+      for (int p = 0; p <= q; p++) jwrp += Jw[p] * rp[p];
+      w2rp[0] = ieta2 * (2.0 * Jw[0] * jwrp - rp[0]);
+      for (int p = 1; p <= q; p++) w2rp[p] = ieta2 * (2.0 * Jw[p] * jwrp + rp[p]);
+      double Aw[UMAX];  // A' (J wb)
+      for (int r = 0; r < u; r++) {
+        double t = a.v[r] * Jw[0], gs = a.v[r] * (-a.sigmu * sinv[0] + w2rp[0]);
+        for (int p = 1; p <= q; p++) {
+          t += a.W[(p - 1) * u + r] * Jw[p];
+          gs += a.W[(p - 1) * u + r] * (-a.sigmu * sinv[p] + w2rp[p]);
+        }
+        Aw[r] = t;
+        g[r] += gs;
+      }
+      for (int r = 0; r < u; r++)
+        for (int t = 0; t < u; t++) {
+          double AJA = a.v[r] * a.v[t];  // A' J A
+          for (int p = 1; p <= q; p++) AJA -= a.W[(p - 1) * u + r] * a.W[(p - 1) * u + t];
+          H[r][t] += ieta2 * (2.0 * Aw[r] * Aw[t] - AJA);
+        }
+    }
+    if (!ok) *a.fail = 3;
+    if (MODE == 1) {
+      for (int r = 0; r < u; r++) {
+        wu[r] = g[r];
+        for (int t = 0; t < u; t++) Ha[r + u * t] = H[r][t];
+      }
+    }
+  }
+  sh[threadIdx.x] = comp;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part_sum[blockIdx.x] = sh[0];
+  __syncthreads();
+  sh[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) part_cnt[blockIdx.x] = sh[0];
+}
+
+// steps ds = A du + rp, dz = sigma mu s^-1 - z - W^-2 ds, stored; largest alpha in (0, 2] keeping s and z inside K
+__global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *amin_bits) {
+  __shared__ double sh[TB];
+  const long long tot = (long long)a.M * a.N;
+  double al = 2.0;  // (the host takes min(1, 0.99 * this): a step that would end ON a boundary just beyond 1 is shortened too)
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
+    const int i = (int)(k / a.N), j = (int)(k % a.N), u = a.u, q = a.q;
+    const double *U = a.U + k * u, *dU = a.dU + k * u;
+    const bool counts = soc_counts(a, i, j);  // (the copies of a shared control take the same step: nothing to test)
+    if (a.lo) {
+      for (int r = 0; r < u; r++) {
+        const double lo = a.lo[k * u + r], hi = a.hi[k * u + r], d = dU[r];
+        if (isfinite(lo) && counts) {
+          const double s = a.sl[k * u + r], z = a.zl[k * u + r], ds = d + ((U[r] - lo) - s);
+          const double dz = a.sigmu / s - z - (z / s) * ds;
+          a.dsl[k * u + r] = ds; a.dzl[k * u + r] = dz;
+          if (ds < 0.0) al = fmin(al, s / -ds);
+          if (dz < 0.0) al = fmin(al, z / -dz);
+        }
+        if (isfinite(hi) && counts) {
+          const double s = a.su[k * u + r], z = a.zu[k * u + r], ds = -d + ((hi - U[r]) - s);
+          const double dz = a.sigmu / s - z - (z / s) * ds;
+          a.dsu[k * u + r] = ds; a.dzu[k * u + r] = dz;
+          if (ds < 0.0) al = fmin(al, s / -ds);
+          if (dz < 0.0) al = fmin(al, z / -dz);
+        }
+      }
+    }
+    if (q > 0 && counts) {
+      double uu[UMAX], du[UMAX], s[1 + QMAX], ds[1 + QMAX], z[1 + QMAX], dz[1 + QMAX], wb[1 + QMAX];
+      for (int r = 0; r < u; r++) { uu[r] = U[r]; du[r] = dU[r]; }
+      const double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
+      cone_slack(a, uu, ds);  // A u + c
+      for (int p = 0; p <= q; p++) { s[p] = sc[p]; ds[p] -= s[p]; z[p] = zc[p]; }  // ds = rp so far
+      for (int r = 0; r < u; r++) ds[0] += a.v[r] * du[r];
+      for (int p = 1; p <= q; p++)
+        for (int r = 0; r < u; r++) ds[p] += a.W[(p - 1) * u + r] * du[r];
+      const double ss = jdot(s, s, q), zz = jdot(z, z, q), rs = 1.0 / sqrt(ss), rz = 1.0 / sqrt(zz);
+      double dotb = 0.0;
+      for (int p = 0; p <= q; p++) dotb += s[p] * z[p] * rs * rz;
+      const double gam = sqrt(0.5 * (1.0 + dotb)), ig = 0.5 / gam, ieta2 = sqrt(zz / ss);
+      wb[0] = (s[0] * rs + z[0] * rz) * ig;
+      for (int p = 1; p <= q; p++) wb[p] = (s[p] * rs - z[p] * rz) * ig;
+      // W^-2 ds = ieta2 (2 (Jwb)(Jwb)'ds - J ds)
+      double jwds = wb[0] * ds[0];
+      for (int p = 1; p <= q; p++) jwds -= wb[p] * ds[p];
+      dz[0] = a.sigmu * s[0] / ss - z[0] - ieta2 * (2.0 * wb[0] * jwds - ds[0]);
+      for (int p = 1; p <= q; p++) dz[p] = -a.sigmu * s[p] / ss - z[p] - ieta2 * (2.0 * (-wb[p]) * jwds + ds[p]);
+      double *dsc = a.dsc + k * (q + 1), *dzc = a.dzc + k * (q + 1);
+      for (int p = 0; p <= q; p++) { dsc[p] = ds[p]; dzc[p] = dz[p]; }
+      al = fmin(al, cone_ratio(s, ds, q, 2.0));
+      al = fmin(al, cone_ratio(z, dz, q, 2.0));
+    }
+  }
+  sh[threadIdx.x] = al;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = fmin(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = sh[0];
+    if (!(v >= 0.0)) v = 0.0;
+    atomicMin(amin_bits, (unsigned long long)__double_as_longlong(v));
+  }
+}
+
+__global__ void k_soc_fill_u(double *U, const double *u0, long long tot, int u) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) U[k] = u0[k % u];
+}
+
+}  // namespace
+
+static unsigned soc_grid(const SocArgs &a) {
+  long long b = ((long long)a.M * a.N + TB - 1) / TB;
+  if (b > PMPC_RED_BLOCKS) b = PMPC_RED_BLOCKS;
+  return (unsigned)b;
+}
+// every launch runs exactly PMPC_RED_BLOCKS-bounded grids and fills part_sum / part_cnt [0, grid): returns the grid size
+int launch_soc_prepare(const SocArgs &a, bool init_duals, double *part_sum, double *part_cnt, hipStream_t s) {
+  const unsigned g = soc_grid(a);
+  if (init_duals) hipLaunchKernelGGL(k_soc_prepare<0>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
+  else hipLaunchKernelGGL(k_soc_prepare<1>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
+  return (int)g;
+}
+void launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, hipStream_t s) {
+  hipLaunchKernelGGL(k_soc_step, dim3(soc_grid(a)), dim3(TB), 0, s, a, amin_bits);
+}
+void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s) {
+  long long b = (tot + TB - 1) / TB;
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(k_soc_fill_u, dim3((unsigned)b), dim3(TB), 0, s, U, u0, tot, u);
+}

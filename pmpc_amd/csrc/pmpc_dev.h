@@ -34,6 +34,7 @@ struct LQArgs {
   const double *X, *U;
   // IPM terms: extra Hessian diagonals / gradient shifts (null when absent)
   const double *Dx, *Du, *wx, *wu;
+  int du_full;  // Du holds full (u x u) column-major blocks per (particle, stage) instead of diagonals (stage-cone extension)
   // fast path only: gradient pre-pass outputs (launch_grad_prep), same shapes as X / U
   //   xm = pw (X - X_ref), xd = pw reg_x (X - X_prev) + wx, um = pw (U - U_ref), ud = pw reg_u (U - U_prev) + wu (free stages;
   //   consensus stages: wu only on the owner's particle 0)
@@ -138,6 +139,23 @@ void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const i
                          const double *part_sum, const double *part_cnt, const double *part_max, int nblocks, hipStream_t s,
                          double mu_target = 0.0, double *part_dev = nullptr,  // these two: phase 0 only
                          IpmScal *mirror = nullptr, unsigned long long *mirror_seq = nullptr, unsigned long long seq = 0);
+
+// ---- kernels_soc.hip (stage-wise second-order cones on the controls, primal-dual path following) ------------------
+struct SocArgs {
+  int M, N, u, Nc, q, owner;
+  const double *U, *dU;              // iterate, Newton step
+  const double *lo, *hi;             // control boxes (M,N,u) or null
+  const double *W, *w0, *v;          // cone || W u + w0 || <= v'u + v0: W (q x u) row-major, w0 (q), v (u); device
+  double v0, mu, sigmu;
+  double *sl, *su, *sc;              // slacks of the box sides (M,N,u) and of the cone (M,N,q+1): variables of their own
+  double *zl, *zu, *zc;              // their duals
+  double *dsl, *dsu, *dsc, *dzl, *dzu, *dzc;  // Newton steps
+  double *Hadd, *wu;                 // outputs: A'W^-2 A as full (u x u) blocks (-> LQArgs.Du, du_full), gradient shift
+  int *fail;
+};
+int launch_soc_prepare(const SocArgs &a, bool init_duals, double *part_sum, double *part_cnt, hipStream_t s);
+void launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, hipStream_t s);
+void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s);
 
 // ---- dynamics.hip -------------------------------------------------------------------------------
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,

@@ -70,6 +70,8 @@ struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc;  // cone path: particle weights / particle costs
+  DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
+  DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
@@ -256,7 +258,8 @@ void pmpc_destroy(pmpc_ctx *c) {
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
-                   &w.warm_lux};
+                   &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
+                   &w.soc_dsu, &w.soc_dsc};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -328,7 +331,16 @@ int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const doub
 }
 
 // -------------------------------------------------------------------------------------------------
+static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc);
+
 int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
+  return solve_impl(c, p, info, verbose, false);
+}
+int pmpc_lsoc_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
+  return solve_impl(c, p, info, verbose, true);
+}
+
+static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
@@ -469,6 +481,116 @@ int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, i
     setup_slab(su, w.su, nu, u, true, lo, hi, w.U.d(), w.dU.d());
   }
   const int B = PMPC_RED_BLOCKS;
+
+  if (soc) {
+    // ---- stage-wise control cones: primal-dual path following on the same Riccati kernels (kernels_soc.hip) ----------
+    if (has_xb || p->weights || a.any_slew || p->soc_u_interior == nullptr || (p->soc_q > 0 && (!p->soc_W || !p->soc_w0 || !p->soc_v)) ||
+        u > 8 || p->soc_q > 4) {
+      fprintf(stderr, "pmpc_hip: pmpc_lsoc_solve_device supports control boxes + one stage cone (udim <= 8, soc_q <= 4), no state boxes / "
+                      "weights / slew, and needs soc_u_interior\n");
+      return finish(2);
+    }
+    const int q = (int)p->soc_q;
+    w.Hadd.ensure(nu * u * D8); w.wu_soc.ensure(nu * D8);
+    const size_t ncz = (size_t)M * N * (q + 1);
+    for (DevBuf *b : {&w.soc_zl, &w.soc_zu, &w.soc_dzl, &w.soc_dzu, &w.soc_sl, &w.soc_su, &w.soc_dsl, &w.soc_dsu}) {
+      b->ensure(nu * D8);
+      HIP_CHECK(hipMemsetAsync(b->p, 0, nu * D8, s));
+    }
+    for (DevBuf *b : {&w.soc_zc, &w.soc_dzc, &w.soc_sc, &w.soc_dsc}) {
+      b->ensure(ncz * D8);
+      HIP_CHECK(hipMemsetAsync(b->p, 0, ncz * D8, s));
+    }
+    SocArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.M = M; sa.N = N; sa.u = u; sa.Nc = Nc; sa.q = q; sa.owner = a.owner;
+    sa.U = w.U.d(); sa.dU = w.dU.d();
+    sa.lo = has_ub ? su.lo : nullptr; sa.hi = has_ub ? su.hi : nullptr;
+    sa.W = p->soc_W; sa.w0 = p->soc_w0; sa.v = p->soc_v; sa.v0 = p->soc_v0;
+    sa.zl = w.soc_zl.d(); sa.zu = w.soc_zu.d(); sa.zc = w.soc_zc.d();
+    sa.dzl = w.soc_dzl.d(); sa.dzu = w.soc_dzu.d(); sa.dzc = w.soc_dzc.d();
+    sa.sl = w.soc_sl.d(); sa.su = w.soc_su.d(); sa.sc = w.soc_sc.d();
+    sa.dsl = w.soc_dsl.d(); sa.dsu = w.soc_dsu.d(); sa.dsc = w.soc_dsc.d();
+    sa.Hadd = w.Hadd.d(); sa.wu = w.wu_soc.d(); sa.fail = (int *)w.fail.p;
+    launch_soc_fill_u(w.U.d(), p->soc_u_interior, (long long)nu, u, s);
+    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+    else launch_rollout(a, w.U.d(), w.X.d(), s);
+    a.Dx = a.wx = nullptr;
+    a.Du = w.Hadd.d();  // full u x u blocks
+    a.du_full = 1;
+    a.wu = w.wu_soc.d();
+    const unsigned long long one_bits = 0x4000000000000000ull;  // 2.0: upper end of the step kernel's search
+    std::vector<double> hs(PMPC_RED_BLOCKS), hc(PMPC_RED_BLOCKS);
+    struct { unsigned long long amin; int fail; } host_rd;
+    // complementarity mu = sum s'z / (number of cones: one per finite box side, one per stage cone), measured on the
+    // device by the prepare kernel; cross-rank: summed
+    auto measure = [&](int nblk, double &mu_out) -> int {
+      HIP_CHECK(hipMemcpyAsync(hs.data(), w.part_sum.p, nblk * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(hc.data(), w.part_cnt.p, nblk * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(&host_rd.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      double sum = 0.0, cnt = 0.0;
+      for (int k = 0; k < nblk; k++) { sum += hs[k]; cnt += hc[k]; }
+      if (c->world > 1) {  // tiny host-staged all-reduce through the device (two doubles)
+        double pair[2] = {sum, cnt};
+        HIP_CHECK(hipMemcpyAsync(w.xch.p, pair, 2 * D8, hipMemcpyHostToDevice, s));
+        allreduce(c, w.xch.p, 2, ncclFloat64, ncclSum);
+        allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
+        HIP_CHECK(hipMemcpyAsync(pair, w.xch.p, 2 * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(&host_rd.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        sum = pair[0]; cnt = pair[1];
+      }
+      mu_out = sum / std::max(cnt, 1.0);
+      return host_rd.fail;
+    };
+    const double sigma = 0.2, mu_tol = 1e-12;
+    double mu = 1.0;
+    int status = 1, newton = 0;
+    sa.mu = 1.0; sa.sigmu = 0.0;
+    int nblk = launch_soc_prepare(sa, /*init_duals=*/true, w.part_sum.d(), w.part_cnt.d(), s);  // z = mu0 s^-1: centred start
+    int fl = measure(nblk, mu);
+    if (fl) return finish(fl == 3 ? 3 : 2);
+    for (int it = 0; it < 200; it++) {
+      sa.mu = mu; sa.sigmu = sigma * mu;
+      nblk = launch_soc_prepare(sa, false, w.part_sum.d(), w.part_cnt.d(), s);
+      structured_solve(c, a, true, fast);
+      inf.structured_solves++;
+      HIP_CHECK(hipMemcpyAsync(&sc->amin_bits, &one_bits, sizeof(one_bits), hipMemcpyHostToDevice, s));
+      launch_soc_step(sa, &sc->amin_bits, s);
+      if (c->world > 1) allreduce(c, &sc->amin_bits, 1, ncclFloat64, ncclMin);  // bit pattern of a non-negative double
+      HIP_CHECK(hipMemcpyAsync(&host_rd.amin, &sc->amin_bits, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(&host_rd.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (host_rd.fail) { status = host_rd.fail == 3 ? 3 : 2; break; }
+      double amax;
+      memcpy(&amax, &host_rd.amin, sizeof(double));
+      const double alpha = std::min(1.0, 0.99 * amax);  // strictly inside the cones, also when the boundary is just beyond 1
+      if (!(alpha > 0.0)) { status = 2; break; }
+      launch_axpy(w.X.d(), w.dX.d(), alpha, (long long)nx, s);
+      launch_axpy(w.U.d(), w.dU.d(), alpha, (long long)nu, s);
+      launch_axpy(sa.zl, sa.dzl, alpha, (long long)nu, s);
+      launch_axpy(sa.zu, sa.dzu, alpha, (long long)nu, s);
+      launch_axpy(sa.zc, sa.dzc, alpha, (long long)ncz, s);
+      launch_axpy(sa.sl, sa.dsl, alpha, (long long)nu, s);
+      launch_axpy(sa.su, sa.dsu, alpha, (long long)nu, s);
+      launch_axpy(sa.sc, sa.dsc, alpha, (long long)ncz, s);
+      newton++;
+      // complementarity of the new iterate (the prepare pass of the next iteration measures it; read it now to decide)
+      sa.mu = mu; sa.sigmu = 0.0;
+      nblk = launch_soc_prepare(sa, false, w.part_sum.d(), w.part_cnt.d(), s);
+      double mu_new;
+      fl = measure(nblk, mu_new);
+      if (fl) { status = fl == 3 ? 3 : 2; break; }
+      if (verbose) printf("pmpc_hip: soc it %3d  mu %9.3e -> %9.3e  alpha %6.4f\n", newton, mu, mu_new, alpha);
+      mu = mu_new;
+      if (mu <= mu_tol) { status = 0; break; }
+    }
+    inf.ipm_iters = newton;
+    inf.mu = mu;
+    if (verbose) printf("pmpc_hip: stage cones: status %d after %d Newton steps\n", status, newton);
+    return finish(status);
+  }
 
   // returns 0: the equality-only optimum satisfies every box (done), 1: boxes violated (interior-point phase), 2: failure
   auto equality_phase = [&]() -> int {

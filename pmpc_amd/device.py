@@ -75,7 +75,8 @@ class DeviceSolver:
     # ---- solve -----------------------------------------------------------------------------------------
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
-                 barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False):
+                 barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, soc_W=None, soc_w0=None,
+                 soc_v=None, soc_v0=0.0, soc_u_interior=None):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
@@ -103,7 +104,9 @@ class DeviceSolver:
             xdim=x, udim=u, N=N, M=M, Nc=int(Nc), flags=flags, reg_x=float(reg_x), reg_u=float(reg_u),
             x0=_p(x0), f=_p(f), fx=_p(fx), fu=_p(fu), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q), R=_p(R),
             X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
-            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu))
+            slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu),
+            soc_q=0 if soc_W is None else int(soc_W.shape[0]), soc_W=_p(soc_W), soc_w0=_p(soc_w0), soc_v=_p(soc_v), soc_v0=float(soc_v0),
+            soc_u_interior=_p(soc_u_interior))
         return prob, X_out, U_out
 
     def lqp_solve(self, *, verbose=False, wait_current_stream=True, **kw):
@@ -126,6 +129,19 @@ class DeviceSolver:
         if wait_current_stream:
             self.stream.wait_stream(torch.cuda.current_stream(self.device))
         status = self.lib.pmpc_lcone_solve_device(self.h, ctypes.byref(prob), float(smooth_alpha), ctypes.byref(info), int(verbose))
+        self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
+        return X_out, U_out, status
+
+    def lsoc_solve(self, *, verbose=False, wait_current_stream=True, **kw):
+        """`lqp_solve` plus one second-order cone ||W u + w0||_2 <= v'u + v0 on the controls of every (particle, stage) —
+        `soc_W (q, udim)`, `soc_w0 (q)`, `soc_v (udim)`, `soc_v0`, and `soc_u_interior (udim)`, a control strictly inside
+        the boxes and the cone (all float64 CUDA tensors).  Config E's thrust cones; the structured case of the reference's
+        pyjulia-only `extra_cstrs` (README.md:219-239)."""
+        prob, X_out, U_out = self._problem(**kw)
+        info = _lib.PmpcInfo()
+        if wait_current_stream:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        status = self.lib.pmpc_lsoc_solve_device(self.h, ctypes.byref(prob), ctypes.byref(info), int(verbose))
         self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
         return X_out, U_out, status
 

@@ -167,3 +167,40 @@ def test_warm_start_paths_give_the_cold_start_optimum(oracle):
     check(argsB, kwT)                                   # remembered controls lie outside the tighter boxes: rejected, cold
     check(argsB, kwT)                                   # and warm again
     s.close()
+
+
+# (M, N, x, u, Nc, u-bound): stage cone || (u_1, .., u_q) || <= 0.5 u_0 + 0.05 on every stage's controls
+SOC_CASES = [(3, 6, 12, 4, 1, 0.8), (4, 8, 4, 2, 0, 0.6), (5, 6, 3, 3, -1, 0.6), (6, 10, 5, 3, 2, None), (40, 12, 12, 4, 1, 0.8)]
+
+
+@pytest.mark.parametrize("case", SOC_CASES, ids=[str(c) for c in SOC_CASES])
+def test_stage_cones_match_cone_oracle(case, oracle):
+    """Config E's constraint type (stage-wise second-order cones on the controls, next to the boxes) — the device's
+    primal log-barrier Newton on the Riccati kernels against the oracle's path following on the sparse joint KKT system."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    M, N, x, u, Nc, bu = case
+    args, kw = rand_problem(np.random.default_rng(7000 + SOC_CASES.index(case)), M, N, x, u, bu)
+    W = np.zeros((u - 1, u))
+    W[np.arange(u - 1), np.arange(1, u)] = 1.0
+    w0, v, v0 = np.zeros(u - 1), np.eye(u)[0] * 0.5, 0.05
+    u_int = np.eye(u)[0] * 0.2
+    Xo, Uo = oracle.lsoc_solve_py(*args, Nc=Nc, reg_x=kw["reg_x"], reg_u=kw["reg_u"], u_l=kw.get("u_l"), u_u=kw.get("u_u"), soc_W=W,
+                                  soc_w0=w0, soc_v=v, soc_v0=v0, u_interior=u_int)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    s = DeviceSolver(0)
+    bounds = dict(lu=dev(kw["u_l"]), uu=dev(kw["u_u"])) if bu is not None else {}
+    X, U, status = s.lsoc_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref),
+                                U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, symmetric_cost=True, soc_W=dev(W),
+                                soc_w0=dev(w0), soc_v=dev(v), soc_v0=v0, soc_u_interior=dev(u_int), **bounds)
+    s.sync()
+    assert status == 0
+    X, U = X.cpu().numpy(), U.cpu().numpy()
+    slack = 0.5 * U[..., 0] + 0.05 - np.linalg.norm(U[..., 1:], axis=-1)
+    assert slack.min() > -1e-9 and (slack < 1e-6).sum() > 0  # inside every cone (to round-off), and the cone is active somewhere
+    assert _rel(X, Xo) < TOL and _rel(U, Uo) < TOL
+    s.close()
