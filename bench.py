@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--model", default="quadrotor", choices=["quadrotor", "unicycle"])
     ap.add_argument("--Nc", type=int, default=1, help="consensus horizon (-1 = N, the reference default)")
     ap.add_argument("--weak", action="store_true", help="weak scaling: --M particles PER GPU instead of in total")
+    ap.add_argument("--soc", action="store_true", help="quadrotor only: add the thrust cone ||(tau_x,tau_y)|| <= 0.3 T per stage "
+                    "(config E's constraint set, fp64; pmpc_lsoc_solve_device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -124,9 +126,19 @@ def main():
     fu = torch.empty((M_loc, N, u, x), dtype=torch.float64, device=dev)
     hist = []
 
+    soc_kw = {}
+    if args.soc:
+        assert args.model == "quadrotor"
+        Wc = torch.zeros((2, 4), dtype=torch.float64, device=dev)
+        Wc[0, 1] = Wc[1, 2] = 1.0
+        soc_kw = dict(soc_W=Wc, soc_w0=torch.zeros(2, dtype=torch.float64, device=dev),
+                      soc_v=torch.tensor([0.3, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev), soc_v0=0.0,
+                      soc_u_interior=torch.tensor([9.81, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev))
+    solve_fn = solver.lsoc_solve if args.soc else solver.lqp_solve
+
     def step(Xp, Up, Xo, Uo):
         solver.linearize(model, d["x0"], Xp, Up, d["params"], f, fx, fu)
-        _, _, status = solver.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
+        _, _, status = solve_fn(**soc_kw, f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
                                         U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
                                         lu=d.get("lu"), uu=d.get("uu"), X_out=Xo, U_out=Uo, verbose=args.verbose,
                                         force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False)
@@ -173,7 +185,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(k2):
-        solver.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xb, U_prev=Ub, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"],
+        solve_fn(**soc_kw, f=f, fx=fx, fu=fu, X_prev=Xb, U_prev=Ub, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"],
                          reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"), X_out=Xa, U_out=Ua,
                          force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False, cold_start=True)
     solver.sync()
@@ -203,7 +215,7 @@ def main():
             "config": {"workload": f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                    "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
                                    if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 else
-                                   f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u",
+                                   f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u" + (" + thrust cone per stage (config E constraints, fp64)" if args.soc else ""),
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",
                        "ipm_iters_per_step": float(np.mean(ipm_its)), "riccati_factorisations_per_step": float(np.mean(solves)),
                        "fast_path": bool(timed[-1][1]["fast_path"]), "final_scp_residual": float(timed[-1][0].item()),

@@ -142,3 +142,47 @@ def test_full_size_properties(solver, M, Nc):
             dU[:, :k] = dU[0:1, :k]  # keep the consensus
             U2 = np.clip(U + scale * dU, prob["u_l"], prob["u_u"])
             assert _objective(prob, _rollout_np(prob, f, fx, fu, U2), U2) >= J0 * (1 - 1e-12)
+
+
+def test_full_size_thrust_cones(solver):
+    """Config E's constraint set at config C's size (quadrotor M=1024, N=50, fp64): control boxes plus the thrust cone
+    ||(tau_x, tau_y)|| <= 0.3 T on every stage — consensus, feasibility, exact linearised dynamics and optimality by
+    feasible perturbations."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem
+
+    M, N = 1024, 50
+    prob = dyn.make_quadrotor_problem(M=M, N=N)
+    d = to_device_problem(prob)
+    f, fx, fu = solver.linearize(MODEL_QUADROTOR, d["x0"], d["X_prev"], d["U_prev"], d["params"])
+    dev = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device="cuda")
+    W = np.zeros((2, 4)); W[0, 1] = W[1, 2] = 1.0
+    X, U, status = solver.lsoc_solve(f=f, fx=fx, fu=fu, X_prev=d["X_prev"], U_prev=d["U_prev"], Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
+                                     U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d["lu"], uu=d["uu"],
+                                     symmetric_cost=True, soc_W=dev(W), soc_w0=dev(np.zeros(2)), soc_v=dev([0.3, 0, 0, 0]), soc_v0=0.0,
+                                     soc_u_interior=dev([9.81, 0, 0, 0]))
+    solver.sync()
+    assert status == 0
+    X, U = X.cpu().numpy(), U.cpu().numpy()
+    cone = lambda V: 0.3 * V[..., 0] - np.linalg.norm(V[..., 1:3], axis=-1)
+    assert np.all(U[:, 0] == U[0:1, 0]) and cone(U).min() > -1e-9 and (cone(U) < 1e-6).sum() > 100  # active on many stages
+    assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9)
+    Xr = _rollout_np(prob, f, fx, fu, U)
+    assert np.max(np.abs(Xr - X)) < 1e-8 * max(1.0, np.max(np.abs(X)))
+    J0 = _objective(prob, Xr, U)
+    rng = np.random.default_rng(3)
+    for scale in (1e-2, 1e-4):
+        for _ in range(3):
+            dU = rng.standard_normal(U.shape)
+            dU[:, :1] = dU[0:1, :1]
+            U2 = np.clip(U + scale * dU, prob["u_l"], prob["u_u"])
+            viol = cone(U2) < 0  # pull violators back onto their cone: shrink the lateral torques
+            nrm = np.maximum(np.linalg.norm(U2[..., 1:3], axis=-1), 1e-300)
+            shrink = np.where(viol, np.maximum(0.3 * U2[..., 0], 0.0) / nrm, 1.0)
+            U2[..., 1:3] *= shrink[..., None]
+            U2[:, :1] = U2[0:1, :1]
+            if cone(U2).min() < -1e-12:
+                continue
+            assert _objective(prob, _rollout_np(prob, f, fx, fu, U2), U2) >= J0 * (1 - 1e-12)
