@@ -9,6 +9,9 @@ which saves one transposing copy of the Jacobian stacks per iteration.  A built-
 "quadrotor"`, `params=...`) is linearised by the HIP kernel of csrc/dynamics.hip instead of a Python callable.
 Nothing crosses PCIe inside the loop except the scalars of the `hist` row (one small read per SCP iteration).
 
+`soc=dict(W=(q,u), w0=(q,), v=(u,), v0=float, u_interior=(u,))` adds the stage-wise second-order cone
+`||W u + w0|| <= v'u + v0` on every stage's controls (thrust cones; `DeviceSolver.lsoc_solve`).
+
 Host-only features of the reference loop that need the sub-problem on the host (`lin_cost_fn`, `extra_cstrs_fns`,
 filters, `solver_state`) are not offered here; `pmpc_amd.scp_mpc.scp_solve` (the default) has them.
 """
@@ -40,7 +43,8 @@ def scp_solve_device(f_fx_fu_fn: Optional[Callable], Q, R, x0, X_ref=None, U_ref
                      res_tol: float = 1e-5, reg_x: float = 1e0, reg_u: float = 1e-2, slew_rate: Optional[float] = None,
                      u0_slew=None, solver_settings: Optional[Dict[str, Any]] = None, device="cuda",
                      jacobians_abi_layout: bool = False, builtin_model: Optional[str] = None, params=None,
-                     return_torch: bool = False, solver: Optional[DeviceSolver] = None, lin_cost_fn=None, cost_fn=None,
+                     return_torch: bool = False, solver: Optional[DeviceSolver] = None, soc: Optional[Dict[str, Any]] = None,
+                     lin_cost_fn=None, cost_fn=None,
                      extra_cstrs_fns=None, solver_state=None, filter_method: str = "", debug: bool = False,
                      return_min_viol: bool = False, **ignored):
     host_only = dict(lin_cost_fn=lin_cost_fn, cost_fn=cost_fn, extra_cstrs_fns=extra_cstrs_fns, solver_state=solver_state,
@@ -85,6 +89,11 @@ def scp_solve_device(f_fx_fu_fn: Optional[Callable], Q, R, x0, X_ref=None, U_ref
         assert params is not None, "builtin_model needs `params` (M, 3) unicycle / (M, 4) quadrotor"
         params = T(params).reshape(M, -1).contiguous()
     x0c = x0.contiguous()
+    soc_kw = {}
+    if soc is not None:
+        soc_kw = dict(soc_W=T(soc["W"]).reshape(-1, udim).contiguous(), soc_w0=T(soc["w0"]).reshape(-1).contiguous(),
+                      soc_v=T(soc["v"]).reshape(udim).contiguous(), soc_v0=float(soc.get("v0", 0.0)),
+                      soc_u_interior=T(soc["u_interior"]).reshape(udim).contiguous())
     Xs = torch.empty((M, N, xdim), dtype=torch.float64, device=dev)
     Us = torch.empty((M, N, udim), dtype=torch.float64, device=dev)
 
@@ -111,7 +120,9 @@ def scp_solve_device(f_fx_fu_fn: Optional[Callable], Q, R, x0, X_ref=None, U_ref
         kw = dict(f=f, fx=fxa, fu=fua, X_prev=X_prev, U_prev=U_prev, Q=Qa, R=Ra, X_ref=X_ref, U_ref=U_ref, reg_x=float(reg_x),
                   reg_u=float(reg_u), Nc=Nc, x0=x0c, lx=lx, ux=ux, lu=lu, uu=uu, slew_reg=slew, slew_reg0=slew0, slew_um1=um1,
                   X_out=Xs, U_out=Us, symmetric_cost=sym, verbose=bool(settings.get("verbose", False)))
-        if cone:
+        if soc is not None:
+            _, _, status = s.lsoc_solve(**soc_kw, **kw)
+        elif cone:
             _, _, status = s.lcone_solve(smooth_alpha=smooth_alpha, **kw)
         else:
             _, _, status = s.lqp_solve(**kw)

@@ -134,3 +134,24 @@ def test_device_resident_scp_loop_matches_host_loop(mode):
     assert np.linalg.norm(Xd - Xh) / np.linalg.norm(Xh) < 1e-4 and np.linalg.norm(Ud - Uh) / np.linalg.norm(Uh) < 1e-4
     for a, b in zip(dd["hist"], dh["hist"]):
         assert abs(a["obj"] - b["obj"]) <= 1e-4 * abs(b["obj"]) and abs(a["resid"] - b["resid"]) <= 1e-3 * max(b["resid"], 1e-3)
+
+
+def test_device_loop_with_thrust_cones():
+    """`solve(..., device="cuda", builtin_model="quadrotor", soc=...)`: the SCP loop with the thrust cone on every stage runs,
+    keeps every iterate inside the cones and boxes, and its residual falls."""
+    import pmpc_amd
+    from pmpc_amd import dynamics as dyn
+
+    M, N = 16, 30
+    prob = dyn.make_quadrotor_problem(M=M, N=N)
+    W = np.zeros((2, 4)); W[0, 1] = W[1, 2] = 1.0
+    params = prob["params"]
+    X, U, data = pmpc_amd.solve(None, prob["Q"], prob["R"], prob["x0"], X_ref=prob["X_ref"], U_ref=prob["U_ref"], X_prev=prob["X_prev"],
+                                U_prev=prob["U_prev"], u_l=prob["u_l"], u_u=prob["u_u"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], max_it=6,
+                                res_tol=0.0, verbose=False, solver_settings=dict(solver="osqp", Nc=1), device="cuda",
+                                builtin_model="quadrotor", params=params,
+                                soc=dict(W=W, w0=np.zeros(2), v=[0.3, 0, 0, 0], v0=0.0, u_interior=[9.81, 0, 0, 0]))
+    assert X.shape == (M, N + 1, 12) and len(data["hist"]) == 6
+    assert (0.3 * U[..., 0] - np.linalg.norm(U[..., 1:3], axis=-1)).min() > -1e-9
+    assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9) and np.all(U[:, 0] == U[0:1, 0])
+    assert data["hist"][-1]["resid"] < data["hist"][0]["resid"]
