@@ -121,6 +121,8 @@ def assemble_abi(
 ) -> JointQP:
     """All array arguments are float64 buffers in ABI layout (any shape, C-contiguous memory)."""
     lib = _load()
+    if Nc > N:  # the reference indexes out of bounds here (lqp_utils.jl loops 1:Nc over N-long arrays); the C restatement would too
+        raise ValueError(f"Nc = {Nc} exceeds the horizon N = {N}")
     t0 = time.perf_counter()
     f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = map(_f64, (f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref))
     lx, ux, lu, uu = map(_f64, (lx, ux, lu, uu))
