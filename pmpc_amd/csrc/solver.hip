@@ -544,7 +544,10 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       mu_out = sum / std::max(cnt, 1.0);
       return host_rd.fail;
     };
-    const double sigma = 0.2, mu_tol = 1e-12;
+    // centering parameter: halved after every full step, doubled after a blocked one (no predictor solve: the step
+    // length of the last iteration is the cheapest estimate of how well centred the iterate is)
+    double sigma = 0.2;
+    const double mu_tol = 1e-12;
     double mu = 1.0;
     int status = 1, newton = 0;
     sa.mu = 1.0; sa.sigmu = 0.0;
@@ -582,7 +585,8 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       double mu_new;
       fl = measure(nblk, mu_new);
       if (fl) { status = fl == 3 ? 3 : 2; break; }
-      if (verbose) printf("pmpc_hip: soc it %3d  mu %9.3e -> %9.3e  alpha %6.4f\n", newton, mu, mu_new, alpha);
+      if (verbose) printf("pmpc_hip: soc it %3d  mu %9.3e -> %9.3e  alpha %6.4f  sigma %5.3f\n", newton, mu, mu_new, alpha, sigma);
+      sigma = alpha >= 1.0 ? std::max(0.5 * sigma, 0.02) : std::min(2.0 * sigma, 0.5);
       mu = mu_new;
       if (mu <= mu_tol) { status = 0; break; }
     }
