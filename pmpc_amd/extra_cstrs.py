@@ -1,0 +1,83 @@
+"""The reference's conic-constraint tuples `(l, q, e, G_left, G_right, h, c_left, c_right)` — `G z - h in K` over the joint
+variable vector `z = [U_cons (Nc*udim); U_free (M*(N-Nc)*udim); X (M*N*xdim)]` (README.md:219-239 and "Variable Layout";
+PMPC.jl/src/main.jl:293-316, cone_solver.jl:166-177) — recognised in the structured case the device solver implements:
+second-order cones only, every cone on the controls of ONE stage (of one particle, or of the shared consensus block), the
+same `(W, w0, v, v0)` for all of them:
+
+    row 0 of a cone:  v'u - (-v0)   = t        rows 1..q:  W u - (-w0) = x        ||x||_2 <= t.
+
+`stage_soc_from_extra_cstrs` returns `dict(W, w0, v, v0)` for `DeviceSolver.lsoc_solve` / `solve(..., device="cuda", soc=...)`,
+and raises `ValueError` saying which part of the structure is outside that case (linear / exponential cones, new variables,
+cost terms, state columns, cones spanning stages, stage-dependent data, stages without a cone)."""
+from __future__ import annotations
+
+from typing import Any, Dict, Sequence
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def stage_soc_from_extra_cstrs(cstr: Sequence[Any], M: int, N: int, xdim: int, udim: int, Nc: int, atol: float = 0.0) -> Dict[str, Any]:
+    l, q, e, G_left, G_right, h, c_left, c_right = cstr
+    q = [int(v) for v in np.atleast_1d(np.asarray(q, dtype=np.int64))] if np.size(q) else []
+    Nc = N if Nc < 0 else min(int(Nc), N)
+    Nf = N - Nc
+    ncu = Nc * udim + M * Nf * udim
+    n = ncu + M * N * xdim
+    if int(l) != 0 or int(e) != 0:
+        raise ValueError("only second-order cones are supported (l = e = 0)")
+    if G_right is not None and np.size(G_right) > 0 and sp.csr_matrix(G_right).shape[1] > 0:
+        raise ValueError("cones that introduce new variables (G_right) are not supported")
+    for c in (c_left, c_right):
+        if c is not None and np.size(c) > 0 and np.any(np.asarray(c, dtype=np.float64) != 0.0):
+            raise ValueError("cost augmentation (c_left / c_right) is not supported")
+    G = sp.csr_matrix(G_left, dtype=np.float64)
+    h = np.asarray(h, dtype=np.float64).reshape(-1)
+    if G.shape != (sum(q), n) or h.size != sum(q):
+        raise ValueError(f"G_left must be ({sum(q)}, {n}) over z = [U_cons; U_free; X], h ({sum(q)},)")
+    if len(set(q)) != 1:
+        raise ValueError("all cones must have the same size")
+    if G[:, ncu:].count_nonzero() > 0:
+        raise ValueError("cones on the states are not supported (only the controls of one stage)")
+    nblocks = ncu // udim  # Nc shared control blocks, then M*Nf free ones
+    if len(q) != nblocks:
+        raise ValueError(f"one cone per control block is required: {nblocks} blocks (Nc shared + M*(N-Nc) free), {len(q)} cones")
+    qq = q[0]
+    seen = np.zeros(nblocks, dtype=bool)
+    ref = None
+    for k in range(len(q)):
+        rows = G[k * qq:(k + 1) * qq]
+        cols = np.unique(rows.indices)
+        if cols.size == 0:
+            raise ValueError(f"cone {k} does not touch any control")
+        blk = int(cols[0]) // udim
+        if np.any(cols // udim != blk):
+            raise ValueError(f"cone {k} couples the controls of several stages")
+        if seen[blk]:
+            raise ValueError(f"control block {blk} carries more than one cone")
+        seen[blk] = True
+        A = rows[:, blk * udim:(blk + 1) * udim].toarray()
+        hk = h[k * qq:(k + 1) * qq]
+        cur = (A, hk)
+        if ref is None:
+            ref = cur
+        elif not (np.allclose(A, ref[0], rtol=0.0, atol=atol) and np.allclose(hk, ref[1], rtol=0.0, atol=atol)):
+            raise ValueError(f"cone {k} differs from cone 0: stage-dependent cone data are not supported")
+    A, hk = ref
+    return dict(W=A[1:].copy(), w0=-hk[1:].copy(), v=A[0].copy(), v0=float(-hk[0]))
+
+
+def stage_soc_to_extra_cstrs(W, w0, v, v0, M: int, N: int, xdim: int, udim: int, Nc: int):
+    """The inverse: the reference-format tuple of the stage-wise cone ||W u + w0|| <= v'u + v0 (what a pyjulia user of the
+    reference would pass in `extra_cstrs` / return from `extra_cstrs_fns`)."""
+    W, w0, v = np.atleast_2d(np.asarray(W, float)), np.asarray(w0, float).reshape(-1), np.asarray(v, float).reshape(-1)
+    Nc = N if Nc < 0 else min(int(Nc), N)
+    ncu = Nc * udim + M * (N - Nc) * udim
+    n = ncu + M * N * xdim
+    A = np.vstack([v[None, :], W])
+    qq = A.shape[0]
+    nblocks = ncu // udim
+    G = sp.kron(sp.identity(nblocks, format="csr"), sp.csr_matrix(A), format="csr")
+    G = sp.hstack([G, sp.csr_matrix((nblocks * qq, n - ncu))], format="csr")
+    h = np.tile(np.concatenate([[-float(v0)], -w0]), nblocks)
+    return (0, [qq] * nblocks, 0, G, sp.csr_matrix((nblocks * qq, 0)), h, np.zeros(n), np.zeros(0))

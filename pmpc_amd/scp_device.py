@@ -9,6 +9,7 @@ which saves one transposing copy of the Jacobian stacks per iteration.  A built-
 "quadrotor"`, `params=...`) is linearised by the HIP kernel of csrc/dynamics.hip instead of a Python callable.
 Nothing crosses PCIe inside the loop except the scalars of the `hist` row (one small read per SCP iteration).
 
+`solver_settings["extra_cstrs"]` in the reference's tuple format is accepted for that case (pmpc_amd/extra_cstrs.py).
 `soc=dict(W=(q,u), w0=(q,), v=(u,), v0=float, u_interior=(u,))` adds the stage-wise second-order cone
 `||W u + w0|| <= v'u + v0` on every stage's controls (thrust cones; `DeviceSolver.lsoc_solve`).
 
@@ -90,6 +91,16 @@ def scp_solve_device(f_fx_fu_fn: Optional[Callable], Q, R, x0, X_ref=None, U_ref
         params = T(params).reshape(M, -1).contiguous()
     x0c = x0.contiguous()
     soc_kw = {}
+    if soc is None and settings.get("extra_cstrs"):  # the reference's tuple format, stage-wise SOC case only
+        from .extra_cstrs import stage_soc_from_extra_cstrs
+
+        tuples = list(settings["extra_cstrs"])
+        if len(tuples) != 1:
+            raise ValueError("one extra_cstrs tuple (the stage-wise second-order cone) is supported")
+        soc = stage_soc_from_extra_cstrs(tuples[0], M, N, xdim, udim, Nc)
+        if "soc_u_interior" not in settings:
+            raise ValueError("solver_settings['soc_u_interior'] (a control strictly inside the boxes and the cone) is required")
+        soc["u_interior"] = settings["soc_u_interior"]
     if soc is not None:
         soc_kw = dict(soc_W=T(soc["W"]).reshape(-1, udim).contiguous(), soc_w0=T(soc["w0"]).reshape(-1).contiguous(),
                       soc_v=T(soc["v"]).reshape(udim).contiguous(), soc_v0=float(soc.get("v0", 0.0)),

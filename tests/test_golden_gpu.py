@@ -151,6 +151,15 @@ def test_device_loop_with_thrust_cones():
                                 res_tol=0.0, verbose=False, solver_settings=dict(solver="osqp", Nc=1), device="cuda",
                                 builtin_model="quadrotor", params=params,
                                 soc=dict(W=W, w0=np.zeros(2), v=[0.3, 0, 0, 0], v0=0.0, u_interior=[9.81, 0, 0, 0]))
+    # the same cone handed over in the reference's `extra_cstrs` tuple format gives the same trajectories
+    from pmpc_amd.extra_cstrs import stage_soc_to_extra_cstrs
+
+    cstr = stage_soc_to_extra_cstrs(W, np.zeros(2), [0.3, 0, 0, 0], 0.0, M, N, 12, 4, 1)
+    X2, U2, _ = pmpc_amd.solve(None, prob["Q"], prob["R"], prob["x0"], X_ref=prob["X_ref"], U_ref=prob["U_ref"], X_prev=prob["X_prev"],
+                               U_prev=prob["U_prev"], u_l=prob["u_l"], u_u=prob["u_u"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], max_it=6,
+                               res_tol=0.0, verbose=False, device="cuda", builtin_model="quadrotor", params=params,
+                               solver_settings=dict(solver="osqp", Nc=1, extra_cstrs=[cstr], soc_u_interior=[9.81, 0, 0, 0]))
+    assert np.array_equal(X2, X) and np.array_equal(U2, U)
     assert X.shape == (M, N + 1, 12) and len(data["hist"]) == 6
     assert (0.3 * U[..., 0] - np.linalg.norm(U[..., 1:3], axis=-1)).min() > -1e-9
     assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9) and np.all(U[:, 0] == U[0:1, 0])

@@ -251,3 +251,36 @@ def test_oracle_and_host_loop_reproduce_reference_notebook_table(oracle, monkeyp
     monkeypatch.setattr(scp, "aff_solve", oracle_aff_solve)
     X, U, data = scp.scp_solve(*args, solver_settings=dict(solver="ecos"), **kw)
     nbp.check_rows(data["hist"], table)
+
+
+def test_extra_cstrs_tuple_to_stage_cones():
+    """The reference's `extra_cstrs` tuple format (README.md:219-239) for the stage-wise thrust cone is recognised and
+    mapped to the device solver's `(W, w0, v, v0)`; anything outside that structure is refused with a reason."""
+    import scipy.sparse as sp
+
+    from pmpc_amd.extra_cstrs import stage_soc_from_extra_cstrs, stage_soc_to_extra_cstrs
+
+    M, N, x, u, Nc = 3, 5, 12, 4, 2
+    W = np.zeros((2, 4)); W[0, 1] = W[1, 2] = 1.0
+    cstr = stage_soc_to_extra_cstrs(W, [0.1, -0.2], [0.3, 0, 0, 0], 0.05, M, N, x, u, Nc)
+    assert cstr[0] == 0 and cstr[2] == 0 and len(cstr[1]) == Nc + M * (N - Nc) and cstr[3].shape[1] == Nc * u + M * (N - Nc) * u + M * N * x
+    soc = stage_soc_from_extra_cstrs(cstr, M, N, x, u, Nc)
+    np.testing.assert_array_equal(soc["W"], W)
+    np.testing.assert_array_equal(soc["w0"], [0.1, -0.2])
+    np.testing.assert_array_equal(soc["v"], [0.3, 0, 0, 0])
+    assert soc["v0"] == 0.05
+    bad = list(cstr); bad[0] = 2
+    with pytest.raises(ValueError, match="second-order"):
+        stage_soc_from_extra_cstrs(bad, M, N, x, u, Nc)
+    G = cstr[3].tolil(); G[0, G.shape[1] - 1] = 1.0
+    with pytest.raises(ValueError, match="states"):
+        stage_soc_from_extra_cstrs((0, cstr[1], 0, G.tocsr(), cstr[4], cstr[5], cstr[6], cstr[7]), M, N, x, u, Nc)
+    G = cstr[3].tolil(); G[3, 5] = 1.0  # second cone (block 1) reaches into block 1 and ... column 5 is block 1: make it span block 0
+    G[3, 1] = 1.0
+    with pytest.raises(ValueError, match="several stages"):
+        stage_soc_from_extra_cstrs((0, cstr[1], 0, G.tocsr(), cstr[4], cstr[5], cstr[6], cstr[7]), M, N, x, u, Nc)
+    h = cstr[5].copy(); h[3] += 1.0
+    with pytest.raises(ValueError, match="stage-dependent"):
+        stage_soc_from_extra_cstrs((0, cstr[1], 0, cstr[3], cstr[4], h, cstr[6], cstr[7]), M, N, x, u, Nc)
+    with pytest.raises(ValueError, match="one cone per control block"):
+        stage_soc_from_extra_cstrs((0, cstr[1][:-1], 0, cstr[3][:-3], cstr[4], cstr[5][:-3], cstr[6], cstr[7]), M, N, x, u, Nc)
