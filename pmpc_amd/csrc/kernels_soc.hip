@@ -57,7 +57,8 @@ __device__ __forceinline__ double cone_ratio(const double *x, const double *d, i
   return al;
 }
 
-// MODE 0: s = A u + c, z = mu s^-1 (centred start);  MODE 1: Hadd, wu from (U, s, z);  sums s'z and counts either way
+// MODE 0: s = A u + c, z = mu s^-1 (centred start);  MODE 2: s = A u + c, z kept (warm start from remembered duals);
+// MODE 1: Hadd, wu from (U, s, z);  sums s'z and counts in every mode
 template <int MODE>
 __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum, double *part_cnt) {
   __shared__ double sh[TB];
@@ -85,14 +86,16 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
       for (int r = 0; r < u; r++) {
         const double lo = a.lo[k * u + r], hi = a.hi[k * u + r];
         if (isfinite(lo)) {
-          if (MODE == 0) { a.sl[k * u + r] = uu[r] - lo; a.zl[k * u + r] = a.mu / (uu[r] - lo); }
+          if (MODE != 1) a.sl[k * u + r] = uu[r] - lo;
+          if (MODE == 0) a.zl[k * u + r] = a.mu / (uu[r] - lo);
           const double s = a.sl[k * u + r], z = a.zl[k * u + r], rp = (uu[r] - lo) - s, d = z / s;
           ok &= (s > 0.0) && (z > 0.0);
           comp += s * z; cnt += 1.0;
           g[r] += -a.sigmu / s + d * rp; H[r][r] += d;   // A = +e_r
         }
         if (isfinite(hi)) {
-          if (MODE == 0) { a.su[k * u + r] = hi - uu[r]; a.zu[k * u + r] = a.mu / (hi - uu[r]); }
+          if (MODE != 1) a.su[k * u + r] = hi - uu[r];
+          if (MODE == 0) a.zu[k * u + r] = a.mu / (hi - uu[r]);
           const double s = a.su[k * u + r], z = a.zu[k * u + r], rp = (hi - uu[r]) - s, d = z / s;
           ok &= (s > 0.0) && (z > 0.0);
           comp += s * z; cnt += 1.0;
@@ -104,9 +107,10 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
       double s[1 + QMAX], z[1 + QMAX], wb[1 + QMAX], rp[1 + QMAX];
       double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
       cone_slack(a, uu, rp);  // A u + c
-      if (MODE == 0) {  // s = A u + c,  z = mu s^-1 = mu J s / (s'Js)
+      if (MODE != 1)
+        for (int p = 0; p <= q; p++) sc[p] = rp[p];  // s = A u + c
+      if (MODE == 0) {  // z = mu s^-1 = mu J s / (s'Js)
         const double ss0 = jdot(rp, rp, q);
-        for (int p = 0; p <= q; p++) sc[p] = rp[p];
         zc[0] = a.mu * rp[0] / ss0;
         for (int p = 1; p <= q; p++) zc[p] = -a.mu * rp[p] / ss0;
       }
@@ -251,9 +255,10 @@ static unsigned soc_grid(const SocArgs &a) {
   return (unsigned)b;
 }
 // every launch runs exactly PMPC_RED_BLOCKS-bounded grids and fills part_sum / part_cnt [0, grid): returns the grid size
-int launch_soc_prepare(const SocArgs &a, bool init_duals, double *part_sum, double *part_cnt, hipStream_t s) {
+int launch_soc_prepare(const SocArgs &a, int mode, double *part_sum, double *part_cnt, hipStream_t s) {
   const unsigned g = soc_grid(a);
-  if (init_duals) hipLaunchKernelGGL(k_soc_prepare<0>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
+  if (mode == 0) hipLaunchKernelGGL(k_soc_prepare<0>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
+  else if (mode == 2) hipLaunchKernelGGL(k_soc_prepare<2>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
   else hipLaunchKernelGGL(k_soc_prepare<1>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
   return (int)g;
 }

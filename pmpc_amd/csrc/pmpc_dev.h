@@ -153,7 +153,8 @@ struct SocArgs {
   double *Hadd, *wu;                 // outputs: A'W^-2 A as full (u x u) blocks (-> LQArgs.Du, du_full), gradient shift
   int *fail;
 };
-int launch_soc_prepare(const SocArgs &a, bool init_duals, double *part_sum, double *part_cnt, hipStream_t s);
+// mode 0: cold start (s from u, z = mu s^-1), 2: warm start (s from u, z kept), 1: Newton system blocks from (u, s, z)
+int launch_soc_prepare(const SocArgs &a, int mode, double *part_sum, double *part_cnt, hipStream_t s);
 void launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, hipStream_t s);
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s);
 

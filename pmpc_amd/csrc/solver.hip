@@ -71,6 +71,8 @@ struct Workspace {
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc;  // cone path: particle weights / particle costs
   DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
+  DevBuf soc_wU, soc_wzl, soc_wzu, soc_wzc;  // remembered early iterate (warm start of the cone path)
+  long long soc_key = -1;
   DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
@@ -259,7 +261,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -512,9 +514,6 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     sa.sl = w.soc_sl.d(); sa.su = w.soc_su.d(); sa.sc = w.soc_sc.d();
     sa.dsl = w.soc_dsl.d(); sa.dsu = w.soc_dsu.d(); sa.dsc = w.soc_dsc.d();
     sa.Hadd = w.Hadd.d(); sa.wu = w.wu_soc.d(); sa.fail = (int *)w.fail.p;
-    launch_soc_fill_u(w.U.d(), p->soc_u_interior, (long long)nu, u, s);
-    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
-    else launch_rollout(a, w.U.d(), w.X.d(), s);
     a.Dx = a.wx = nullptr;
     a.Du = w.Hadd.d();  // full u x u blocks
     a.du_full = 1;
@@ -550,13 +549,37 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     const double mu_tol = 1e-12;
     double mu = 1.0;
     int status = 1, newton = 0;
+    // warm start as on the box path: the early iterate (mu <= 0.5) of the previous solve of this
+    // shape — controls and duals; the slacks are recomputed from the new data — if it is strictly feasible for them
+    static const bool soc_warm_off = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
+    const long long skey = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 8 + q) * 2 + (has_ub ? 1 : 0);
+    bool warm = !soc_warm_off && !(p->flags & PMPC_COLD_START) && w.soc_key == skey, remembered = false;
+    int nblk, fl;
+  soc_restart:
     sa.mu = 1.0; sa.sigmu = 0.0;
-    int nblk = launch_soc_prepare(sa, /*init_duals=*/true, w.part_sum.d(), w.part_cnt.d(), s);  // z = mu0 s^-1: centred start
-    int fl = measure(nblk, mu);
+    if (warm) {
+      HIP_CHECK(hipMemcpyAsync(w.U.p, w.soc_wU.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(sa.zl, w.soc_wzl.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(sa.zu, w.soc_wzu.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(sa.zc, w.soc_wzc.p, ncz * D8, hipMemcpyDeviceToDevice, s));
+    } else {
+      launch_soc_fill_u(w.U.d(), p->soc_u_interior, (long long)nu, u, s);
+    }
+    if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+    else launch_rollout(a, w.U.d(), w.X.d(), s);
+    nblk = launch_soc_prepare(sa, warm ? 2 : 0, w.part_sum.d(), w.part_cnt.d(), s);  // cold: z = mu0 s^-1, a centred start
+    fl = measure(nblk, mu);
+    if (fl && warm) {  // the remembered controls are not strictly inside the new boxes / cones
+      if (verbose) printf("pmpc_hip: stage cones: remembered iterate rejected, cold start\n");
+      warm = false;
+      w.soc_key = -1;
+      HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+      goto soc_restart;
+    }
     if (fl) return finish(fl == 3 ? 3 : 2);
     for (int it = 0; it < 200; it++) {
       sa.mu = mu; sa.sigmu = sigma * mu;
-      nblk = launch_soc_prepare(sa, false, w.part_sum.d(), w.part_cnt.d(), s);
+      nblk = launch_soc_prepare(sa, 1, w.part_sum.d(), w.part_cnt.d(), s);
       structured_solve(c, a, true, fast);
       inf.structured_solves++;
       HIP_CHECK(hipMemcpyAsync(&sc->amin_bits, &one_bits, sizeof(one_bits), hipMemcpyHostToDevice, s));
@@ -581,14 +604,31 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       newton++;
       // complementarity of the new iterate (the prepare pass of the next iteration measures it; read it now to decide)
       sa.mu = mu; sa.sigmu = 0.0;
-      nblk = launch_soc_prepare(sa, false, w.part_sum.d(), w.part_cnt.d(), s);
+      nblk = launch_soc_prepare(sa, 1, w.part_sum.d(), w.part_cnt.d(), s);
       double mu_new;
       fl = measure(nblk, mu_new);
       if (fl) { status = fl == 3 ? 3 : 2; break; }
       if (verbose) printf("pmpc_hip: soc it %3d  mu %9.3e -> %9.3e  alpha %6.4f  sigma %5.3f\n", newton, mu, mu_new, alpha, sigma);
       sigma = alpha >= 1.0 ? std::max(0.5 * sigma, 0.02) : std::min(2.0 * sigma, 0.5);
       mu = mu_new;
+      if (!remembered && !soc_warm_off && mu <= 0.5) {
+        for (DevBuf *b : {&w.soc_wU, &w.soc_wzl, &w.soc_wzu}) b->ensure(nu * D8);
+        w.soc_wzc.ensure(ncz * D8);
+        HIP_CHECK(hipMemcpyAsync(w.soc_wU.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.soc_wzl.p, sa.zl, nu * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.soc_wzu.p, sa.zu, nu * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.soc_wzc.p, sa.zc, ncz * D8, hipMemcpyDeviceToDevice, s));
+        w.soc_key = skey;
+        remembered = true;
+      }
       if (mu <= mu_tol) { status = 0; break; }
+    }
+    if (status != 0 && warm) {  // a warm-started run that fails is repeated cold
+      if (verbose) printf("pmpc_hip: stage cones: warm-started run failed (status %d), cold start\n", status);
+      warm = false; remembered = false; status = 1; newton = 0; sigma = 0.2;
+      w.soc_key = -1;
+      HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+      goto soc_restart;
     }
     inf.ipm_iters = newton;
     inf.mu = mu;
