@@ -159,7 +159,7 @@ def test_device_loop_with_thrust_cones():
                                U_prev=prob["U_prev"], u_l=prob["u_l"], u_u=prob["u_u"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], max_it=6,
                                res_tol=0.0, verbose=False, device="cuda", builtin_model="quadrotor", params=params,
                                solver_settings=dict(solver="osqp", Nc=1, extra_cstrs=[cstr], soc_u_interior=[9.81, 0, 0, 0]))
-    assert np.allclose(X2, X, rtol=0, atol=1e-8) and np.allclose(U2, U, rtol=0, atol=1e-8)  # (warm starts differ: not bitwise)
+    assert np.allclose(X2, X, rtol=0, atol=1e-6) and np.allclose(U2, U, rtol=0, atol=1e-6)  # (warm-start histories differ: not bitwise)
     assert X.shape == (M, N + 1, 12) and len(data["hist"]) == 6
     assert (0.3 * U[..., 0] - np.linalg.norm(U[..., 1:3], axis=-1)).min() > -1e-9
     assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9) and np.all(U[:, 0] == U[0:1, 0])
