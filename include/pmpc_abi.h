@@ -155,6 +155,10 @@ int pmpc_particle_costs_device(pmpc_ctx *ctx, const pmpc_problem *prob, const do
  * all-reduces the consensus Hessian/gradient and the IPM scalars. */
 int pmpc_comm_unique_id(void *unique_id_128);
 int pmpc_comm_init(pmpc_ctx *ctx, int rank, int world, const void *unique_id_128);
+/* TEST HOOK (tests/test_multirank_gpu.py): an in-process stand-in for the communicator — `world` contexts on ONE device, one
+ * host thread each, collectives staged through host memory — so that the world > 1 code paths run on a single-GPU box
+ * (RCCL refuses two ranks on one device).  Not for production use. */
+int pmpc_comm_init_mock(pmpc_ctx *ctx, int rank, int world, int group);
 int pmpc_comm_rank(pmpc_ctx *ctx);
 int pmpc_comm_world(pmpc_ctx *ctx);
 

@@ -23,7 +23,7 @@ HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, CO
 ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
-    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device",
+    "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
 ]
 
 
@@ -79,6 +79,8 @@ def load():
     lib.pmpc_comm_unique_id.restype = ctypes.c_int
     lib.pmpc_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     lib.pmpc_comm_init.restype = ctypes.c_int
+    lib.pmpc_comm_init_mock.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.pmpc_comm_init_mock.restype = ctypes.c_int
     lib.pmpc_comm_rank.argtypes = [vp]
     lib.pmpc_comm_rank.restype = ctypes.c_int
     lib.pmpc_comm_world.argtypes = [vp]

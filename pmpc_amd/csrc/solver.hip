@@ -12,7 +12,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <limits>
 #include <vector>
 
@@ -44,6 +47,70 @@ struct Rccl {
   }
 };
 Rccl g_rccl;
+
+// ---- in-process communicator (TEST HOOK, pmpc_comm_init_mock) --------------------------------------------------------
+// RCCL refuses two ranks on one device, so on a single-GPU box the world > 1 code paths (packed scalar exchange, consensus
+// all-reduce, owner / bounds broadcast) could never run.  This stand-in lets N contexts on ONE device, each driven by its
+// own host thread, play the ranks: a collective synchronises the caller's stream, meets the other ranks at a barrier,
+// reduces on the host in rank order and writes the result back.  Same call signature as the RCCL entry points it
+// replaces; correctness only, no performance meaning.
+struct MockGroup {
+  int world = 0, arrived = 0, generation = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  std::vector<std::vector<unsigned char>> slot;  // one staging buffer per rank
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const int gen = generation;
+    if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != generation; });
+  }
+};
+struct MockRank { MockGroup *g; int rank; };
+std::map<int, MockGroup *> g_mock_groups;
+std::mutex g_mock_mutex;
+
+template <class T>
+void mock_reduce(MockGroup *g, size_t n, ncclRedOp_t op, T *out) {
+  for (size_t k = 0; k < n; k++) {
+    T acc = ((const T *)g->slot[0].data())[k];
+    for (int r = 1; r < g->world; r++) {
+      const T v = ((const T *)g->slot[r].data())[k];
+      acc = op == ncclSum ? (T)(acc + v) : (op == ncclMin ? std::min(acc, v) : std::max(acc, v));
+    }
+    out[k] = acc;
+  }
+}
+ncclResult_t mock_allreduce(const void *send, void *recv, size_t n, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t s) {
+  MockRank *mr = (MockRank *)comm;
+  MockGroup *g = mr->g;
+  const size_t esz = dt == ncclFloat64 ? 8 : 4;
+  HIP_CHECK(hipStreamSynchronize(s));
+  g->slot[mr->rank].resize(n * esz);
+  HIP_CHECK(hipMemcpy(g->slot[mr->rank].data(), send, n * esz, hipMemcpyDeviceToHost));
+  g->barrier();
+  std::vector<unsigned char> out(n * esz);
+  if (dt == ncclFloat64) mock_reduce<double>(g, n, op, (double *)out.data());
+  else mock_reduce<int>(g, n, op, (int *)out.data());
+  g->barrier();  // everyone has read the slots before anyone overwrites them in the next collective
+  HIP_CHECK(hipMemcpy(recv, out.data(), n * esz, hipMemcpyHostToDevice));
+  return ncclSuccess;
+}
+ncclResult_t mock_broadcast(const void *send, void *recv, size_t n, ncclDataType_t dt, int root, ncclComm_t comm, hipStream_t s) {
+  MockRank *mr = (MockRank *)comm;
+  MockGroup *g = mr->g;
+  const size_t esz = dt == ncclFloat64 ? 8 : 4;
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (mr->rank == root) {
+    g->slot[root].resize(n * esz);
+    HIP_CHECK(hipMemcpy(g->slot[root].data(), send, n * esz, hipMemcpyDeviceToHost));
+  }
+  g->barrier();
+  std::vector<unsigned char> out(g->slot[root].begin(), g->slot[root].begin() + n * esz);
+  g->barrier();
+  HIP_CHECK(hipMemcpy(recv, out.data(), n * esz, hipMemcpyHostToDevice));
+  return ncclSuccess;
+}
 
 struct DevBuf {
   void *p = nullptr;
@@ -103,6 +170,7 @@ struct pmpc_ctx {
   unsigned long long seq = 0;
   // RCCL
   ncclComm_t comm = nullptr;
+  bool mock_comm = false;  // comm is a MockRank (test hook), not an RCCL communicator
   int rank = 0, world = 1;
   // staging for the host-pointer ABI
   DevBuf stage[19];
@@ -255,7 +323,8 @@ void pmpc_destroy(pmpc_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->comm && c->mock_comm) delete (MockRank *)c->comm;
+  else if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
@@ -318,6 +387,26 @@ int pmpc_comm_init(pmpc_ctx *c, int rank, int world, const void *id128) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return 2;
+  c->rank = rank;
+  c->world = world;
+  return 0;
+}
+// TEST HOOK: join the in-process communicator `group` (see MockGroup above) as rank `rank` of `world`.  Every context of
+// the group lives on one device and must be driven by its own host thread.  Installs the stand-in collectives
+// process-wide: do not mix with a real RCCL communicator in the same process.
+int pmpc_comm_init_mock(pmpc_ctx *c, int rank, int world, int group) {
+  std::lock_guard<std::mutex> lk(g_mock_mutex);
+  MockGroup *&g = g_mock_groups[group];
+  if (!g) {
+    g = new MockGroup();
+    g->world = world;
+    g->slot.resize(world);
+  }
+  if (g->world != world || rank < 0 || rank >= world) return 1;
+  g_rccl.AllReduce = mock_allreduce;
+  g_rccl.Broadcast = mock_broadcast;
+  c->comm = (ncclComm_t) new MockRank{g, rank};
+  c->mock_comm = true;
   c->rank = rank;
   c->world = world;
   return 0;

@@ -1,0 +1,115 @@
+"""The world > 1 code paths on ONE GPU: N contexts joined by the library's in-process stand-in communicator
+(`pmpc_comm_init_mock`, a test hook — RCCL refuses two ranks on one device), one host thread per rank, particles sharded
+in contiguous blocks exactly as bench.py shards them over RCCL.  What runs is everything but RCCL itself: the packed scalar
+exchange (pack / all-reduce / unpack kernels), the consensus Hessian / gradient all-reduce and redundant dense solve, the
+owner logic (global particle 0 carries the consensus boxes; its bounds are broadcast), warm starts across ranks."""
+import threading
+
+import numpy as np
+import pytest
+
+from tests.support.problems import rand_problem
+
+pytestmark = pytest.mark.gpu
+_group = [1000]
+
+
+def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False):
+    import torch
+
+    from pmpc_amd import _lib
+    from pmpc_amd.device import DeviceSolver
+
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    M = f.shape[0]
+    assert M % world == 0
+    Ml = M // world
+    _group[0] += 1
+    group = _group[0]
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            sl = slice(rank * Ml, (rank + 1) * Ml)
+            dev = lambda a: torch.tensor(np.ascontiguousarray(a[sl]), dtype=torch.float64, device="cuda")
+            T = lambda a: dev(np.swapaxes(a, -1, -2))
+            s = DeviceSolver(0)
+            if world > 1:
+                assert s.lib.pmpc_comm_init_mock(s.h, rank, world, group) == 0
+                s.rank, s.world = rank, world
+            opt = {}
+            if "u_l" in kw:
+                opt.update(lu=dev(kw["u_l"]), uu=dev(kw["u_u"]))
+            if "x_l" in kw:
+                opt.update(lx=dev(kw["x_l"]), ux=dev(kw["x_u"]))
+            if "slew_reg" in kw:
+                opt.update(slew_reg=dev(kw["slew_reg"]))
+            if "slew_reg0" in kw:
+                opt.update(slew_reg0=dev(kw["slew_reg0"]), slew_um1=dev(kw["slew_um1"]))
+            for _ in range(repeats):  # repeats > 1: the second solve is warm-started on every rank
+                X, U, status = s.lqp_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
+                                           X_ref=dev(X_ref), U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc,
+                                           symmetric_cost=True, **opt)
+                s.sync()
+            out[rank] = (X.cpu().numpy(), U.cpu().numpy(), status, dict(s.last_info))
+            s.close()
+        except Exception as e:  # surface failures of a rank thread in the main thread
+            errs.append(e)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish (deadlock in a collective?)"
+    assert all(o[2] == 0 for o in out)
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out]), [o[3] for o in out]
+
+
+# (M, N, x, u, Nc, u-bound, x-bound, slew, slew0)
+MR_CASES = [
+    (8, 9, 12, 4, 1, 0.4, None, None, None),
+    (8, 7, 4, 2, 3, 0.3, 6.0, None, None),
+    (6, 8, 5, 3, -1, 0.4, None, None, None),
+    (8, 6, 3, 2, 2, 0.3, 5.0, 0.5, 0.3),
+    (8, 9, 12, 4, 0, 0.4, None, None, None),
+    (12, 20, 2, 1, -1, 0.5, None, None, None),
+]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", MR_CASES, ids=[str(c) for c in MR_CASES])
+def test_sharded_solve_matches_single_rank_and_oracle(case, world, oracle):
+    M, N, x, u, Nc, bu, bx, sl, sl0 = case
+    if M % world:
+        pytest.skip("particles do not divide")
+    rng = np.random.default_rng(9000 + MR_CASES.index(case))
+    args, kw = rand_problem(rng, M, N, x, u, bu, bx, sl, sl0)
+    if Nc != 0 and bu is not None:  # per-particle control boxes: the consensus stages must use GLOBAL particle 0's everywhere
+        scale = 1.0 + 0.5 * rng.random((M, 1, 1))
+        kw["u_l"], kw["u_u"] = kw["u_l"] * scale, kw["u_u"] * scale
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    X1, U1, _ = _solve_sharded(args, kw, Nc, 1)
+    Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, repeats=2)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    assert rel(X1, Xo) < 1e-7 and rel(U1, Uo) < 1e-7
+    assert rel(Xw, Xo) < 1e-7 and rel(Uw, Uo) < 1e-7
+    k = N if Nc < 0 else Nc
+    if k:
+        assert np.all(Uw[:, :k] == Uw[0:1, :k])  # the shared controls are bit-identical on every rank
+    assert len({i["ipm_iters"] for i in infos}) == 1  # every rank took the same decisions
+
+
+def test_eight_ranks_quadrotor_shape(oracle):
+    """bench.py's 8-GPU layout in miniature: 8 ranks x 4 particles, quadrotor dimensions, Nc = 1, control boxes."""
+    from pmpc_amd import dynamics as dyn
+
+    prob = dyn.make_quadrotor_problem(M=32, N=12)
+    f, fx, fu = prob["f_fx_fu_fn"](np.concatenate([prob["x0"][:, None, :], prob["X_prev"][:, :-1, :]], 1), prob["U_prev"])
+    args = (prob["x0"], f, fx, fu, prob["X_prev"], prob["U_prev"], prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"])
+    kw = dict(reg_x=prob["reg_x"], reg_u=prob["reg_u"], u_l=prob["u_l"], u_u=prob["u_u"])
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=1, **kw)
+    Xw, Uw, infos = _solve_sharded(args, kw, 1, 8, repeats=2)
+    assert np.linalg.norm(Xw - Xo) / np.linalg.norm(Xo) < 1e-7 and np.linalg.norm(Uw - Uo) / np.linalg.norm(Uo) < 1e-7
+    assert np.all(Uw[:, :1] == Uw[0:1, :1]) and len({i["ipm_iters"] for i in infos}) == 1
