@@ -137,7 +137,7 @@ int pmpc_lqp_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, pmpc_info *in
  * ABI: k = M, no extra_cstrs): min (1+eps) sum_i y_i + (1-eps) M t  s.t.  J_i <= y_i + t, y >= 0, dynamics, boxes,
  * eps = 1e-3, J_i the particle cost of qp_utils.jl:60-162.  Eliminating (y, t) gives sum_i w_i J_i with w = 1+eps
  * above the threshold particle(s) — solved as a short sequence of weighted QPs.  smooth_alpha = NaN: hard boxes.
- * Single rank only (the particle ranking is not exchanged across ranks yet). */
+ * Sharded runs: equal particle counts per rank; the costs are gathered so that every rank ranks them identically. */
 int pmpc_lcone_solve_device(pmpc_ctx *ctx, const pmpc_problem *prob, double smooth_alpha, pmpc_info *info, int verbose);
 
 /* The QP of pmpc_lqp_solve_device plus the stage-wise control cones of pmpc_problem.soc_* (control boxes allowed, state

@@ -136,7 +136,7 @@ struct SlabBufs {
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
-  DevBuf pw, Jc;  // cone path: particle weights / particle costs
+  DevBuf pw, Jc, Jg;  // cone path: particle weights / particle costs (local, gathered)
   DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
   DevBuf soc_wU, soc_wzl, soc_wzu, soc_wzc;  // remembered early iterate (warm start of the cone path)
   long long soc_key = -1;
@@ -328,7 +328,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   Workspace &w = c->ws;
   DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
-                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
+                   &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
                    &w.soc_dsu, &w.soc_dsc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc};
   for (DevBuf *b : all) b->release();
@@ -920,20 +920,38 @@ int pmpc_particle_costs_device(pmpc_ctx *c, const pmpc_problem *p, const double 
 
 int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose) {
   HIP_CHECK(hipSetDevice(c->device));
-  if (c->world > 1) {
-    fprintf(stderr, "pmpc_hip: pmpc_lcone_solve_device is single-rank (the particle ranking is not exchanged over RCCL)\n");
-    return 2;
-  }
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
-  const size_t M = p->M, D8 = sizeof(double);
+  // particles are sharded in equal contiguous blocks (bench.py's layout): the ranking of the particle costs is global, so
+  // every rank gathers all costs (all-reduce(sum) of a zero-padded vector) and takes the same decisions
+  const size_t Ml = p->M, M = Ml * (size_t)c->world, off = (size_t)c->rank * Ml, D8 = sizeof(double);
   const double eps = 1e-3;  // COST_ANCHOR_EPS, main.jl:223
-  w.pw.ensure(M * D8); w.Jc.ensure(M * D8);
-  std::vector<double> user(M, 1.0), pw(M), J(M);
-  if (p->weights) {
-    HIP_CHECK(hipMemcpyAsync(user.data(), p->weights, M * D8, hipMemcpyDeviceToHost, s));
+  w.pw.ensure(Ml * D8); w.Jc.ensure(Ml * D8); w.Jg.ensure(M * D8);
+  std::vector<double> user(M, 1.0), pw(Ml), J(M), loc(Ml);
+  auto gather = [&](const double *local_dev, std::vector<double> &global) {  // global[rank*Ml + i] = local[i] on every rank
+    if (c->world <= 1) {
+      HIP_CHECK(hipMemcpyAsync(global.data(), local_dev, Ml * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      return;
+    }
+    HIP_CHECK(hipMemsetAsync(w.Jg.p, 0, M * D8, s));
+    HIP_CHECK(hipMemcpyAsync(w.Jg.d() + off, local_dev, Ml * D8, hipMemcpyDeviceToDevice, s));
+    allreduce(c, w.Jg.p, M, ncclFloat64, ncclSum);
+    HIP_CHECK(hipMemcpyAsync(global.data(), w.Jg.p, M * D8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+  };
+  if (c->world > 1) {  // equal shards are assumed by the offsets above
+    double cnt[2] = {(double)Ml, -(double)Ml};
+    HIP_CHECK(hipMemcpyAsync(w.Jg.p, cnt, 2 * D8, hipMemcpyHostToDevice, s));
+    allreduce(c, w.Jg.p, 2, ncclFloat64, ncclMax);
+    HIP_CHECK(hipMemcpyAsync(cnt, w.Jg.p, 2 * D8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (cnt[0] != -cnt[1]) {
+      fprintf(stderr, "pmpc_hip: pmpc_lcone_solve_device needs the same number of particles on every rank\n");
+      return 2;
+    }
   }
+  if (p->weights) gather(p->weights, user);
   pmpc_problem q = *p;
   q.weights = w.pw.d();
   // smooth_cstr = "logbarrier" (main.jl:246-262): -1/alpha sum log(alpha slack) replaces the hard boxes
@@ -946,8 +964,8 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
   const double w_hi = 1.0 + eps, w_thr = (1.0 + eps) * (double)mstar - 2.0 * eps * (double)M, w_floor = 1e-4;
 
   auto solve_with = [&](const std::vector<double> &rankw) -> int {
-    for (size_t i = 0; i < M; i++) pw[i] = user[i] * rankw[i];
-    HIP_CHECK(hipMemcpyAsync(w.pw.p, pw.data(), M * D8, hipMemcpyHostToDevice, s));
+    for (size_t i = 0; i < Ml; i++) pw[i] = user[off + i] * rankw[off + i];
+    HIP_CHECK(hipMemcpyAsync(w.pw.p, pw.data(), Ml * D8, hipMemcpyHostToDevice, s));
     const int st = pmpc_lqp_solve_device(c, &q, &inf, verbose > 1);
     outer++;
     solves_total += inf.structured_solves;
@@ -955,8 +973,7 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
     last = inf;
     if (st != 0) return st;
     pmpc_particle_costs_device(c, p, p->X_out, p->U_out, w.Jc.d());
-    HIP_CHECK(hipMemcpyAsync(J.data(), w.Jc.p, M * D8, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
+    gather(w.Jc.d(), J);
     for (size_t i = 0; i < M; i++) J[i] *= user[i];  // scale_probs_cost! (main.jl:96-112) acts on the costs themselves
     return 0;
   };

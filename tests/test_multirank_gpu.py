@@ -47,7 +47,7 @@ def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False):
             if "slew_reg0" in kw:
                 opt.update(slew_reg0=dev(kw["slew_reg0"]), slew_um1=dev(kw["slew_um1"]))
             for _ in range(repeats):  # repeats > 1: the second solve is warm-started on every rank
-                X, U, status = s.lqp_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
+                X, U, status = (s.lcone_solve if cone else s.lqp_solve)(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
                                            X_ref=dev(X_ref), U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc,
                                            symmetric_cost=True, **opt)
                 s.sync()
@@ -113,3 +113,21 @@ def test_eight_ranks_quadrotor_shape(oracle):
     Xw, Uw, infos = _solve_sharded(args, kw, 1, 8, repeats=2)
     assert np.linalg.norm(Xw - Xo) / np.linalg.norm(Xo) < 1e-7 and np.linalg.norm(Uw - Uo) / np.linalg.norm(Uo) < 1e-7
     assert np.all(Uw[:, :1] == Uw[0:1, :1]) and len({i["ipm_iters"] for i in infos}) == 1
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("kink", [False, True])
+def test_sharded_cone_path_matches_cone_oracle(world, kink, oracle):
+    """`pmpc_lcone_solve_device` on sharded particles: the particle costs are gathered so that every rank ranks them
+    identically (threshold particle, kink bisection) — against the cone oracle on the whole ensemble."""
+    from tests.test_cone_gpu import _make_kink
+
+    M, N, x, u, Nc = 60, 6, 4, 2, 1
+    args, kw = rand_problem(np.random.default_rng(4005), M, N, x, u, 1.0)
+    if kink:
+        args, kw = _make_kink(oracle, args, kw, Nc)
+    Xo, Uo, info = oracle.lcone_solve_py(*args, Nc=Nc, return_info=True, **kw)
+    assert bool(info.get("kink", False)) == kink
+    Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, cone=True)
+    assert np.linalg.norm(Xw - Xo) / np.linalg.norm(Xo) < 1e-6 and np.linalg.norm(Uw - Uo) / np.linalg.norm(Uo) < 1e-6
+    assert len({i["outer_solves"] for i in infos}) == 1 and infos[0]["outer_solves"] >= 2
