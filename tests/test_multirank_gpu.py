@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 _group = [1000]
 
 
-def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False):
+def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None):
     import torch
 
     from pmpc_amd import _lib
@@ -47,7 +47,11 @@ def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False):
             if "slew_reg0" in kw:
                 opt.update(slew_reg0=dev(kw["slew_reg0"]), slew_um1=dev(kw["slew_um1"]))
             for _ in range(repeats):  # repeats > 1: the second solve is warm-started on every rank
-                X, U, status = (s.lcone_solve if cone else s.lqp_solve)(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
+                if soc is not None:
+                    full = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device="cuda")
+                    opt.update(soc_W=full(soc["W"]), soc_w0=full(soc["w0"]), soc_v=full(soc["v"]), soc_v0=soc["v0"],
+                               soc_u_interior=full(soc["u_interior"]))
+                X, U, status = (s.lsoc_solve if soc is not None else (s.lcone_solve if cone else s.lqp_solve))(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
                                            X_ref=dev(X_ref), U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc,
                                            symmetric_cost=True, **opt)
                 s.sync()
@@ -131,3 +135,16 @@ def test_sharded_cone_path_matches_cone_oracle(world, kink, oracle):
     Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, cone=True)
     assert np.linalg.norm(Xw - Xo) / np.linalg.norm(Xo) < 1e-6 and np.linalg.norm(Uw - Uo) / np.linalg.norm(Uo) < 1e-6
     assert len({i["outer_solves"] for i in infos}) == 1 and infos[0]["outer_solves"] >= 2
+
+
+@pytest.mark.parametrize("Nc", [0, 1, -1])
+def test_sharded_stage_cones_match_oracle(Nc, oracle):
+    """`pmpc_lsoc_solve_device` on 2 ranks: the complementarity sums, step lengths and failure flag cross ranks."""
+    M, N, x, u = 6, 7, 5, 3
+    args, kw = rand_problem(np.random.default_rng(77), M, N, x, u, 0.6)
+    W = np.zeros((2, 3)); W[0, 1] = W[1, 2] = 1.0
+    soc = dict(W=W, w0=np.zeros(2), v=np.array([0.5, 0, 0]), v0=0.05, u_interior=np.array([0.2, 0, 0]))
+    Xo, Uo = oracle.lsoc_solve_py(*args, Nc=Nc, reg_x=kw["reg_x"], reg_u=kw["reg_u"], u_l=kw["u_l"], u_u=kw["u_u"], soc_W=W,
+                                  soc_w0=soc["w0"], soc_v=soc["v"], soc_v0=soc["v0"], u_interior=soc["u_interior"])
+    Xw, Uw, _ = _solve_sharded(args, kw, Nc, 2, repeats=2, soc=soc)
+    assert np.linalg.norm(Xw - Xo) / np.linalg.norm(Xo) < 1e-6 and np.linalg.norm(Uw - Uo) / np.linalg.norm(Uo) < 1e-6
