@@ -792,7 +792,9 @@ void launch_rollout_t(const LQArgs &a, const double *U, double *X, hipStream_t s
 }  // namespace
 
 // (xdim, udim) pairs with compiled instances
-#define PMPC_FAST_DIMS(X) X(12, 4) X(4, 2) X(2, 1) X(3, 2) X(5, 3) X(6, 2) X(8, 4)
+#define PMPC_FAST_DIMS(X)                                                                                          \
+  X(12, 4) X(12, 3) X(12, 2) X(10, 4) X(10, 2) X(9, 4) X(9, 3) X(8, 4) X(8, 2) X(7, 3) X(6, 4) X(6, 3) X(6, 2) X(5, 3) \
+  X(5, 2) X(4, 4) X(4, 3) X(4, 2) X(4, 1) X(3, 3) X(3, 2) X(3, 1) X(2, 2) X(2, 1) X(1, 1)
 
 bool lq_fast_supported(const LQArgs &a) {
   if (a.w != 0 || a.any_slew || !a.sym_cost) return false;
