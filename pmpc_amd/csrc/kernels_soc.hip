@@ -16,6 +16,10 @@
 // block R instead would make the kernels form R_eff (u - u_ref) and cancel 1e12-sized terms against the shift.)  The slacks are variables of their own (s += alpha ds, residual rp = A u + c - s
 // carried in the Newton system: ds = A du + rp, wu += A' W_nt^-2 rp): recomputing hi - u at slack ~ mu/z ~ 1e-11 would tie
 // their positivity to the last bits of u and stall the iteration near mu = 1e-10.  The step length keeps s, z inside K.
+// Each iteration is a Mehrotra predictor-corrector pair on ONE factorisation: the predictor (sigma = 0) gives the affine step,
+// the step polynomial mu_aff(alpha) = (S0 + alpha S1 + alpha^2 S2)/deg and the second-order term — c = ds*dz for a box side,
+// c = W^-1 (lambda \ ((W^-1 ds) o (W dz))) for the cone (lambda = W z = W^-1 s, o and \ the Jordan product and division) —
+// and the corrector solves only for the DIFFERENCE step with the gradient  A'(-sigma mu s^-1 + c)  (vector sweeps).
 // Consensus stages carry ONE shared control: its constraints are counted once, on the owner rank's particle 0.
 #include "pmpc_dev.h"
 
@@ -57,12 +61,44 @@ __device__ __forceinline__ double cone_ratio(const double *x, const double *d, i
   return al;
 }
 
+// NT scaling of one cone pair (s, z): wb, eta, and products with W, W^-1, W^-2
+struct NtScal {
+  double wb[1 + QMAX], eta, ieta2;
+  __device__ void init(const double *s, const double *z, int q) {
+    const double ss = jdot(s, s, q), zz = jdot(z, z, q), rs = 1.0 / sqrt(ss), rz = 1.0 / sqrt(zz);
+    double dotb = 0.0;
+    for (int p = 0; p <= q; p++) dotb += s[p] * z[p] * rs * rz;
+    const double ig = 0.5 / sqrt(0.5 * (1.0 + dotb));
+    wb[0] = (s[0] * rs + z[0] * rz) * ig;
+    for (int p = 1; p <= q; p++) wb[p] = (s[p] * rs - z[p] * rz) * ig;
+    ieta2 = sqrt(zz / ss);
+    eta = sqrt(sqrt(ss / zz));
+  }
+  // W x = eta [wb0 x0 + wb1'x1 ; x0 wb1 + x1 + wb1 (wb1'x1)/(1 + wb0)],  W^-1 x: same with wb1 -> -wb1 and 1/eta
+  __device__ void mulW(const double *x, double *y, int q, bool inverse) const {
+    const double sg = inverse ? -1.0 : 1.0, sc = inverse ? 1.0 / eta : eta;
+    double d = 0.0;
+    for (int p = 1; p <= q; p++) d += wb[p] * x[p];
+    y[0] = sc * (wb[0] * x[0] + sg * d);
+    for (int p = 1; p <= q; p++) y[p] = sc * (sg * x[0] * wb[p] + x[p] + wb[p] * d / (1.0 + wb[0]));
+  }
+  __device__ void mulWm2(const double *x, double *y, int q) const {  // W^-2 x = ieta2 (2 (J wb)(J wb)'x - J x)
+    double jw = wb[0] * x[0];
+    for (int p = 1; p <= q; p++) jw -= wb[p] * x[p];
+    y[0] = ieta2 * (2.0 * wb[0] * jw - x[0]);
+    for (int p = 1; p <= q; p++) y[p] = ieta2 * (-2.0 * wb[p] * jw + x[p]);
+  }
+};
+
 // MODE 0: s = A u + c, z = mu s^-1 (centred start);  MODE 2: s = A u + c, z kept (warm start from remembered duals);
-// MODE 1: Hadd, wu from (U, s, z);  sums s'z and counts in every mode
+// MODE 1: Newton-system inputs from (U, s, z) — predictor (a.corr == 0): Hadd = A'W^-2 A and wu = A'W^-2 rp (sigma = 0);
+// corrector (a.corr == 1): wu = the DIFFERENCE of the gradient shifts, A'(-sigma mu s^-1 + c), Hadd left as it is.
+// Sums s'z and the cone count in every mode.
 template <int MODE>
 __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum, double *part_cnt) {
   __shared__ double sh[TB];
   const long long tot = (long long)a.M * a.N;
+  const bool corr = MODE == 1 && a.corr;
   double comp = 0.0, cnt = 0.0;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
     const int i = (int)(k / a.N), j = (int)(k % a.N), u = a.u, q = a.q;
@@ -70,7 +106,8 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
     double *Ha = a.Hadd + k * u * u, *wu = a.wu + k * u;
     if (!soc_counts(a, i, j)) {
       if (MODE == 1) {
-        for (int e = 0; e < u * u; e++) Ha[e] = 0.0;
+        if (!corr)
+          for (int e = 0; e < u * u; e++) Ha[e] = 0.0;
         for (int r = 0; r < u; r++) wu[r] = 0.0;
       }
       continue;
@@ -91,7 +128,8 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
           const double s = a.sl[k * u + r], z = a.zl[k * u + r], rp = (uu[r] - lo) - s, d = z / s;
           ok &= (s > 0.0) && (z > 0.0);
           comp += s * z; cnt += 1.0;
-          g[r] += -a.sigmu / s + d * rp; H[r][r] += d;   // A = +e_r
+          if (corr) g[r] += -(a.sigmu - a.cl[k * u + r]) / s;  // A = +e_r
+          else { g[r] += d * rp; H[r][r] += d; }
         }
         if (isfinite(hi)) {
           if (MODE != 1) a.su[k * u + r] = hi - uu[r];
@@ -99,12 +137,13 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
           const double s = a.su[k * u + r], z = a.zu[k * u + r], rp = (hi - uu[r]) - s, d = z / s;
           ok &= (s > 0.0) && (z > 0.0);
           comp += s * z; cnt += 1.0;
-          g[r] -= -a.sigmu / s + d * rp; H[r][r] += d;   // A = -e_r
+          if (corr) g[r] -= -(a.sigmu - a.cu[k * u + r]) / s;  // A = -e_r
+          else { g[r] -= d * rp; H[r][r] += d; }
         }
       }
     }
     if (q > 0) {
-      double s[1 + QMAX], z[1 + QMAX], wb[1 + QMAX], rp[1 + QMAX];
+      double s[1 + QMAX], z[1 + QMAX], rp[1 + QMAX], t[1 + QMAX];
       double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
       cone_slack(a, uu, rp);  // A u + c
       if (MODE != 1)
@@ -115,53 +154,46 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
         for (int p = 1; p <= q; p++) zc[p] = -a.mu * rp[p] / ss0;
       }
       for (int p = 0; p <= q; p++) { s[p] = sc[p]; rp[p] -= s[p]; z[p] = zc[p]; }
-      const double ss = jdot(s, s, q);
-      ok &= (s[0] > 0.0) && (ss > 0.0);
-      const double zz = jdot(z, z, q);
-      ok &= (z[0] > 0.0) && (zz > 0.0);
+      const double ss = jdot(s, s, q), zz = jdot(z, z, q);
+      ok &= (s[0] > 0.0) && (ss > 0.0) && (z[0] > 0.0) && (zz > 0.0);
       double sz = 0.0;
       for (int p = 0; p <= q; p++) sz += s[p] * z[p];
       comp += sz; cnt += 1.0;
-      // NT scaling point: sb = s/sqrt(ss), zb = z/sqrt(zz), gam = sqrt((1 + sb'zb)/2), wb = (sb + J zb)/(2 gam)
-      const double rs = 1.0 / sqrt(ss), rz = 1.0 / sqrt(zz);
-      double dotb = 0.0;
-      for (int p = 0; p <= q; p++) dotb += s[p] * z[p] * rs * rz;
-      const double gam = sqrt(0.5 * (1.0 + dotb)), ig = 0.5 / gam;
-      wb[0] = (s[0] * rs + z[0] * rz) * ig;
-      for (int p = 1; p <= q; p++) wb[p] = (s[p] * rs - z[p] * rz) * ig;
-      const double ieta2 = sqrt(zz / ss);  // 1 / eta^2
-      // W^-2 = ieta2 (2 (J wb)(J wb)' - J);  rows of A: a_0 = v, a_p = W[p-1, :]
-      // s^-1 = J s / ss
-      double Jw[1 + QMAX], sinv[1 + QMAX];
-      Jw[0] = wb[0]; sinv[0] = s[0] / ss;
-      for (int p = 1; p <= q; p++) { Jw[p] = -wb[p]; sinv[p] = -s[p] / ss; }
-      // W^-2 rp = ieta2 (2 (Jwb)(Jwb)'rp - J rp)
-      double jwrp = 0.0, w2rp[1 + QMAX];
-      for (int p = 0; p <= q; p++) jwrp += Jw[p] * rp[p];
-      w2rp[0] = ieta2 * (2.0 * Jw[0] * jwrp - rp[0]);
-      for (int p = 1; p <= q; p++) w2rp[p] = ieta2 * (2.0 * Jw[p] * jwrp + rp[p]);
-      double Aw[UMAX];  // A' (J wb)
-      for (int r = 0; r < u; r++) {
-        double t = a.v[r] * Jw[0], gs = a.v[r] * (-a.sigmu * sinv[0] + w2rp[0]);
-        for (int p = 1; p <= q; p++) {
-          t += a.W[(p - 1) * u + r] * Jw[p];
-          gs += a.W[(p - 1) * u + r] * (-a.sigmu * sinv[p] + w2rp[p]);
+      if (MODE == 1) {
+        if (corr) {  // t = -sigma mu s^-1 + c,  s^-1 = J s / s'Js
+          const double *cc = a.cc + k * (q + 1);
+          t[0] = -a.sigmu * s[0] / ss + cc[0];
+          for (int p = 1; p <= q; p++) t[p] = a.sigmu * s[p] / ss + cc[p];
+        } else {
+          NtScal nt;
+          nt.init(s, z, q);
+          nt.mulWm2(rp, t, q);  // t = W^-2 rp
+          double Aw[UMAX];      // A'(J wb)
+          for (int r = 0; r < u; r++) {
+            double v = a.v[r] * nt.wb[0];
+            for (int p = 1; p <= q; p++) v -= a.W[(p - 1) * u + r] * nt.wb[p];
+            Aw[r] = v;
+          }
+          for (int r = 0; r < u; r++)
+            for (int c2 = 0; c2 < u; c2++) {
+              double AJA = a.v[r] * a.v[c2];  // A'JA
+              for (int p = 1; p <= q; p++) AJA -= a.W[(p - 1) * u + r] * a.W[(p - 1) * u + c2];
+              H[r][c2] += nt.ieta2 * (2.0 * Aw[r] * Aw[c2] - AJA);
+            }
         }
-        Aw[r] = t;
-        g[r] += gs;
+        for (int r = 0; r < u; r++) {  // g += A't
+          double v = a.v[r] * t[0];
+          for (int p = 1; p <= q; p++) v += a.W[(p - 1) * u + r] * t[p];
+          g[r] += v;
+        }
       }
-      for (int r = 0; r < u; r++)
-        for (int t = 0; t < u; t++) {
-          double AJA = a.v[r] * a.v[t];  // A' J A
-          for (int p = 1; p <= q; p++) AJA -= a.W[(p - 1) * u + r] * a.W[(p - 1) * u + t];
-          H[r][t] += ieta2 * (2.0 * Aw[r] * Aw[t] - AJA);
-        }
     }
     if (!ok) *a.fail = 3;
     if (MODE == 1) {
       for (int r = 0; r < u; r++) {
         wu[r] = g[r];
-        for (int t = 0; t < u; t++) Ha[r + u * t] = H[r][t];
+        if (!corr)
+          for (int t = 0; t < u; t++) Ha[r + u * t] = H[r][t];
       }
     }
   }
@@ -176,56 +208,77 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
   if (threadIdx.x == 0) part_cnt[blockIdx.x] = sh[0];
 }
 
-// steps ds = A du + rp, dz = sigma mu s^-1 - z - W^-2 ds, stored; largest alpha in (0, 2] keeping s and z inside K
-__global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *amin_bits) {
+// Steps ds = A du + rp, dz = (sigma mu s^-1 - c) - z - W^-2 ds of every cone (du = dU, or dU + dU2 in the corrector), stored;
+// largest alpha in (0, 2] keeping s and z inside K.  The predictor (a.corr == 0, sigma mu = 0, c = 0) also stores the
+// second-order terms c and the partial sums S1 = sum (s'dz + z'ds), S2 = sum ds'dz of the step polynomial.
+__global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *amin_bits, double *part_s1, double *part_s2) {
   __shared__ double sh[TB];
   const long long tot = (long long)a.M * a.N;
+  const bool corr = a.corr != 0;
   double al = 2.0;  // (the host takes min(1, 0.99 * this): a step that would end ON a boundary just beyond 1 is shortened too)
+  double s1 = 0.0, s2 = 0.0;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
     const int i = (int)(k / a.N), j = (int)(k % a.N), u = a.u, q = a.q;
-    const double *U = a.U + k * u, *dU = a.dU + k * u;
-    const bool counts = soc_counts(a, i, j);  // (the copies of a shared control take the same step: nothing to test)
+    if (!soc_counts(a, i, j)) continue;  // (the copies of a shared control take the same step: nothing to test)
+    double uu[UMAX], du[UMAX];
+    for (int r = 0; r < u; r++) {
+      uu[r] = a.U[k * u + r];
+      du[r] = a.dU[k * u + r] + (corr ? a.dU2[k * u + r] : 0.0);
+    }
     if (a.lo) {
       for (int r = 0; r < u; r++) {
-        const double lo = a.lo[k * u + r], hi = a.hi[k * u + r], d = dU[r];
-        if (isfinite(lo) && counts) {
-          const double s = a.sl[k * u + r], z = a.zl[k * u + r], ds = d + ((U[r] - lo) - s);
-          const double dz = a.sigmu / s - z - (z / s) * ds;
+        const double lo = a.lo[k * u + r], hi = a.hi[k * u + r];
+        if (isfinite(lo)) {
+          const double s = a.sl[k * u + r], z = a.zl[k * u + r], ds = du[r] + ((uu[r] - lo) - s);
+          const double dz = (a.sigmu - (corr ? a.cl[k * u + r] : 0.0)) / s - z - (z / s) * ds;
           a.dsl[k * u + r] = ds; a.dzl[k * u + r] = dz;
+          if (!corr) { a.cl[k * u + r] = ds * dz; s1 += s * dz + z * ds; s2 += ds * dz; }
           if (ds < 0.0) al = fmin(al, s / -ds);
           if (dz < 0.0) al = fmin(al, z / -dz);
         }
-        if (isfinite(hi) && counts) {
-          const double s = a.su[k * u + r], z = a.zu[k * u + r], ds = -d + ((hi - U[r]) - s);
-          const double dz = a.sigmu / s - z - (z / s) * ds;
+        if (isfinite(hi)) {
+          const double s = a.su[k * u + r], z = a.zu[k * u + r], ds = -du[r] + ((hi - uu[r]) - s);
+          const double dz = (a.sigmu - (corr ? a.cu[k * u + r] : 0.0)) / s - z - (z / s) * ds;
           a.dsu[k * u + r] = ds; a.dzu[k * u + r] = dz;
+          if (!corr) { a.cu[k * u + r] = ds * dz; s1 += s * dz + z * ds; s2 += ds * dz; }
           if (ds < 0.0) al = fmin(al, s / -ds);
           if (dz < 0.0) al = fmin(al, z / -dz);
         }
       }
     }
-    if (q > 0 && counts) {
-      double uu[UMAX], du[UMAX], s[1 + QMAX], ds[1 + QMAX], z[1 + QMAX], dz[1 + QMAX], wb[1 + QMAX];
-      for (int r = 0; r < u; r++) { uu[r] = U[r]; du[r] = dU[r]; }
+    if (q > 0) {
+      double s[1 + QMAX], ds[1 + QMAX], z[1 + QMAX], dz[1 + QMAX], t[1 + QMAX];
       const double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
+      double *cc = a.cc + k * (q + 1);
       cone_slack(a, uu, ds);  // A u + c
       for (int p = 0; p <= q; p++) { s[p] = sc[p]; ds[p] -= s[p]; z[p] = zc[p]; }  // ds = rp so far
       for (int r = 0; r < u; r++) ds[0] += a.v[r] * du[r];
       for (int p = 1; p <= q; p++)
         for (int r = 0; r < u; r++) ds[p] += a.W[(p - 1) * u + r] * du[r];
-      const double ss = jdot(s, s, q), zz = jdot(z, z, q), rs = 1.0 / sqrt(ss), rz = 1.0 / sqrt(zz);
-      double dotb = 0.0;
-      for (int p = 0; p <= q; p++) dotb += s[p] * z[p] * rs * rz;
-      const double gam = sqrt(0.5 * (1.0 + dotb)), ig = 0.5 / gam, ieta2 = sqrt(zz / ss);
-      wb[0] = (s[0] * rs + z[0] * rz) * ig;
-      for (int p = 1; p <= q; p++) wb[p] = (s[p] * rs - z[p] * rz) * ig;
-      // W^-2 ds = ieta2 (2 (Jwb)(Jwb)'ds - J ds)
-      double jwds = wb[0] * ds[0];
-      for (int p = 1; p <= q; p++) jwds -= wb[p] * ds[p];
-      dz[0] = a.sigmu * s[0] / ss - z[0] - ieta2 * (2.0 * wb[0] * jwds - ds[0]);
-      for (int p = 1; p <= q; p++) dz[p] = -a.sigmu * s[p] / ss - z[p] - ieta2 * (2.0 * (-wb[p]) * jwds + ds[p]);
+      NtScal nt;
+      nt.init(s, z, q);
+      nt.mulWm2(ds, t, q);
+      const double ss = jdot(s, s, q);
+      dz[0] = a.sigmu * s[0] / ss - z[0] - t[0] - (corr ? cc[0] : 0.0);
+      for (int p = 1; p <= q; p++) dz[p] = -a.sigmu * s[p] / ss - z[p] - t[p] - (corr ? cc[p] : 0.0);
       double *dsc = a.dsc + k * (q + 1), *dzc = a.dzc + k * (q + 1);
       for (int p = 0; p <= q; p++) { dsc[p] = ds[p]; dzc[p] = dz[p]; }
+      if (!corr) {
+        // c = W^-1 (lambda \ ((W^-1 ds) o (W dz))),  lambda = W z
+        double lam[1 + QMAX], x[1 + QMAX], y[1 + QMAX], pr[1 + QMAX], dv[1 + QMAX];
+        nt.mulW(z, lam, q, false);
+        nt.mulW(ds, x, q, true);
+        nt.mulW(dz, y, q, false);
+        pr[0] = 0.0;
+        for (int p = 0; p <= q; p++) pr[0] += x[p] * y[p];
+        for (int p = 1; p <= q; p++) pr[p] = x[0] * y[p] + y[0] * x[p];
+        double ll = 0.0, lr = 0.0;
+        for (int p = 1; p <= q; p++) { ll += lam[p] * lam[p]; lr += lam[p] * pr[p]; }
+        dv[0] = (lam[0] * pr[0] - lr) / (lam[0] * lam[0] - ll);
+        for (int p = 1; p <= q; p++) dv[p] = (pr[p] - dv[0] * lam[p]) / lam[0];
+        nt.mulW(dv, t, q, true);
+        for (int p = 0; p <= q; p++) { cc[p] = t[p]; s1 += s[p] * dz[p] + z[p] * ds[p]; s2 += ds[p] * dz[p]; }
+      }
       al = fmin(al, cone_ratio(s, ds, q, 2.0));
       al = fmin(al, cone_ratio(z, dz, q, 2.0));
     }
@@ -240,6 +293,18 @@ __global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *
     double v = sh[0];
     if (!(v >= 0.0)) v = 0.0;
     atomicMin(amin_bits, (unsigned long long)__double_as_longlong(v));
+  }
+  if (!corr) {
+    __syncthreads();
+    sh[threadIdx.x] = s1;
+    __syncthreads();
+    for (int o = TB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part_s1[blockIdx.x] = sh[0];
+    __syncthreads();
+    sh[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = TB / 2; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part_s2[blockIdx.x] = sh[0];
   }
 }
 
@@ -262,8 +327,10 @@ int launch_soc_prepare(const SocArgs &a, int mode, double *part_sum, double *par
   else hipLaunchKernelGGL(k_soc_prepare<1>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
   return (int)g;
 }
-void launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, hipStream_t s) {
-  hipLaunchKernelGGL(k_soc_step, dim3(soc_grid(a)), dim3(TB), 0, s, a, amin_bits);
+int launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, double *part_s1, double *part_s2, hipStream_t s) {
+  const unsigned g = soc_grid(a);
+  hipLaunchKernelGGL(k_soc_step, dim3(g), dim3(TB), 0, s, a, amin_bits, part_s1, part_s2);
+  return (int)g;
 }
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s) {
   long long b = (tot + TB - 1) / TB;

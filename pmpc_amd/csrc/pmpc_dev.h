@@ -143,7 +143,9 @@ void launch_ipm_exchange(int phase, bool pack, bool unpack, IpmScal *sc, const i
 // ---- kernels_soc.hip (stage-wise second-order cones on the controls, primal-dual path following) ------------------
 struct SocArgs {
   int M, N, u, Nc, q, owner;
-  const double *U, *dU;              // iterate, Newton step
+  const double *U, *dU, *dU2;        // iterate, predictor step, corrector difference step
+  int corr;                          // 0 predictor pass, 1 corrector pass
+  double *cl, *cu, *cc;              // second-order terms of the box sides (M,N,u) and of the cone (M,N,q+1)
   const double *lo, *hi;             // control boxes (M,N,u) or null
   const double *W, *w0, *v;          // cone || W u + w0 || <= v'u + v0: W (q x u) row-major, w0 (q), v (u); device
   double v0, mu, sigmu;
@@ -155,7 +157,7 @@ struct SocArgs {
 };
 // mode 0: cold start (s from u, z = mu s^-1), 2: warm start (s from u, z kept), 1: Newton system blocks from (u, s, z)
 int launch_soc_prepare(const SocArgs &a, int mode, double *part_sum, double *part_cnt, hipStream_t s);
-void launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, hipStream_t s);
+int launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, double *part_s1, double *part_s2, hipStream_t s);
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s);
 
 // ---- dynamics.hip -------------------------------------------------------------------------------

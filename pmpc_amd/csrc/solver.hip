@@ -138,6 +138,7 @@ struct Workspace {
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc, Jg;  // cone path: particle weights / particle costs (local, gathered)
   DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
+  DevBuf soc_cl, soc_cu, soc_cc;  // second-order (Mehrotra) terms
   DevBuf soc_wU, soc_wzl, soc_wzu, soc_wzc;  // remembered early iterate (warm start of the cone path)
   long long soc_key = -1;
   DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift
@@ -330,7 +331,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -584,18 +585,19 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     const int q = (int)p->soc_q;
     w.Hadd.ensure(nu * u * D8); w.wu_soc.ensure(nu * D8);
     const size_t ncz = (size_t)M * N * (q + 1);
-    for (DevBuf *b : {&w.soc_zl, &w.soc_zu, &w.soc_dzl, &w.soc_dzu, &w.soc_sl, &w.soc_su, &w.soc_dsl, &w.soc_dsu}) {
+    for (DevBuf *b : {&w.soc_zl, &w.soc_zu, &w.soc_dzl, &w.soc_dzu, &w.soc_sl, &w.soc_su, &w.soc_dsl, &w.soc_dsu, &w.soc_cl, &w.soc_cu}) {
       b->ensure(nu * D8);
       HIP_CHECK(hipMemsetAsync(b->p, 0, nu * D8, s));
     }
-    for (DevBuf *b : {&w.soc_zc, &w.soc_dzc, &w.soc_sc, &w.soc_dsc}) {
+    for (DevBuf *b : {&w.soc_zc, &w.soc_dzc, &w.soc_sc, &w.soc_dsc, &w.soc_cc}) {
       b->ensure(ncz * D8);
       HIP_CHECK(hipMemsetAsync(b->p, 0, ncz * D8, s));
     }
     SocArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.M = M; sa.N = N; sa.u = u; sa.Nc = Nc; sa.q = q; sa.owner = a.owner;
-    sa.U = w.U.d(); sa.dU = w.dU.d();
+    sa.U = w.U.d(); sa.dU = w.dU.d(); sa.dU2 = w.dU2.d();
+    sa.cl = w.soc_cl.d(); sa.cu = w.soc_cu.d(); sa.cc = w.soc_cc.d();
     sa.lo = has_ub ? su.lo : nullptr; sa.hi = has_ub ? su.hi : nullptr;
     sa.W = p->soc_W; sa.w0 = p->soc_w0; sa.v = p->soc_v; sa.v0 = p->soc_v0;
     sa.zl = w.soc_zl.d(); sa.zu = w.soc_zu.d(); sa.zc = w.soc_zc.d();
@@ -609,6 +611,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     a.wu = w.wu_soc.d();
     const unsigned long long one_bits = 0x4000000000000000ull;  // 2.0: upper end of the step kernel's search
     std::vector<double> hs(PMPC_RED_BLOCKS), hc(PMPC_RED_BLOCKS);
+    double cone_cnt = 1.0;  // number of cones (degree of the complementarity measure), all ranks
     struct { unsigned long long amin; int fail; } host_rd;
     // complementarity mu = sum s'z / (number of cones: one per finite box side, one per stage cone), measured on the
     // device by the prepare kernel; cross-rank: summed
@@ -629,13 +632,11 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         HIP_CHECK(hipStreamSynchronize(s));
         sum = pair[0]; cnt = pair[1];
       }
-      mu_out = sum / std::max(cnt, 1.0);
+      cone_cnt = std::max(cnt, 1.0);
+      mu_out = sum / cone_cnt;
       return host_rd.fail;
     };
-    // centering parameter: halved after every full step, doubled after a blocked one (no predictor solve: the step
-    // length of the last iteration is the cheapest estimate of how well centred the iterate is)
-    double sigma = 0.2;
-    const double mu_tol = 1e-12;
+    const double mu_tol = 1e-12;  // (C mu with C ~ 3e3 on these problems: trajectories within ~3e-9)
     double mu = 1.0;
     int status = 1, newton = 0;
     // warm start as on the box path: the early iterate (mu <= 0.5) of the previous solve of this
@@ -666,39 +667,76 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       goto soc_restart;
     }
     if (fl) return finish(fl == 3 ? 3 : 2);
-    for (int it = 0; it < 200; it++) {
-      sa.mu = mu; sa.sigmu = sigma * mu;
-      nblk = launch_soc_prepare(sa, 1, w.part_sum.d(), w.part_cnt.d(), s);
-      structured_solve(c, a, true, fast);
-      inf.structured_solves++;
-      HIP_CHECK(hipMemcpyAsync(&sc->amin_bits, &one_bits, sizeof(one_bits), hipMemcpyHostToDevice, s));
-      launch_soc_step(sa, &sc->amin_bits, s);
+    // the prepare pass above (cold / warm start) measured mu; from here on the pass that follows every update both
+    // measures mu and builds the predictor system of the next iteration (a.corr = 0, sigma = 0)
+    sa.corr = 0; sa.sigmu = 0.0;
+    nblk = launch_soc_prepare(sa, 1, w.part_sum.d(), w.part_cnt.d(), s);
+    fl = measure(nblk, mu);
+    if (fl) { status = fl == 3 ? 3 : 2; }
+    auto read_step = [&](double &amax) -> int {  // step length of the last step kernel (+ failure flag), across ranks
       if (c->world > 1) allreduce(c, &sc->amin_bits, 1, ncclFloat64, ncclMin);  // bit pattern of a non-negative double
       HIP_CHECK(hipMemcpyAsync(&host_rd.amin, &sc->amin_bits, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(&host_rd.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
-      if (host_rd.fail) { status = host_rd.fail == 3 ? 3 : 2; break; }
-      double amax;
       memcpy(&amax, &host_rd.amin, sizeof(double));
+      return host_rd.fail;
+    };
+    for (int it = 0; it < 100 && status == 1; it++) {
+      // ---- predictor: factorisation, affine step, step polynomial, second-order terms -------------------------------
+      a.dX = w.dX.d(); a.dU = w.dU.d();
+      structured_solve(c, a, true, fast);
+      inf.structured_solves++;
+      HIP_CHECK(hipMemcpyAsync(&sc->amin_bits, &one_bits, sizeof(one_bits), hipMemcpyHostToDevice, s));
+      sa.corr = 0; sa.sigmu = 0.0;
+      nblk = launch_soc_step(sa, &sc->amin_bits, w.part_sum.d(), w.part_cnt.d(), s);
+      HIP_CHECK(hipMemcpyAsync(hs.data(), w.part_sum.p, nblk * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(hc.data(), w.part_cnt.p, nblk * D8, hipMemcpyDeviceToHost, s));
+      double a_aff;
+      if (read_step(a_aff)) { status = 2; break; }
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < nblk; k++) { s1 += hs[k]; s2 += hc[k]; }
+      if (c->world > 1) {
+        double pair[2] = {s1, s2};
+        HIP_CHECK(hipMemcpyAsync(w.xch.p, pair, 2 * D8, hipMemcpyHostToDevice, s));
+        allreduce(c, w.xch.p, 2, ncclFloat64, ncclSum);
+        HIP_CHECK(hipMemcpyAsync(pair, w.xch.p, 2 * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        s1 = pair[0]; s2 = pair[1];
+      }
+      a_aff = std::min(1.0, a_aff);
+      const double mu_aff = mu + a_aff * (s1 + a_aff * s2) / cone_cnt;  // (S0 + a S1 + a^2 S2) / deg
+      double sigma = mu_aff / mu;
+      sigma = std::min(1.0, std::max(0.0, sigma * sigma * sigma));
+      // ---- corrector: difference step on the same factorisation -----------------------------------------------------
+      sa.corr = 1; sa.sigmu = sigma * mu;
+      launch_soc_prepare(sa, 1, w.part_sum.d(), w.part_cnt.d(), s);
+      a.dX = w.dX2.d(); a.dU = w.dU2.d();
+      structured_solve(c, a, false, fast);
+      a.dX = w.dX.d(); a.dU = w.dU.d();
+      HIP_CHECK(hipMemcpyAsync(&sc->amin_bits, &one_bits, sizeof(one_bits), hipMemcpyHostToDevice, s));
+      launch_soc_step(sa, &sc->amin_bits, w.part_sum.d(), w.part_cnt.d(), s);
+      double amax;
+      if (read_step(amax)) { status = 2; break; }
       const double alpha = std::min(1.0, 0.99 * amax);  // strictly inside the cones, also when the boundary is just beyond 1
       if (!(alpha > 0.0)) { status = 2; break; }
-      launch_axpy(w.X.d(), w.dX.d(), alpha, (long long)nx, s);
-      launch_axpy(w.U.d(), w.dU.d(), alpha, (long long)nu, s);
-      launch_axpy(sa.zl, sa.dzl, alpha, (long long)nu, s);
-      launch_axpy(sa.zu, sa.dzu, alpha, (long long)nu, s);
+      for (auto pr : {std::make_pair(w.X.d(), w.dX.d()), std::make_pair(w.X.d(), w.dX2.d())}) launch_axpy(pr.first, pr.second, alpha, (long long)nx, s);
+      for (auto pr : {std::make_pair(w.U.d(), w.dU.d()), std::make_pair(w.U.d(), w.dU2.d()), std::make_pair(sa.zl, sa.dzl),
+                      std::make_pair(sa.zu, sa.dzu), std::make_pair(sa.sl, sa.dsl), std::make_pair(sa.su, sa.dsu)})
+        launch_axpy(pr.first, pr.second, alpha, (long long)nu, s);
       launch_axpy(sa.zc, sa.dzc, alpha, (long long)ncz, s);
-      launch_axpy(sa.sl, sa.dsl, alpha, (long long)nu, s);
-      launch_axpy(sa.su, sa.dsu, alpha, (long long)nu, s);
       launch_axpy(sa.sc, sa.dsc, alpha, (long long)ncz, s);
       newton++;
-      // complementarity of the new iterate (the prepare pass of the next iteration measures it; read it now to decide)
-      sa.mu = mu; sa.sigmu = 0.0;
+      // ---- complementarity of the new iterate + the next predictor system ------------------------------------------
+      sa.corr = 0; sa.sigmu = 0.0;
       nblk = launch_soc_prepare(sa, 1, w.part_sum.d(), w.part_cnt.d(), s);
       double mu_new;
       fl = measure(nblk, mu_new);
-      if (fl) { status = fl == 3 ? 3 : 2; break; }
-      if (verbose) printf("pmpc_hip: soc it %3d  mu %9.3e -> %9.3e  alpha %6.4f  sigma %5.3f\n", newton, mu, mu_new, alpha, sigma);
-      sigma = alpha >= 1.0 ? std::max(0.5 * sigma, 0.02) : std::min(2.0 * sigma, 0.5);
+      if (fl) {  // round-off pushed a pair onto its cone boundary: accept what has been reached if that is the end game
+        status = (mu <= 1e2 * mu_tol) ? 0 : (fl == 3 ? 3 : 2);
+        break;
+      }
+      if (verbose) printf("pmpc_hip: soc it %3d  mu %9.3e -> %9.3e  alpha_aff %6.4f  sigma %8.2e  alpha %6.4f\n", newton, mu, mu_new, a_aff, sigma, alpha);
+      const bool stalled = alpha < 1e-3 && mu <= 1e2 * mu_tol;  // at the precision floor
       mu = mu_new;
       if (!remembered && !soc_warm_off && mu <= 0.5) {
         for (DevBuf *b : {&w.soc_wU, &w.soc_wzl, &w.soc_wzu}) b->ensure(nu * D8);
@@ -710,11 +748,11 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         w.soc_key = skey;
         remembered = true;
       }
-      if (mu <= mu_tol) { status = 0; break; }
+      if (mu <= mu_tol || stalled) { status = 0; break; }
     }
     if (status != 0 && warm) {  // a warm-started run that fails is repeated cold
       if (verbose) printf("pmpc_hip: stage cones: warm-started run failed (status %d), cold start\n", status);
-      warm = false; remembered = false; status = 1; newton = 0; sigma = 0.2;
+      warm = false; remembered = false; status = 1; newton = 0;
       w.soc_key = -1;
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
       goto soc_restart;
