@@ -30,13 +30,13 @@ constexpr int TB = 256, UMAX = 8, QMAX = 4;
 __device__ __forceinline__ bool soc_counts(const SocArgs &a, int i, int j) { return j >= a.Nc || (i == 0 && a.owner); }
 
 // cone slack s = (v'u + v0, W u + w0) of one stage
-__device__ __forceinline__ void cone_slack(const SocArgs &a, const double *u, double *s) {
+__device__ __forceinline__ void cone_slack(const SocArgs &a, const double *uvec, double *s, int u, int q) {
   double s0 = a.v0;
-  for (int r = 0; r < a.u; r++) s0 += a.v[r] * u[r];
+  for (int r = 0; r < u; r++) s0 += a.v[r] * uvec[r];
   s[0] = s0;
-  for (int p = 0; p < a.q; p++) {
+  for (int p = 0; p < q; p++) {
     double bp = a.w0[p];
-    for (int r = 0; r < a.u; r++) bp += a.W[p * a.u + r] * u[r];
+    for (int r = 0; r < u; r++) bp += a.W[p * u + r] * uvec[r];
     s[1 + p] = bp;
   }
 }
@@ -94,14 +94,16 @@ struct NtScal {
 // MODE 1: Newton-system inputs from (U, s, z) — predictor (a.corr == 0): Hadd = A'W^-2 A and wu = A'W^-2 rp (sigma = 0);
 // corrector (a.corr == 1): wu = the DIFFERENCE of the gradient shifts, A'(-sigma mu s^-1 + c), Hadd left as it is.
 // Sums s'z and the cone count in every mode.
-template <int MODE>
+// UDT / QT: compile-time udim / cone rows (0 = run-time sizes): with constant trip counts the per-stage arrays stay in
+// registers; with run-time bounds they live in scratch memory and the pass is ~3x slower
+template <int MODE, int UDT, int QT>
 __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum, double *part_cnt) {
   __shared__ double sh[TB];
   const long long tot = (long long)a.M * a.N;
   const bool corr = MODE == 1 && a.corr;
   double comp = 0.0, cnt = 0.0;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
-    const int i = (int)(k / a.N), j = (int)(k % a.N), u = a.u, q = a.q;
+    const int i = (int)(k / a.N), j = (int)(k % a.N), u = UDT ? UDT : a.u, q = UDT ? QT : a.q;
     const double *U = a.U + k * u;
     double *Ha = a.Hadd + k * u * u, *wu = a.wu + k * u;
     if (!soc_counts(a, i, j)) {
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
     if (q > 0) {
       double s[1 + QMAX], z[1 + QMAX], rp[1 + QMAX], t[1 + QMAX];
       double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
-      cone_slack(a, uu, rp);  // A u + c
+      cone_slack(a, uu, rp, u, q);  // A u + c
       if (MODE != 1)
         for (int p = 0; p <= q; p++) sc[p] = rp[p];  // s = A u + c
       if (MODE == 0) {  // z = mu s^-1 = mu J s / (s'Js)
@@ -211,6 +213,7 @@ __global__ void __launch_bounds__(TB) k_soc_prepare(SocArgs a, double *part_sum,
 // Steps ds = A du + rp, dz = (sigma mu s^-1 - c) - z - W^-2 ds of every cone (du = dU, or dU + dU2 in the corrector), stored;
 // largest alpha in (0, 2] keeping s and z inside K.  The predictor (a.corr == 0, sigma mu = 0, c = 0) also stores the
 // second-order terms c and the partial sums S1 = sum (s'dz + z'ds), S2 = sum ds'dz of the step polynomial.
+template <int UDT, int QT>
 __global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *amin_bits, double *part_s1, double *part_s2) {
   __shared__ double sh[TB];
   const long long tot = (long long)a.M * a.N;
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *
   double al = 2.0;  // (the host takes min(1, 0.99 * this): a step that would end ON a boundary just beyond 1 is shortened too)
   double s1 = 0.0, s2 = 0.0;
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) {
-    const int i = (int)(k / a.N), j = (int)(k % a.N), u = a.u, q = a.q;
+    const int i = (int)(k / a.N), j = (int)(k % a.N), u = UDT ? UDT : a.u, q = UDT ? QT : a.q;
     if (!soc_counts(a, i, j)) continue;  // (the copies of a shared control take the same step: nothing to test)
     double uu[UMAX], du[UMAX];
     for (int r = 0; r < u; r++) {
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *
       double s[1 + QMAX], ds[1 + QMAX], z[1 + QMAX], dz[1 + QMAX], t[1 + QMAX];
       const double *sc = a.sc + k * (q + 1), *zc = a.zc + k * (q + 1);
       double *cc = a.cc + k * (q + 1);
-      cone_slack(a, uu, ds);  // A u + c
+      cone_slack(a, uu, ds, u, q);  // A u + c
       for (int p = 0; p <= q; p++) { s[p] = sc[p]; ds[p] -= s[p]; z[p] = zc[p]; }  // ds = rp so far
       for (int r = 0; r < u; r++) ds[0] += a.v[r] * du[r];
       for (int p = 1; p <= q; p++)
@@ -308,6 +311,19 @@ __global__ void __launch_bounds__(TB) k_soc_step(SocArgs a, unsigned long long *
   }
 }
 
+// the whole update in one launch: X += alpha (dX + dX2), U += alpha (dU + dU2), every slack / dual += alpha * its step
+__global__ void __launch_bounds__(TB) k_soc_update(SocArgs a, double alpha, double *X, const double *dX, const double *dX2, double *U,
+                                                   long long nx, long long nu, long long ncz) {
+  const long long stride = (long long)gridDim.x * TB, t0 = blockIdx.x * (long long)TB + threadIdx.x;
+  for (long long k = t0; k < nx; k += stride) X[k] += alpha * (dX[k] + dX2[k]);
+  for (long long k = t0; k < nu; k += stride) {
+    U[k] += alpha * (a.dU[k] + a.dU2[k]);
+    a.sl[k] += alpha * a.dsl[k]; a.su[k] += alpha * a.dsu[k];
+    a.zl[k] += alpha * a.dzl[k]; a.zu[k] += alpha * a.dzu[k];
+  }
+  for (long long k = t0; k < ncz; k += stride) { a.sc[k] += alpha * a.dsc[k]; a.zc[k] += alpha * a.dzc[k]; }
+}
+
 __global__ void k_soc_fill_u(double *U, const double *u0, long long tot, int u) {
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < tot; k += (long long)gridDim.x * TB) U[k] = u0[k % u];
 }
@@ -320,17 +336,35 @@ static unsigned soc_grid(const SocArgs &a) {
   return (unsigned)b;
 }
 // every launch runs exactly PMPC_RED_BLOCKS-bounded grids and fills part_sum / part_cnt [0, grid): returns the grid size
+// compiled (udim, cone rows) pairs; anything else takes the run-time-size instance
+#define PMPC_SOC_DIMS(X) X(4, 2) X(4, 3) X(4, 1) X(3, 2) X(3, 1) X(2, 1)
+template <int UDT, int QT>
+static void soc_prepare_t(const SocArgs &a, int mode, unsigned g, double *ps, double *pc, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL((k_soc_prepare<0, UDT, QT>), dim3(g), dim3(TB), 0, s, a, ps, pc);
+  else if (mode == 2) hipLaunchKernelGGL((k_soc_prepare<2, UDT, QT>), dim3(g), dim3(TB), 0, s, a, ps, pc);
+  else hipLaunchKernelGGL((k_soc_prepare<1, UDT, QT>), dim3(g), dim3(TB), 0, s, a, ps, pc);
+}
 int launch_soc_prepare(const SocArgs &a, int mode, double *part_sum, double *part_cnt, hipStream_t s) {
   const unsigned g = soc_grid(a);
-  if (mode == 0) hipLaunchKernelGGL(k_soc_prepare<0>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
-  else if (mode == 2) hipLaunchKernelGGL(k_soc_prepare<2>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
-  else hipLaunchKernelGGL(k_soc_prepare<1>, dim3(g), dim3(TB), 0, s, a, part_sum, part_cnt);
+#define X(ud, qq) if (a.u == ud && a.q == qq) { soc_prepare_t<ud, qq>(a, mode, g, part_sum, part_cnt, s); return (int)g; }
+  PMPC_SOC_DIMS(X)
+#undef X
+  soc_prepare_t<0, 0>(a, mode, g, part_sum, part_cnt, s);
   return (int)g;
 }
 int launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, double *part_s1, double *part_s2, hipStream_t s) {
   const unsigned g = soc_grid(a);
-  hipLaunchKernelGGL(k_soc_step, dim3(g), dim3(TB), 0, s, a, amin_bits, part_s1, part_s2);
+#define X(ud, qq) if (a.u == ud && a.q == qq) { hipLaunchKernelGGL((k_soc_step<ud, qq>), dim3(g), dim3(TB), 0, s, a, amin_bits, part_s1, part_s2); return (int)g; }
+  PMPC_SOC_DIMS(X)
+#undef X
+  hipLaunchKernelGGL((k_soc_step<0, 0>), dim3(g), dim3(TB), 0, s, a, amin_bits, part_s1, part_s2);
   return (int)g;
+}
+void launch_soc_update(const SocArgs &a, double alpha, double *X, const double *dX, const double *dX2, double *U, long long nx,
+                       long long nu, long long ncz, hipStream_t s) {
+  long long b = (nx + TB - 1) / TB;
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(k_soc_update, dim3((unsigned)b), dim3(TB), 0, s, a, alpha, X, dX, dX2, U, nx, nu, ncz);
 }
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s) {
   long long b = (tot + TB - 1) / TB;

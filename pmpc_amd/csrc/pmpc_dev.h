@@ -158,6 +158,8 @@ struct SocArgs {
 // mode 0: cold start (s from u, z = mu s^-1), 2: warm start (s from u, z kept), 1: Newton system blocks from (u, s, z)
 int launch_soc_prepare(const SocArgs &a, int mode, double *part_sum, double *part_cnt, hipStream_t s);
 int launch_soc_step(const SocArgs &a, unsigned long long *amin_bits, double *part_s1, double *part_s2, hipStream_t s);
+void launch_soc_update(const SocArgs &a, double alpha, double *X, const double *dX, const double *dX2, double *U, long long nx,
+                       long long nu, long long ncz, hipStream_t s);
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s);
 
 // ---- dynamics.hip -------------------------------------------------------------------------------

@@ -719,12 +719,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       if (read_step(amax)) { status = 2; break; }
       const double alpha = std::min(1.0, 0.99 * amax);  // strictly inside the cones, also when the boundary is just beyond 1
       if (!(alpha > 0.0)) { status = 2; break; }
-      for (auto pr : {std::make_pair(w.X.d(), w.dX.d()), std::make_pair(w.X.d(), w.dX2.d())}) launch_axpy(pr.first, pr.second, alpha, (long long)nx, s);
-      for (auto pr : {std::make_pair(w.U.d(), w.dU.d()), std::make_pair(w.U.d(), w.dU2.d()), std::make_pair(sa.zl, sa.dzl),
-                      std::make_pair(sa.zu, sa.dzu), std::make_pair(sa.sl, sa.dsl), std::make_pair(sa.su, sa.dsu)})
-        launch_axpy(pr.first, pr.second, alpha, (long long)nu, s);
-      launch_axpy(sa.zc, sa.dzc, alpha, (long long)ncz, s);
-      launch_axpy(sa.sc, sa.dsc, alpha, (long long)ncz, s);
+      launch_soc_update(sa, alpha, w.X.d(), w.dX.d(), w.dX2.d(), w.U.d(), (long long)nx, (long long)nu, (long long)ncz, s);
       newton++;
       // ---- complementarity of the new iterate + the next predictor system ------------------------------------------
       sa.corr = 0; sa.sigmu = 0.0;
