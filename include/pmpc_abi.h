@@ -66,6 +66,22 @@ void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_
                    double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
                    long long verbose, double smooth_alpha, char *solver);
 
+/* Extensions (not in the reference): the two entry points above for callers that hold fx, fu, Q, R as ROW-major blocks —
+ * numpy's C-ordered (M, N, row, col) stacks, which the reference's Python side transposes on the host on every call to
+ * reach the column-major layout (pmpc/static_backend.py:83-101 via pybind11's f_style cast: ~630 MB at M = 4096, the
+ * dominant cost of the call once the solve runs on the GPU).  Bit k of `rowmajor` marks fx (0), fu (1), Q (2), R (3) as
+ * row-major; everything else is as above.  The transposition is done in HBM after the upload. */
+void pmpc_lqp_solve_host(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
+                         double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
+                         double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
+                         double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                         long long verbose, unsigned rowmajor);
+void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
+                           double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
+                           double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
+                           double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                           long long verbose, double smooth_alpha, unsigned rowmajor);
+
 /* ---------------------------------------------------------------------------------------------
  * Part 2 — device-resident extension
  * ------------------------------------------------------------------------------------------- */

@@ -21,7 +21,7 @@ c_dp = ctypes.POINTER(ctypes.c_double)
 HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, COLD_START = 1, 2, 4, 8, 16, 32, 64
 
 ABI_SYMBOLS = [
-    "c_lqp_solve", "c_lcone_solve", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
+    "c_lqp_solve", "c_lcone_solve", "pmpc_lqp_solve_host", "pmpc_lcone_solve_host", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
 ]
@@ -59,6 +59,10 @@ def load():
     lib.c_lqp_solve.restype = None
     lib.c_lcone_solve.argtypes = common + [dbl, ctypes.c_char_p]
     lib.c_lcone_solve.restype = None
+    lib.pmpc_lqp_solve_host.argtypes = common + [ctypes.c_uint]
+    lib.pmpc_lqp_solve_host.restype = None
+    lib.pmpc_lcone_solve_host.argtypes = common + [dbl, ctypes.c_uint]
+    lib.pmpc_lcone_solve_host.restype = None
     lib.pmpc_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.pmpc_create.restype = ctypes.c_int
     lib.pmpc_destroy.argtypes = [vp]

@@ -44,6 +44,9 @@ def jl2py(x, keep: int = 1):
     return np.transpose(x, tuple(range(n - 1, keep - 1, -1)) + tuple(range(0, keep)))
 
 
+_BLOCK_BIT = {2: 0, 3: 1, 6: 2, 7: 3}  # positions of fx, fu, Q, R -> bit of the `rowmajor` mask (include/pmpc_abi.h)
+
+
 def _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1):
     assert x0.ndim == 2
     xdim, M = x0.shape
@@ -72,10 +75,22 @@ def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, 
     lib = _lib.load()
     xdim, udim, N, M = _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg,
                                      slew_reg0, slew_um1)
-    arrs = [np.asfortranarray(np.asarray(z, dtype=np.float64))
-            for z in (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1)]
+    arrs, rowmajor = [], 0
+    for k, z in enumerate((x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1)):
+        z = np.asarray(z, dtype=np.float64)
+        bit = _BLOCK_BIT.get(k)
+        if bit is not None and not z.flags.f_contiguous and z.transpose(3, 2, 0, 1).flags.c_contiguous:
+            # `py2jl` view of a C-ordered (M, N, row, col) stack: the blocks are row-major.  The reference transposes them on
+            # the host here (f_style cast, static_backend.py:83-101); libpmpc_hip does it in HBM after the upload instead.
+            rowmajor |= 1 << bit
+            arrs.append(z)
+        else:
+            arrs.append(np.asfortranarray(z))
     X_out, U_out = np.empty(xdim * N * M), np.empty(udim * N * M)
     ptr = lambda a: a.ctypes.data_as(_lib.c_dp)
+    if rowmajor:
+        entry = {"c_lqp_solve": "pmpc_lqp_solve_host", "c_lcone_solve": "pmpc_lcone_solve_host"}[entry]
+        extra = tuple(extra[:1]) + (rowmajor,)  # the `solver` string only selects the conic back end upstream
     getattr(lib, entry)(ptr(X_out), ptr(U_out), xdim, udim, N, M, int(Nc), *[ptr(a) for a in arrs[:14]], float(reg_x),
                         float(reg_u), *[ptr(a) for a in arrs[14:]], int(verbose), *extra)
     # pmpc/static_backend.py:103

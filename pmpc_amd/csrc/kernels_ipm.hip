@@ -414,6 +414,42 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
   }
 }
 
+// Input checks of the host-pointer ABI, on the device after the upload (the host would scan ~320 MB per call at config D):
+// flags[0] |= 1 if lx or ux holds a NaN, flags[1] |= 1 if lu or uu does (sentinels of c_interface.jl:56-70),
+// flags[2] |= 1 if some Q_j or R_j block is not exactly symmetric (then the generic kernels must be used).
+__global__ void __launch_bounds__(TB) k_host_checks(const double *lx, const double *ux, long long nx, const double *lu, const double *uu,
+                                                    long long nu, const double *Q, long long nq, int x, const double *R, long long nr,
+                                                    int u, int *flags) {
+  const long long stride = (long long)gridDim.x * TB, t0 = blockIdx.x * (long long)TB + threadIdx.x;
+  int fx = 0, fu = 0, fs = 0;
+  for (long long k = t0; k < nx; k += stride) fx |= (lx[k] != lx[k]) || (ux[k] != ux[k]);
+  for (long long k = t0; k < nu; k += stride) fu |= (lu[k] != lu[k]) || (uu[k] != uu[k]);
+  for (long long k = t0; k < nq; k += stride) {  // element (r, c) of block b against (c, r)
+    const long long b = k / (x * x), e = k - b * (x * x);
+    const int r = (int)(e % x), c = (int)(e / x);
+    fs |= Q[k] != Q[b * (x * x) + c + (long long)x * r];
+  }
+  for (long long k = t0; k < nr; k += stride) {
+    const long long b = k / (u * u), e = k - b * (u * u);
+    const int r = (int)(e % u), c = (int)(e / u);
+    fs |= R[k] != R[b * (u * u) + c + (long long)u * r];
+  }
+  if (fx) atomicOr(&flags[0], 1);
+  if (fu) atomicOr(&flags[1], 1);
+  if (fs) atomicOr(&flags[2], 1);
+}
+
+// out (column-major rows x cols blocks) <- in (row-major blocks); n = total element count
+__global__ void __launch_bounds__(TB) k_block_transpose(const double *__restrict__ in, double *__restrict__ out, int rows, int cols,
+                                                        long long n) {
+  const int rc = rows * cols;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) {
+    const long long b = k / rc;
+    const int e = (int)(k - b * rc), r = e % rows, c = e / rows;
+    out[k] = in[b * rc + r * cols + c];
+  }
+}
+
 inline int grid_for(long long n) {
   long long b = (n + TB - 1) / TB;
   if (b > PMPC_RED_BLOCKS) b = PMPC_RED_BLOCKS;
@@ -423,6 +459,13 @@ inline int grid_for(long long n) {
 
 }  // namespace
 
+void launch_block_transpose(const double *in, double *out, int rows, int cols, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(k_block_transpose, dim3(grid_for(n)), dim3(TB), 0, s, in, out, rows, cols, n);
+}
+void launch_host_checks(const double *lx, const double *ux, long long nx, const double *lu, const double *uu, long long nu,
+                        const double *Q, long long nq, int x, const double *R, long long nr, int u, int *flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_host_checks, dim3(2048), dim3(TB), 0, s, lx, ux, nx, lu, uu, nu, Q, nq, x, R, nr, u, flags);
+}
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s) {
   hipLaunchKernelGGL(k_axpy, dim3(grid_for(n) * 4), dim3(TB), 0, s, y, xv, alpha, n);
 }

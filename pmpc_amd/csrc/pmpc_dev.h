@@ -122,6 +122,9 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s);
 void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
+void launch_block_transpose(const double *in, double *out, int rows, int cols, long long n, hipStream_t s);
+void launch_host_checks(const double *lx, const double *ux, long long nx, const double *lu, const double *uu, long long nu,
+                        const double *Q, long long nq, int x, const double *R, long long nr, int u, int *flags, hipStream_t s);
 void launch_axpy(double *y, const double *xv, double alpha, long long n, hipStream_t s);
 void launch_fill(double *y, double v, long long n, hipStream_t s);
 void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hipStream_t s);

@@ -15,7 +15,9 @@
 #include <condition_variable>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <limits>
 #include <vector>
 
@@ -174,7 +176,10 @@ struct pmpc_ctx {
   bool mock_comm = false;  // comm is a MockRank (test hook), not an RCCL communicator
   int rank = 0, world = 1;
   // staging for the host-pointer ABI
-  DevBuf stage[19];
+  DevBuf stage[19], stage_t[4];
+  void *pinned = nullptr;  // host-coherent bounce buffer of the host-pointer ABI (threaded memcpy -> DMA)
+  size_t pinned_bytes = 0;
+  DevBuf host_flags;
 };
 
 namespace {
@@ -337,6 +342,8 @@ void pmpc_destroy(pmpc_ctx *c) {
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
   for (DevBuf &b : c->stage) b.release();
   (void)hipHostFree(c->mirror);
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  c->host_flags.release();
   free(c->sc_host);
   free(c->fail_host);
   (void)hipStreamDestroy(c->stream);
@@ -1091,21 +1098,49 @@ static bool any_nan(const double *p, size_t n) {
   return false;
 }
 
-static bool blocks_symmetric(const double *B, size_t d, size_t nblocks) {
-  for (size_t b = 0; b < nblocks; b++) {
-    const double *P = B + b * d * d;
-    for (size_t r = 0; r < d; r++)
-      for (size_t t = r + 1; t < d; t++)
-        if (P[r + d * t] != P[t + d * r]) return false;
+// Pageable host arrays -> HBM: hipMemcpyAsync from pageable memory stages through a single-threaded copy (~7 GB/s measured,
+// 100 ms for config D's 700 MB).  Here worker threads copy 8 MB chunks into a pinned bounce buffer and hand each one to the
+// copy engine as soon as it is staged (chunk order is irrelevant: the solve is enqueued behind all of them).
+struct UploadItem { void *dst; const void *src; size_t bytes; };
+static void upload_all(pmpc_ctx *c, const std::vector<UploadItem> &items) {
+  constexpr size_t CH = 8u << 20;
+  struct Chunk { char *dst; const char *src; size_t bytes, off; };
+  std::vector<Chunk> chunks;
+  size_t total = 0;
+  for (const UploadItem &it : items)
+    for (size_t o = 0; o < it.bytes; o += CH) {
+      const size_t b = std::min(CH, it.bytes - o);
+      chunks.push_back({(char *)it.dst + o, (const char *)it.src + o, b, total});
+      total += (b + 255) & ~(size_t)255;
+    }
+  if (total > c->pinned_bytes) {
+    if (c->pinned) HIP_CHECK(hipHostFree(c->pinned));
+    HIP_CHECK(hipHostMalloc(&c->pinned, total, hipHostMallocDefault));
+    c->pinned_bytes = total;
   }
-  return true;
+  unsigned nthreads = std::thread::hardware_concurrency();
+  nthreads = std::max(1u, std::min(nthreads ? nthreads : 4u, 16u));
+  if (chunks.size() < 4) nthreads = 1;
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    (void)hipSetDevice(c->device);
+    for (size_t k = next++; k < chunks.size(); k = next++) {
+      const Chunk &ch = chunks[k];
+      memcpy((char *)c->pinned + ch.off, ch.src, ch.bytes);
+      HIP_CHECK(hipMemcpyAsync(ch.dst, (char *)c->pinned + ch.off, ch.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(work);
+  work();
+  for (std::thread &t : pool) t.join();
 }
 
 static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
                        double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R,
                        double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x,
                        double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, bool cone = false,
-                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN()) {
+                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN(), unsigned rowmajor = 0) {
   const size_t nx = xdim * N * M, nu = udim * N * M;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   auto fail_out = [&]() {  // osqp_solver.jl:65-71 convention
@@ -1122,32 +1157,57 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
   pmpc_problem p;
   memset(&p, 0, sizeof(p));
   p.xdim = xdim; p.udim = udim; p.N = N; p.M = M; p.Nc = Nc; p.reg_x = reg_x; p.reg_u = reg_u;
-  // sentinels: c_interface.jl:56-70
-  if (!(any_nan(lx, nx) || any_nan(ux, nx))) p.flags |= PMPC_HAS_XBOUNDS;
-  if (!(any_nan(lu, nu) || any_nan(uu, nu))) p.flags |= PMPC_HAS_UBOUNDS;
+  // slew sentinels (tiny arrays) on the host: c_interface.jl:56-70
   bool slew_nonzero = false;
   if (!any_nan(slew_reg, M)) {
     for (size_t k = 0; k < M; k++) slew_nonzero |= (slew_reg[k] != 0.0);
     if (slew_nonzero) p.flags |= PMPC_HAS_SLEW;
   }
   if (!(any_nan(slew_reg0, M) || any_nan(slew_um1, udim * M))) p.flags |= PMPC_HAS_SLEW0;
-  if (blocks_symmetric(Q, xdim, N * M) && blocks_symmetric(R, udim, N * M)) p.flags |= PMPC_SYMMETRIC_COST;
   const void *src[19] = {x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1,
                          nullptr, nullptr};
   const size_t cnt[19] = {xdim * M, nx, nx * xdim, nx * udim, nx, nu, nx * xdim, nu * udim, nx, nu, nx, nx, nu, nu, M, M,
                           udim * M, nx, nu};
-  const bool used[19] = {true, true, true, true, true, true, true, true, true, true,
-                         (bool)(p.flags & PMPC_HAS_XBOUNDS), (bool)(p.flags & PMPC_HAS_XBOUNDS),
-                         (bool)(p.flags & PMPC_HAS_UBOUNDS), (bool)(p.flags & PMPC_HAS_UBOUNDS),
-                         (bool)(p.flags & PMPC_HAS_SLEW), (bool)(p.flags & PMPC_HAS_SLEW0), (bool)(p.flags & PMPC_HAS_SLEW0),
-                         true, true};
+  bool used[19] = {true, true, true, true, true, true, true, true, true, true,
+                   lx && ux, lx && ux, lu && uu, lu && uu,  // the box arrays are uploaded first and checked for NaN sentinels there
+                   (bool)(p.flags & PMPC_HAS_SLEW), (bool)(p.flags & PMPC_HAS_SLEW0), (bool)(p.flags & PMPC_HAS_SLEW0),
+                   true, true};
+  std::vector<UploadItem> items;
   for (int k = 0; k < 19; k++) {
     if (!used[k]) continue;
     c->stage[k].ensure(cnt[k] * sizeof(double));
-    if (src[k]) HIP_CHECK(hipMemcpyAsync(c->stage[k].p, src[k], cnt[k] * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (src[k]) items.push_back({c->stage[k].p, src[k], cnt[k] * sizeof(double)});
+  }
+  upload_all(c, items);
+  // NaN sentinels of the boxes and exact symmetry of the cost blocks: checked on the device (one pass over what was uploaded)
+  c->host_flags.ensure(4 * sizeof(int));
+  HIP_CHECK(hipMemsetAsync(c->host_flags.p, 0, 4 * sizeof(int), c->stream));
+  launch_host_checks(used[10] ? c->stage[10].d() : nullptr, used[11] ? c->stage[11].d() : nullptr, used[10] ? (long long)nx : 0,
+                     used[12] ? c->stage[12].d() : nullptr, used[13] ? c->stage[13].d() : nullptr, used[12] ? (long long)nu : 0,
+                     c->stage[6].d(), (long long)(nx * xdim), (int)xdim, c->stage[7].d(), (long long)(nu * udim), (int)udim,
+                     (int *)c->host_flags.p, c->stream);
+  int hf[4];
+  HIP_CHECK(hipMemcpyAsync(hf, c->host_flags.p, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (used[10] && !hf[0]) p.flags |= PMPC_HAS_XBOUNDS;
+  if (used[12] && !hf[1]) p.flags |= PMPC_HAS_UBOUNDS;
+  if (!hf[2]) p.flags |= PMPC_SYMMETRIC_COST;
+  used[10] = used[11] = (p.flags & PMPC_HAS_XBOUNDS) != 0;
+  used[12] = used[13] = (p.flags & PMPC_HAS_UBOUNDS) != 0;
+  // row-major blocks (numpy's (M, N, row, col) stacks handed over without the host-side transposition): transposed here.
+  // Symmetric cost blocks are their own transpose.
+  const void *blk[4] = {c->stage[2].p, c->stage[3].p, c->stage[6].p, c->stage[7].p};
+  const int brow[4] = {(int)xdim, (int)xdim, (int)xdim, (int)udim}, bcol[4] = {(int)xdim, (int)udim, (int)xdim, (int)udim};
+  for (int k = 0; k < 4; k++) {
+    if (!(rowmajor >> k & 1u) || (k >= 2 && !hf[2])) continue;
+    const size_t n = (size_t)brow[k] * bcol[k] * N * M;
+    c->stage_t[k].ensure(n * sizeof(double));
+    launch_block_transpose((const double *)blk[k], c->stage_t[k].d(), brow[k], bcol[k], (long long)n, c->stream);
+    blk[k] = c->stage_t[k].p;
   }
   auto dp = [&](int k) { return used[k] ? (const double *)c->stage[k].p : (const double *)nullptr; };
   p.x0 = dp(0); p.f = dp(1); p.fx = dp(2); p.fu = dp(3); p.X_prev = dp(4); p.U_prev = dp(5); p.Q = dp(6); p.R = dp(7);
+  p.fx = (const double *)blk[0]; p.fu = (const double *)blk[1]; p.Q = (const double *)blk[2]; p.R = (const double *)blk[3];
   p.X_ref = dp(8); p.U_ref = dp(9); p.lx = dp(10); p.ux = dp(11); p.lu = dp(12); p.uu = dp(13);
   p.slew_reg = dp(14); p.slew_reg0 = dp(15); p.slew_um1 = dp(16);
   p.X_out = c->stage[17].d(); p.U_out = c->stage[18].d();
@@ -1182,6 +1242,28 @@ void c_lcone_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_
   (void)solver;
   host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
              reg_u, slew_reg, slew_reg0, slew_um1, verbose, true, smooth_alpha);
+}
+
+// Extensions of the two entry points above for callers that hold the Jacobian / cost stacks as row-major blocks (numpy's
+// (M, N, row, col) arrays: the reference's Python side pays a host transposition of ~630 MB per call at M = 4096 to reach
+// the column-major ABI layout, static_backend.py:83-101 through pybind11's f_style cast).  Bit k of `rowmajor` marks
+// fx (0), fu (1), Q (2), R (3) as row-major; the transposition then happens in HBM after the upload.
+void pmpc_lqp_solve_host(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc, double *x0,
+                         double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R,
+                         double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x,
+                         double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose,
+                         unsigned rowmajor) {
+  host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
+             reg_u, slew_reg, slew_reg0, slew_um1, verbose, false, std::numeric_limits<double>::quiet_NaN(), rowmajor);
+}
+
+void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc,
+                           double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
+                           double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
+                           double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                           long long verbose, double smooth_alpha, unsigned rowmajor) {
+  host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
+             reg_u, slew_reg, slew_reg0, slew_um1, verbose, true, smooth_alpha, rowmajor);
 }
 
 }  // extern "C"

@@ -29,3 +29,30 @@ def test_lqp_solve_matches_oracle(case, oracle):
     if Nc != 0 and M > 1:  # consensus: the first Nc controls are shared exactly (examples/simple_demo.ipynb:402-421)
         k = N if Nc < 0 else Nc
         assert np.all(U[:, :k] == U[0:1, :k])
+
+
+@pytest.mark.parametrize("case", [CASES[2], CASES[13], CASES[17]], ids=lambda c: str(c))
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_column_major_and_row_major_entries_agree(case, symmetric, oracle):
+    """`c_lqp_solve` proper (Fortran-contiguous arrays, the layout of c_interface.jl:28-46) and `pmpc_lqp_solve_host`
+    (row-major Jacobian / cost blocks, transposed in HBM) against the oracle, with cost blocks that are exactly symmetric
+    or not (then OSQP's triu(P) semantics apply and the transposition of Q, R matters)."""
+    from pmpc_amd import backend
+
+    M, N, x, u, Nc, bu, bx, sl, sl0 = case
+    rng = np.random.default_rng(77)
+    args, kw = rand_problem(rng, M, N, x, u, bu, bx, sl, sl0)
+    args = list(args)
+    if symmetric:
+        args[6], args[7] = [0.5 * (a + np.swapaxes(a, -1, -2)) for a in (args[6], args[7])]
+    else:
+        args[6] = args[6] + 0.05 * np.triu(rng.standard_normal((M, N, x, x)), 1)
+        args[7] = args[7] + 0.05 * np.triu(rng.standard_normal((M, N, u, u)), 1)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    a = abi_args(tuple(args), kw, Nc)
+    assert not a[3].flags.f_contiguous  # py2jl view of the C-ordered fx stack -> row-major entry point
+    fa = tuple(np.asfortranarray(v) if isinstance(v, np.ndarray) else v for v in a)
+    for arrs in (a, fa):
+        X, U = backend.lqp_solve(*arrs)
+        assert _rel(X, Xo) <= TOL, _rel(X, Xo)
+        assert _rel(U, Uo, 1.0) <= TOL, _rel(U, Uo, 1.0)
