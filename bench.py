@@ -85,6 +85,38 @@ def cpu_baseline(model, M_total, N, Nc, budget_s=20.0):
                         f"{tm['factorizations']} sparse LU) {tm['solve_s']:.2f}s = {t:.2f}s; scaled x{M_total / Ms:g}"))
 
 
+def cpu_baseline_structured(model, M_total, N, Nc, budget_s=6.0):
+    """Second, stronger CPU line: the SAME structured algorithm as the HIP path (Riccati + condensing
+    + Mehrotra on the boxes) in plain C with OpenMP over particles (oracle/structured_cpu.c), all host cores, on the first
+    M_s particles of the same seeded batch; per-particle work is independent, so the time scales by M_total / M_s."""
+    from oracle import lqp_oracle as orc
+    from pmpc_amd import dynamics as dyn
+
+    cores = len(os.sched_getaffinity(0))
+
+    def one(Ms):
+        prob = dyn.make_quadrotor_problem(M=Ms, N=N, Nc=Nc) if model == "quadrotor" else dyn.make_unicycle_problem(M=Ms, N=N, Nc=Nc)
+        X_ = np.concatenate([prob["x0"][:, None, :], prob["X_prev"][:, :-1]], 1)
+        f, fx, fu = prob["f_fx_fu_fn"](X_, prob["U_prev"])
+        _, _, info = orc.structured_cpu_solve_py(prob["x0"], f, fx, fu, prob["X_prev"], prob["U_prev"], prob["Q"], prob["R"],
+                                                 prob["X_ref"], prob["U_ref"], prob["reg_x"], prob["reg_u"], Nc=Nc,
+                                                 u_l=prob["u_l"], u_u=prob["u_u"], threads=cores)
+        assert info["status"] == 0, info
+        return info
+
+    Ms = min(M_total, 16 * cores)
+    info = one(Ms)  # also warms the thread pool up
+    info = one(Ms)
+    while info["solve_s"] < budget_s / 4 and Ms < M_total:
+        Ms = min(M_total, Ms * 2)
+        info = one(Ms)
+    scaled = info["solve_s"] * (M_total / Ms)
+    return dict(value=1.0 / scaled, unit="SCP iterations/s", cores=cores, kind="port",
+                sample=(f"{model} M_s={Ms} of {M_total} particles, N={N}, one SCP sub-problem by the structured algorithm in C + "
+                        f"OpenMP (oracle/structured_cpu.c, {info['iters']} interior-point iterations, cold start) "
+                        f"{info['solve_s']:.2f}s; scaled x{M_total / Ms:g}"))
+
+
 def main():
     args = parse()
     import torch
@@ -229,6 +261,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.model, M_total, N, Nc)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            out["cpu_baseline_structured"] = cpu_baseline_structured(args.model, M_total, N, Nc)
+            out["cpu_baseline_structured"]["gpu_over_cpu"] = value / out["cpu_baseline_structured"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

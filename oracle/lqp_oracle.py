@@ -84,6 +84,46 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+_SO_CPU = _HERE / "libstructured_cpu.so"
+_lib_cpu = None
+
+
+def build_structured_cpu(force: bool = False) -> Path:
+    """gcc -fopenmp build of oracle/structured_cpu.c (the multi-core structured CPU baseline; recipe also in oracle/Makefile).
+    AVX2 + FMA only (no -march=native): the .so is built in the dev container and travels to the GPU box."""
+    src = _HERE / "structured_cpu.c"
+    if force or not _SO_CPU.exists() or _SO_CPU.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["gcc", "-O3", "-mavx2", "-mfma", "-fopenmp", "-fPIC", "-shared", "-std=gnu99", "-o", str(_SO_CPU),
+                               str(src), "-lm"])
+    return _SO_CPU
+
+
+def structured_cpu_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x_l=None, x_u=None, u_l=None,
+                            u_u=None, threads=0):
+    """The same QP as `lqp_solve_py` (py layout in, py layout out) through oracle/structured_cpu.c: Riccati + condensing +
+    Mehrotra on the boxes, OpenMP over particles.  No slew terms.  Returns X (M,N,x), U (M,N,u), info."""
+    global _lib_cpu
+    if _lib_cpu is None:
+        build_structured_cpu()
+        _lib_cpu = ctypes.CDLL(str(_SO_CPU))
+        _lib_cpu.structured_cpu_solve.restype = ctypes.c_int
+    f = _f64(f)
+    M, N, x = f.shape
+    u = np.asarray(fu).shape[-1]
+    bc = lambda a, d: None if a is None else _f64(np.broadcast_to(np.asarray(a, float), (M, N, d)))
+    arrs = [_f64(x0), f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev), to_abi_mat(Q), to_abi_mat(R), _f64(X_ref),
+            _f64(U_ref)]
+    bnd = [bc(x_l, x), bc(x_u, x), bc(u_l, u), bc(u_u, u)]
+    X, U = np.empty((M, N, x)), np.empty((M, N, u))
+    iters = ctypes.c_int(0)
+    t0 = time.perf_counter()
+    st = _lib_cpu.structured_cpu_solve(
+        ctypes.c_int(x), ctypes.c_int(u), ctypes.c_int(N), ctypes.c_int(M), ctypes.c_longlong(int(Nc)), *[_p(a) for a in arrs],
+        *[None if b is None else _p(b) for b in bnd], ctypes.c_double(reg_x), ctypes.c_double(reg_u), ctypes.c_int(int(threads)),
+        _p(X), _p(U), ctypes.byref(iters))
+    return X, U, dict(status=int(st), iters=int(iters.value), solve_s=time.perf_counter() - t0)
+
+
 def _f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 

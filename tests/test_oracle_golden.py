@@ -86,3 +86,18 @@ def test_oracle_assembly_shapes(oracle):
                              np.full(1, np.nan), np.full(1, np.nan), np.full((1, 2), np.nan))
     assert qp.A.shape == (120, 180) and qp.P.shape == (180, 180) and qp.G.shape == (60, 180)
     assert qp.A.nnz == 4 * 2 * 30 + 30 * 4 + 29 * 16
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[7] is None and c[8] is None], ids=lambda c: str(c))
+def test_structured_cpu_baseline_matches_oracle(case):
+    """oracle/structured_cpu.c (the OpenMP baseline bench.py times) solves the same QP as the exact oracle."""
+    from oracle import lqp_oracle as orc
+
+    M, N, x, u, Nc, bu, bx, _, _ = case
+    args, kw = rand_problem(np.random.default_rng(1000 + CASES.index(case)), M, N, x, u, bu, bx)
+    Xo, Uo = orc.lqp_solve_py(*args, Nc=Nc, **kw)
+    X, U, info = orc.structured_cpu_solve_py(*args, kw["reg_x"], kw["reg_u"], Nc=Nc, x_l=kw.get("x_l"), x_u=kw.get("x_u"),
+                                             u_l=kw.get("u_l"), u_u=kw.get("u_u"), threads=2)
+    assert info["status"] == 0
+    assert np.linalg.norm(X - Xo) <= 1e-7 * np.linalg.norm(Xo)
+    assert np.linalg.norm(U - Uo) <= 1e-7 * max(1.0, np.linalg.norm(Uo))
