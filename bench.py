@@ -21,6 +21,8 @@ from pathlib import Path
 
 import numpy as np
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # CPU baselines: no spinning OpenMP barriers under a cgroup CPU quota
+
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
@@ -85,6 +87,25 @@ def cpu_baseline(model, M_total, N, Nc, budget_s=20.0):
                         f"{tm['factorizations']} sparse LU) {tm['solve_s']:.2f}s = {t:.2f}s; scaled x{M_total / Ms:g}"))
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 hardware
+    threads under a 16-CPU quota; 256 spinning OpenMP threads there run 50x slower than 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline_structured(model, M_total, N, Nc, budget_s=6.0):
     """Second, stronger CPU line: the SAME structured algorithm as the HIP path (Riccati + condensing
     + Mehrotra on the boxes) in plain C with OpenMP over particles (oracle/structured_cpu.c), all host cores, on the first
@@ -92,7 +113,7 @@ def cpu_baseline_structured(model, M_total, N, Nc, budget_s=6.0):
     from oracle import lqp_oracle as orc
     from pmpc_amd import dynamics as dyn
 
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
 
     def one(Ms):
         prob = dyn.make_quadrotor_problem(M=Ms, N=N, Nc=Nc) if model == "quadrotor" else dyn.make_unicycle_problem(M=Ms, N=N, Nc=Nc)
@@ -104,7 +125,7 @@ def cpu_baseline_structured(model, M_total, N, Nc, budget_s=6.0):
         assert info["status"] == 0, info
         return info
 
-    Ms = min(M_total, 16 * cores)
+    Ms = min(M_total, 32 * cores)
     info = one(Ms)  # also warms the thread pool up
     info = one(Ms)
     while info["solve_s"] < budget_s / 4 and Ms < M_total:
