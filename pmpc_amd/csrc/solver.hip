@@ -175,6 +175,8 @@ struct pmpc_ctx {
   ncclComm_t comm = nullptr;
   bool mock_comm = false;  // comm is a MockRank (test hook), not an RCCL communicator
   int rank = 0, world = 1;
+  bool single_rank_comm = false;  // a real 1-rank RCCL communicator drives the multi-rank code paths (PMPC_RCCL_SINGLE, test hook)
+  bool multi() const { return world > 1 || single_rank_comm; }
   // staging for the host-pointer ABI
   DevBuf stage[19], stage_t[4];
   void *pinned = nullptr;  // host-coherent bounce buffer of the host-pointer ABI (threaded memcpy -> DMA)
@@ -185,7 +187,7 @@ struct pmpc_ctx {
 namespace {
 
 void allreduce(pmpc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t op) {
-  if (c->world <= 1) return;
+  if (!c->multi()) return;
   ncclResult_t r = g_rccl.AllReduce(buf, buf, n, dt, op, c->comm, c->stream);
   if (r != ncclSuccess) {
     fprintf(stderr, "pmpc_hip: ncclAllReduce failed (%d)\n", (int)r);
@@ -244,7 +246,7 @@ void exchange(pmpc_ctx *c, int phase) {
   IpmScal *sc = (IpmScal *)w.sc.p;
   const int B2 = 2 * PMPC_RED_BLOCKS;
   c->seq++;
-  if (c->world <= 1) {
+  if (!c->multi()) {
     launch_ipm_exchange(phase, true, true, sc, (const int *)w.fail.p, w.xch.d(), 0, 1, w.part_sum.d(), w.part_cnt.d(),
                         w.part_max.d(), B2, c->stream, 0.0, nullptr, &c->mirror_dev->sc, &c->mirror_dev->seq, c->seq);
     return;
@@ -272,7 +274,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
     double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
     if (fast && factor) launch_cond_fast(a, s);
     if (nc * nc + nc <= 32) {
-      const bool solve_now = c->world <= 1;
+      const bool solve_now = !c->multi();
       launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
       if (!solve_now) {
         if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
@@ -385,11 +387,16 @@ int pmpc_comm_unique_id(void *out128) {
 }
 
 int pmpc_comm_init(pmpc_ctx *c, int rank, int world, const void *id128) {
-  if (world <= 1) {
+  // TEST HOOK: PMPC_RCCL_SINGLE=1 makes a world of one a real 1-rank RCCL communicator and sends every solve through the
+  // multi-rank code paths (packed exchange, consensus all-reduce, bounds broadcast) — the only way to run the actual
+  // ncclAllReduce / ncclBroadcast calls on a one-GPU box (RCCL refuses two ranks on one device).
+  const char *single = getenv("PMPC_RCCL_SINGLE");
+  if (world <= 1 && !(single && single[0] == '1')) {
     c->rank = 0;
     c->world = 1;
     return 0;
   }
+  if (world <= 1) { world = 1; rank = 0; c->single_rank_comm = true; }
   if (!g_rccl.load()) return 1;
   HIP_CHECK(hipSetDevice(c->device));
   ncclUniqueId id;
@@ -566,11 +573,11 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
   if (has_xb) setup_slab(sx, w.sx, nx, x, false, p->lx, p->ux, w.X.d(), w.dX.d());
   if (has_ub) {
     const double *lo = p->lu, *hi = p->uu;
-    if (Nc > 0 && (M > 1 || c->world > 1)) {  // consensus bounds = global particle 0's (lqp_utils.jl:329-330)
+    if (Nc > 0 && (M > 1 || c->multi())) {  // consensus bounds = global particle 0's (lqp_utils.jl:329-330)
       w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
       HIP_CHECK(hipMemcpyAsync(w.su.lo.p, p->lu, nu * D8, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipMemcpyAsync(w.su.hi.p, p->uu, nu * D8, hipMemcpyDeviceToDevice, s));
-      if (c->world > 1) {
+      if (c->multi()) {
         g_rccl.Broadcast(w.su.lo.p, w.su.lo.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
         g_rccl.Broadcast(w.su.hi.p, w.su.hi.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
       }
@@ -629,7 +636,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       HIP_CHECK(hipStreamSynchronize(s));
       double sum = 0.0, cnt = 0.0;
       for (int k = 0; k < nblk; k++) { sum += hs[k]; cnt += hc[k]; }
-      if (c->world > 1) {  // tiny host-staged all-reduce through the device (two doubles)
+      if (c->multi()) {  // tiny host-staged all-reduce through the device (two doubles)
         double pair[2] = {sum, cnt};
         HIP_CHECK(hipMemcpyAsync(w.xch.p, pair, 2 * D8, hipMemcpyHostToDevice, s));
         allreduce(c, w.xch.p, 2, ncclFloat64, ncclSum);
@@ -681,7 +688,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     fl = measure(nblk, mu);
     if (fl) { status = fl == 3 ? 3 : 2; }
     auto read_step = [&](double &amax) -> int {  // step length of the last step kernel (+ failure flag), across ranks
-      if (c->world > 1) allreduce(c, &sc->amin_bits, 1, ncclFloat64, ncclMin);  // bit pattern of a non-negative double
+      if (c->multi()) allreduce(c, &sc->amin_bits, 1, ncclFloat64, ncclMin);  // bit pattern of a non-negative double
       HIP_CHECK(hipMemcpyAsync(&host_rd.amin, &sc->amin_bits, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(&host_rd.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
@@ -702,7 +709,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       if (read_step(a_aff)) { status = 2; break; }
       double s1 = 0.0, s2 = 0.0;
       for (int k = 0; k < nblk; k++) { s1 += hs[k]; s2 += hc[k]; }
-      if (c->world > 1) {
+      if (c->multi()) {
         double pair[2] = {s1, s2};
         HIP_CHECK(hipMemcpyAsync(w.xch.p, pair, 2 * D8, hipMemcpyHostToDevice, s));
         allreduce(c, w.xch.p, 2, ncclFloat64, ncclSum);
@@ -966,10 +973,10 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
   // every rank gathers all costs (all-reduce(sum) of a zero-padded vector) and takes the same decisions
   const size_t Ml = p->M, M = Ml * (size_t)c->world, off = (size_t)c->rank * Ml, D8 = sizeof(double);
   const double eps = 1e-3;  // COST_ANCHOR_EPS, main.jl:223
-  w.pw.ensure(Ml * D8); w.Jc.ensure(Ml * D8); w.Jg.ensure(M * D8);
+  w.pw.ensure(Ml * D8); w.Jc.ensure(Ml * D8); w.Jg.ensure(std::max<size_t>(M, 2) * D8);
   std::vector<double> user(M, 1.0), pw(Ml), J(M), loc(Ml);
   auto gather = [&](const double *local_dev, std::vector<double> &global) {  // global[rank*Ml + i] = local[i] on every rank
-    if (c->world <= 1) {
+    if (!c->multi()) {
       HIP_CHECK(hipMemcpyAsync(global.data(), local_dev, Ml * D8, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
       return;
@@ -980,7 +987,7 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
     HIP_CHECK(hipMemcpyAsync(global.data(), w.Jg.p, M * D8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
   };
-  if (c->world > 1) {  // equal shards are assumed by the offsets above
+  if (c->multi()) {  // equal shards are assumed by the offsets above
     double cnt[2] = {(double)Ml, -(double)Ml};
     HIP_CHECK(hipMemcpyAsync(w.Jg.p, cnt, 2 * D8, hipMemcpyHostToDevice, s));
     allreduce(c, w.Jg.p, 2, ncclFloat64, ncclMax);

@@ -148,3 +148,64 @@ def test_sharded_stage_cones_match_oracle(Nc, oracle):
                                   soc_w0=soc["w0"], soc_v=soc["v"], soc_v0=soc["v0"], u_interior=soc["u_interior"])
     Xw, Uw, _ = _solve_sharded(args, kw, Nc, 2, repeats=2, soc=soc)
     assert np.linalg.norm(Xw - Xo) / np.linalg.norm(Xo) < 1e-6 and np.linalg.norm(Uw - Uo) / np.linalg.norm(Uo) < 1e-6
+
+
+_RCCL_SINGLE_SCRIPT = r"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from pmpc_amd.device import DeviceSolver
+from tests.support.problems import rand_problem
+
+def make(comm):
+    s = DeviceSolver(0)
+    if comm:
+        buf = ctypes.create_string_buffer(128)
+        assert s.lib.pmpc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)) == 0
+        assert s.lib.pmpc_comm_init(s.h, 0, 1, ctypes.cast(buf, ctypes.c_void_p)) == 0
+    return s
+
+plain, rccl = make(False), make(True)
+dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+T = lambda a: dev(np.swapaxes(a, -1, -2))
+worst = 0.0
+for k, (M, N, x, u, Nc, kind) in enumerate([(8, 9, 12, 4, 1, "qp"), (6, 8, 5, 3, -1, "qp"), (8, 7, 4, 2, 3, "qp"), (8, 9, 12, 4, 0, "qp"),
+                                            (40, 6, 4, 2, 1, "cone"), (6, 7, 5, 3, 1, "soc")]):
+    args, kw = rand_problem(np.random.default_rng(500 + k), M, N, x, u, 0.4 if kind != "soc" else 0.6)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    opt = dict(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref),
+               U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, symmetric_cost=True, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]))
+    if kind == "soc":
+        W = np.zeros((2, 3)); W[0, 1] = W[1, 2] = 1.0
+        opt.update(soc_W=dev(W), soc_w0=dev(np.zeros(2)), soc_v=dev(np.array([0.5, 0, 0])), soc_v0=0.05, soc_u_interior=dev(np.array([0.2, 0, 0])))
+    res = []
+    for s in (plain, rccl):
+        for _ in range(2):  # the second solve is warm-started
+            X, U, status = getattr(s, {"qp": "lqp_solve", "cone": "lcone_solve", "soc": "lsoc_solve"}[kind])(**opt)
+            s.sync()
+            assert status == 0, (kind, status)
+        res.append((X.cpu().numpy(), U.cpu().numpy()))
+    e = max(np.abs(res[0][0] - res[1][0]).max(), np.abs(res[0][1] - res[1][1]).max())
+    worst = max(worst, e)
+    print(kind, (M, N, x, u, Nc), "max abs diff", e, flush=True)
+assert worst < 1e-9, worst
+plain.close(); rccl.close()
+print("RCCL_SINGLE_OK")
+"""
+
+
+def test_real_rccl_calls_on_a_one_rank_communicator():
+    """RCCL itself, as far as a one-GPU box allows: with PMPC_RCCL_SINGLE=1 (test hook) `pmpc_comm_init` builds a REAL 1-rank
+    RCCL communicator (ncclGetUniqueId / ncclCommInitRank through the library's own dlopen) and every solve goes through the
+    multi-rank code paths — ncclAllReduce (sum / min / max, fp64 and int32, in place, on the solver's non-blocking stream,
+    next to the host's sequence-number polling) and ncclBroadcast.  Own process: the mock communicator of the tests above
+    replaces the collectives process-wide."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    env = dict(os.environ, PMPC_RCCL_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SINGLE_SCRIPT], cwd=str(Path(__file__).resolve().parents[1]), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_SINGLE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
