@@ -134,6 +134,7 @@ typedef struct pmpc_info {
   double slack_res;    /* final slack residual (inf-norm) */
   double max_violation;/* bound violation of the equality-only optimum */
   int outer_solves;    /* cone path: weighted QPs solved (active-set + bisection on the threshold particle) */
+  int active_set_rounds; /* structured solves spent in the active-set finish of the box interior-point iteration */
 } pmpc_info;
 
 /* Opaque solver context: owns the HIP stream, the workspace cache keyed on

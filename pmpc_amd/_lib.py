@@ -41,7 +41,7 @@ class PmpcProblem(ctypes.Structure):
 class PmpcInfo(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int), ("ipm_iters", ctypes.c_int), ("structured_solves", ctypes.c_int),
                 ("fast_path", ctypes.c_int), ("mu", ctypes.c_double), ("slack_res", ctypes.c_double),
-                ("max_violation", ctypes.c_double), ("outer_solves", ctypes.c_int)]
+                ("max_violation", ctypes.c_double), ("outer_solves", ctypes.c_int), ("active_set_rounds", ctypes.c_int)]
 
 
 def load():

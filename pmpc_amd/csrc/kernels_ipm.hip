@@ -414,6 +414,77 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
   }
 }
 
+// ---- primal-dual active-set finish of the box interior-point iteration (control boxes) ---------------------------------
+// Once mu is small the interior-point iterate has identified the active set: lower side if l_l > slack_l, upper side
+// likewise.  The finish solves the equality-constrained QP on that set EXACTLY with one structured solve: the base point is
+// the iterate with its active controls moved ONTO their bounds (and the states rolled out again), the active controls are
+// held there by a quadratic penalty `big` on their step — du_b = -(grad L)_b / (H_bb + big), i.e. zero to ~1e-14, and
+// -big du_b is the multiplier, to full relative precision (no cancellation: the penalty's target is du_b = 0).  The check
+// pass verifies the KKT signs (multipliers of the active set >= 0, inactive controls inside their boxes) and applies the
+// primal-dual active-set update where they fail; an unchanged set is the optimum of the QP (lqp_utils.jl:306-393 boxes
+// included), with complementarity exactly zero.  act: 0 free, 1 at the lower bound, 2 at the upper bound.
+__global__ void __launch_bounds__(TB) k_as_setup(Slab s, int from_ipm, int keep_base, int *act, double *ztry, double big) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const double lo = s.lo[k], hi = s.hi[k], z = s.z[k];
+    int a;
+    if (from_ipm) {
+      const double ll = s.ll[k], lu = s.lu[k];
+      bool aL = isfinite(lo) && ll > z - lo, aU = isfinite(hi) && lu > hi - z;
+      if (aL && aU) { aL = ll >= lu; aU = !aL; }
+      a = aL ? 1 : (aU ? 2 : 0);
+      act[k] = a;
+    } else {
+      a = act[k];
+    }
+    if (!keep_base) ztry[k] = a == 1 ? lo : (a == 2 ? hi : fmin(fmax(z, lo), hi));  // (keep_base: only D changes)
+    s.D[k] = a ? big : 0.0;
+    s.w[k] = 0.0;
+  }
+}
+
+// counters[0] += variables released (negative multiplier), counters[1] += variables activated (outside their box),
+// counters[2] |= a NaN step was seen; worst_bits = max over the changes of the multiplier's resp. the violation's magnitude
+__global__ void __launch_bounds__(TB) k_as_check(Slab s, int *act, const double *ztry, double big, double tol_p, double tol_l,
+                                                 int *counters, unsigned long long *worst_bits) {
+  __shared__ double sh[TB];
+  double rel = 0.0, add = 0.0, bad = 0.0, worst = 0.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const int a = act[k];
+    const double dz = s.dz[k];
+    if (!(dz == dz)) { bad = 1.0; continue; }
+    if (a) {
+      const double lam = a == 1 ? -big * dz : big * dz;  // multiplier of the active side
+      if (lam < -tol_l) { act[k] = 0; rel += 1.0; worst = fmax(worst, -lam); }
+    } else {
+      const double lo = s.lo[k], hi = s.hi[k], zt = ztry[k] + dz;
+      if (zt < lo - tol_p * fmax(1.0, fabs(lo))) { act[k] = 1; add += 1.0; worst = fmax(worst, lo - zt); }
+      else if (zt > hi + tol_p * fmax(1.0, fabs(hi))) { act[k] = 2; add += 1.0; worst = fmax(worst, zt - hi); }
+    }
+  }
+  rel = block_sum(rel, sh);
+  add = block_sum(add, sh);
+  bad = block_max(bad, sh);
+  worst = block_max(worst, sh);
+  if (threadIdx.x == 0) {
+    if (rel > 0.0) atomicAdd(&counters[0], (int)fmin(rel, 1e6));
+    if (add > 0.0) atomicAdd(&counters[1], (int)fmin(add, 1e6));
+    if (bad > 0.0) atomicMax(&counters[2], 1);
+    if (worst > 0.0) atomicMax(worst_bits, (unsigned long long)__double_as_longlong(worst));
+  }
+}
+
+// accepted: z <- bound on the active set, base + step (kept inside the box against round-off) elsewhere
+__global__ void __launch_bounds__(TB) k_as_accept(Slab s, const int *act, const double *ztry) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const int a = act[k];
+    const double lo = s.lo[k], hi = s.hi[k];
+    s.z[k] = a == 1 ? lo : (a == 2 ? hi : fmin(fmax(ztry[k] + s.dz[k], lo), hi));
+  }
+}
+__global__ void __launch_bounds__(TB) k_add(double *out, const double *a, const double *b, long long n) {
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) out[k] = a[k] + b[k];
+}
+
 // Input checks of the host-pointer ABI, on the device after the upload (the host would scan ~320 MB per call at config D):
 // flags[0] |= 1 if lx or ux holds a NaN, flags[1] |= 1 if lu or uu does (sentinels of c_interface.jl:56-70),
 // flags[2] |= 1 if some Q_j or R_j block is not exactly symmetric (then the generic kernels must be used).
@@ -483,6 +554,21 @@ void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int 
 // partial slots never hold stale values.
 void launch_violation(const Slab &sl, double *part_max, hipStream_t s) {
   hipLaunchKernelGGL(k_violation, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, part_max);
+}
+void launch_as_setup(const Slab &sl, int from_ipm, int keep_base, int *act, double *ztry, double big, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_setup, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, from_ipm, keep_base, act, ztry, big);
+}
+void launch_as_check(const Slab &sl, int *act, const double *ztry, double big, double tol_p, double tol_l, int *counters,
+                     unsigned long long *worst_bits, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_check, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry, big, tol_p, tol_l, counters, worst_bits);
+}
+void launch_as_accept(const Slab &sl, const int *act, const double *ztry, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_accept, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry);
+}
+void launch_add(double *out, const double *a, const double *b, long long n, hipStream_t s) {
+  long long nb = (n + TB - 1) / TB;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_add, dim3((unsigned)nb), dim3(TB), 0, s, out, a, b, n);
 }
 void launch_ipm_clip(const Slab &sl, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_clip, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl);

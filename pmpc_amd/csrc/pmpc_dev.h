@@ -131,6 +131,12 @@ void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hip
 void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc, hipStream_t s);
 void launch_violation(const Slab &sl, double *part_max, hipStream_t s);
 void launch_ipm_clip(const Slab &sl, hipStream_t s);
+// primal-dual active-set finish (kernels_ipm.hip): act 0 free / 1 lower / 2 upper; counters = {released, activated, NaN seen}
+void launch_as_setup(const Slab &sl, int from_ipm, int keep_base, int *act, double *ztry, double big, hipStream_t s);
+void launch_as_check(const Slab &sl, int *act, const double *ztry, double big, double tol_p, double tol_l, int *counters,
+                     unsigned long long *worst_bits, hipStream_t s);
+void launch_as_accept(const Slab &sl, const int *act, const double *ztry, hipStream_t s);
+void launch_add(double *out, const double *a, const double *b, long long n, hipStream_t s);
 void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s, double thr_frac = 1e-2);
 void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s);

@@ -147,6 +147,9 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
+  DevBuf as_act, as_cnt;  // active-set iteration: status per bounded control (int), counters
+  long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
+  double as_scale = 1.0;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
   SlabBufs sx, su;
 };
@@ -338,7 +341,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -499,6 +502,8 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
   }
   HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+  const long long as_prev = w.as_key;  // accepted active set + solution of the previous solve (valid only if nothing ran since)
+  w.as_key = -1;
   if (!has_slew || !has_slew0) {
     if (w.zslew.bytes < (size_t)M * D8 || w.zum1.bytes < (size_t)M * u * D8) {
       w.zslew.ensure((size_t)M * D8); w.zslew0.ensure((size_t)M * D8); w.zum1.ensure((size_t)M * u * D8);
@@ -786,6 +791,88 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     if (c->sc_host->viol_max <= 0.0 && mu_target == 0.0) return 0;  // (a barrier acts on feasible points too)
     return 1;
   };
+  // ---- primal-dual active-set iteration on the control boxes (kernels_ipm.hip, k_as_*) -----------------------------------
+  // Given a guess of the active set, ONE structured solve from a base point with those controls ON their bounds gives the
+  // exact optimum on that set; a check pass verifies the KKT signs and, where they fail, applies the primal-dual active-set
+  // update (release negative multipliers, hold violated boxes).  An unchanged set is the optimum of the QP, complementarity
+  // exactly zero.  Two uses: (a) FINISH of the interior-point iteration — once mu <= polish_mu * mu_peak its iterate names
+  // the set (l > slack), which replaces the last predictor-corrector iterations (4 sweeps each) by a few factor + forward
+  // sweeps; (b) WARM START — the accepted set of the previous solve of this shape (consecutive SCP sub-problems differ in a
+  // few hundred of ~1e6 entries) starts the next solve directly: no equality-only phase, no interior-point iteration.
+  // If the set does not settle the interior-point iteration runs (on), its state untouched.  Control boxes only (a state
+  // cannot be moved onto its bound without leaving the dynamics); not in barrier mode.
+  static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
+  static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
+  const bool polish_on = polish_mu > 0.0 && has_ub && !has_xb && mu_target == 0.0;
+  const long long as_key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0);
+  // mode 1: guess from the interior-point iterate in (w.U, slacks, multipliers); mode 0: the stored set, base point = w.U
+  // (the previous solution).  Returns 0 accepted (w.X, w.U hold the optimum), 1 not settled, 2 numerical failure.
+  auto active_set_solve = [&](double dual_scale, int mode, int max_rounds) -> int {
+    // `big` never meets a normal-sized term in a sum (the penalty's target is a ZERO step), so it only has to dwarf every
+    // H_uu entry: gains, H_uu^-1 and the step of a held control come out ~1e-30 relative and -big du_b is its multiplier
+    const double big = 1e30, tol_p = 1e-13;
+    w.as_act.ensure(nu * sizeof(int)); w.as_cnt.ensure(4 * sizeof(int) + 8);
+    int *act = (int *)w.as_act.p, *cnt = (int *)w.as_cnt.p;
+    unsigned long long *worst_dev = (unsigned long long *)(cnt + 4);
+    double *Xtry = w.dX2.d(), *Utry = w.dU2.d();  // (free here: the corrector's difference step is already applied)
+    LQArgs b = a;
+    b.X = Xtry; b.U = Utry; b.Dx = b.wx = nullptr; b.Du = su.D; b.wu = su.w; b.dX = w.dX.d(); b.dU = w.dU.d();
+    Slab st = su;
+    st.z = w.U.d(); st.dz = w.dU.d(); st.dz2 = nullptr;
+    int last_add = 1, last_changes = 0x7fffffff, stalls = 0;
+    w.as_key = -1;
+    for (int round = 0; round < max_rounds; round++) {
+      // anti-cycling on (nearly) degenerate boxes — a control at its bound with a multiplier of a few ulps flips for ever —:
+      // the sign tolerance of the multipliers widens tenfold per round after the fourth, up to 1e-8 of the dual scale
+      const double tol_l = dual_scale * std::min(1e-8, 1e-11 * std::pow(10.0, std::max(0, round - 3)));
+      // a round that only RELEASED controls keeps its base point (a released control may start from its bound): no new
+      // rollout, and the gradient pre-pass arrays of the fast path are still valid; only D changes
+      const bool same_base = round > 0 && last_add == 0;
+      launch_as_setup(st, round == 0 ? mode : 0, same_base, act, Utry, big, s);
+      if (!same_base) {
+        if (fast) launch_rollout_fast(b, Utry, Xtry, s);
+        else launch_rollout(b, Utry, Xtry, s);
+      }
+      structured_solve(c, b, true, fast, /*prep_done=*/same_base);
+      inf.structured_solves++;
+      inf.active_set_rounds++;
+      HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
+      launch_as_check(st, act, Utry, big, tol_p, tol_l, cnt, worst_dev, s);
+      if (c->multi()) {
+        allreduce(c, cnt, 3, ncclInt32, ncclSum);
+        allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
+      }
+      struct { int rel, add, bad, pad; unsigned long long worst; int fail; } hc;
+      HIP_CHECK(hipMemcpyAsync(&hc, cnt, 4 * sizeof(int) + 8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(&hc.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      double worst;
+      memcpy(&worst, &hc.worst, sizeof(double));
+      if (verbose)
+        printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest %.2e)%s\n", mode ? "finish" : "warm", round + 1,
+               hc.rel, hc.add, worst, (hc.bad || hc.fail) ? " (numerical failure)" : "");
+      if (hc.bad || hc.fail) return 2;
+      last_add = hc.add;
+      const int changes = hc.rel + hc.add;
+      if (changes == 0) {
+        launch_as_accept(st, act, Utry, s);
+        launch_add(w.X.d(), Xtry, w.dX.d(), (long long)nx, s);
+        w.as_key = as_key;  // act + w.U start the next solve of this shape
+        w.as_scale = dual_scale;
+        return 0;
+      }
+      if (changes * 2 > last_changes && ++stalls >= 2) return 1;  // not contracting: leave it to the interior-point iteration
+      last_changes = changes;
+    }
+    return 1;
+  };
+  if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key) {
+    a.Dx = a.wx = nullptr;
+    const int r = active_set_solve(w.as_scale, 0, 8);
+    if (r == 0) return finish(0);
+    if (verbose) printf("pmpc_hip: warm active-set iteration not settled (%d): interior-point path\n", r);
+    if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+  }
   // Warm start (see below): when the previous solve of this shape ended in the interior-point phase, go there directly —
   // the equality-only solve (one factorisation + forward sweep) would only tell us that the boxes are active again; it
   // is done later if the warm attempt is rejected or fails
@@ -857,6 +944,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     int status = 1;
     double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
                            // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
+    double polish_next = polish_mu;  // try the active-set finish once mu <= polish_next * mu_peak (relative, like `tol`)
     bool advanced = false;  // this iteration's elementwise pass is already in flight (launched behind the last exchange)
     for (int it = 1; it <= max_iter; it++) {
       // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
@@ -894,6 +982,17 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       if (it == max_iter) break;
+      if (polish_on && it > 1 && h.mu <= polish_next * mu_peak) {
+        const double mu_now = h.mu;  // (h aliases the host snapshot)
+        const int r = active_set_solve(std::max(1.0, mu_peak), 1, 6);
+        if (r == 0) { inf.mu = 0.0; status = 0; break; }
+        // not settled: the interior-point state (U, X, slacks, multipliers) is untouched; rebuild what the attempt
+        // overwrote (D, w, gradient pre-pass arrays) and go on; try again two orders of magnitude further down
+        if (verbose) printf("pmpc_hip: active-set finish not settled (%d): continuing the interior-point iteration\n", r);
+        polish_next = mu_now / mu_peak * 1e-2;
+        if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+        launch_ipm_advance(ex, eu, 0, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
+      }
       // predictor (factorisation) ...
       structured_solve(c, a, true, fast, /*prep_done=*/true);
       inf.structured_solves++;
