@@ -545,7 +545,13 @@ __global__ void __launch_bounds__(256) k_particle_cost(LQArgs a, const double *X
 // Stage data (F_j, K_j, k_j resp. U_j - U_prev_j, f_j, X_prev_j) is loaded one stage ahead; lanes
 // without an entry read the zero buffer through a zero-stride pointer.
 // ------------------------------------------------------------------------------------------------
-template <int XD, int UD, bool ROLLOUT>
+// AS (active-set mode, !ROLLOUT): the sweep also carries out the primal-dual active-set update of the control boxes as it
+// goes — a held control whose multiplier (-/+ big du) is negative is released, a free control that would leave its box is
+// clamped onto the bound and held from now on — and propagates the CLAMPED step, so that base + step is the next
+// dynamics-consistent base point with every held control exactly on its bound (later stages react to the clamped state
+// through their feedback gains, as in a control-limited DDP forward pass).  With no change anywhere the step is the exact
+// optimum on the current set.  Writes the new statuses and per-particle change counters.
+template <int XD, int UD, bool ROLLOUT, bool AS = false>
 __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, double *Xout) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
@@ -590,6 +596,13 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
   load_row(pF, Fn);
   Kn = *pK;
   kn = *pk;
+  // active-set mode: status, box and base value of control g, per k-group (prefetched like k_j)
+  int actn = 0, nrel = 0, nadd = 0, nbad = 0;
+  double lon = 0.0, hin = 0.0, ubn = 0.0;
+  if (AS && gu) {
+    actn = *(const int *)((const char *)a.as_act + (ou_g >> 1));
+    lon = ldo(a.as_lo, ou_g); hin = ldo(a.as_hi, ou_g); ubn = ldo(a.U, ou_g);
+  }
   un = ROLLOUT ? *pu - *pup : 0.0;
   if (ROLLOUT) {
 #pragma unroll
@@ -604,6 +617,8 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
 #pragma unroll
     for (int r = 0; r < KS; r++) { Fr[r] = Fn[r]; fr[r] = fn[r]; xpr[r] = xpn[r]; }
     const double Kreg = Kn, kreg = kn, ureg = un;
+    const int actc = actn;
+    const double loc = lon, hic = hin, ubc = ubn;
     if (j == 0) {  // A~_0 = 0
 #pragma unroll
       for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
@@ -626,6 +641,10 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         Kn = *pK;
         pk = badd(pk, sk);
         kn = *pk;
+        if (AS && gu) {
+          actn = *(const int *)((const char *)a.as_act + ((ou_g + SU) >> 1));
+          lon = ldo(a.as_lo, ou_g + SU); hin = ldo(a.as_hi, ou_g + SU); ubn = ldo(a.U, ou_g + SU);
+        }
       }
     }
     double ycol;
@@ -633,7 +652,33 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
       ycol = L.cxv ? xcol : ureg;  // ureg is zero off the control columns
     } else {
       double du_c;
-      if (j < Nc) {
+      if (AS) {
+        // du[g] in every lane of k-group g: the shared consensus step (identical in every particle, so are the decisions)
+        // resp. the feedback law on the (clamped) state
+        double dug;
+        if (j < Nc) dug = gu ? a.duc[j * UD + g] : 0.0;
+        else dug = -row_allsum(Kreg * xcol) - kreg;
+        const bool cnt_here = store_u && (j >= Nc || i == 0);
+        int anew = actc;
+        if (gu) {
+          if (!(dug == dug)) nbad |= 1;
+          if (actc) {
+            const double lam = actc == 1 ? -a.as_big * dug : a.as_big * dug;  // multiplier of the held side
+            if (lam < -a.as_tol_l) { anew = 0; nrel += cnt_here ? 1 : 0; }
+            dug = 0.0;  // held (a released control starts the next round from its bound)
+          } else {
+            const double zt = ubc + dug;
+            if (zt < loc - a.as_tol_p * fmax(1.0, fabs(loc))) { anew = 1; dug = loc - ubc; nadd += cnt_here ? 1 : 0; }
+            else if (zt > hic + a.as_tol_p * fmax(1.0, fabs(hic))) { anew = 2; dug = hic - ubc; nadd += cnt_here ? 1 : 0; }
+          }
+        }
+        const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
+        du_c = L.cu ? t : 0.0;
+        if (store_u) {
+          *(double *)((char *)a.dU + ou_g) = dug;
+          *(int *)((char *)a.as_act + (ou_g >> 1)) = anew;
+        }
+      } else if (j < Nc) {
         du_c = *pdc;  // shared consensus step (zero off the control columns)
         pdc = badd(pdc, sdc);
         if (store_u) {
@@ -684,6 +729,56 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
     ox_row += SX;
     ou_g += SU;
   }
+  if (AS) {  // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
+    const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
+    if (lane == 0) {
+      a.as_cnt[3 * i + 0] = (int)r;
+      a.as_cnt[3 * i + 1] = (int)d;
+      a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
+    }
+  }
+}
+
+// base point of an active-set round and everything the factor sweep needs at it (see launch_as_prep in pmpc_dev.h)
+__global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double *Du) {
+  const long long nx = (long long)a.M * a.N * a.x, nu = (long long)a.M * a.N * a.u;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long perx = (long long)a.N * a.x, peru = (long long)a.N * a.u;
+  double *Xb = const_cast<double *>(a.X), *Ub = const_cast<double *>(a.U);
+  for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nx; k += stride) {
+    double X = Xb[k];
+    if (add_step) { X += a.dX[k]; Xb[k] = X; }
+    const double pw = a.pw ? a.pw[k / perx] : 1.0;
+    a.xm[k] = pw * (X - a.X_ref[k]);
+    a.xd[k] = pw * a.reg_x * (X - a.X_prev[k]);
+  }
+  for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nu; k += stride) {
+    const int act = a.as_act[k];
+    double U = Ub[k];
+    if (add_step) U += a.dU[k];
+    if (act) U = act == 1 ? a.as_lo[k] : a.as_hi[k];  // exactly on the bound
+    if (add_step || act) Ub[k] = U;
+    const double pw = a.pw ? a.pw[k / peru] : 1.0;
+    a.um[k] = pw * (U - a.U_ref[k]);
+    a.ud[k] = pw * a.reg_u * (U - a.U_prev[k]);
+    Du[k] = act ? a.as_big : 0.0;
+  }
+}
+__global__ void __launch_bounds__(256) k_as_reduce(const int *cnt_part, int M, int *counters) {
+  __shared__ int sh[3][256];
+  int r = 0, d = 0, b = 0;
+  for (int i = threadIdx.x; i < M; i += 256) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
+  sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+      sh[2][threadIdx.x] |= sh[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { counters[0] = sh[0][0]; counters[1] = sh[1][0]; counters[2] = sh[2][0]; }
 }
 
 
@@ -782,7 +877,8 @@ void launch_cond_t(const LQArgs &a, hipStream_t s) {
 }
 template <int XD, int UD>
 void launch_fwd_t(const LQArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
+  if (a.as_act) hipLaunchKernelGGL((k_fwd_fast<XD, UD, false, true>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
+  else hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
 }
 template <int XD, int UD>
 void launch_rollout_t(const LQArgs &a, const double *U, double *X, hipStream_t s) {
@@ -833,6 +929,16 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s) {
   long long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
   hipLaunchKernelGGL(k_grad_prep, dim3((unsigned)b), dim3(256), 0, s, a);
+}
+
+void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s) {
+  long long n = (long long)a.M * a.N * a.x;
+  long long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du);
+}
+void launch_as_reduce(const int *cnt_part, int M, int *counters, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_reduce, dim3(1), dim3(256), 0, s, cnt_part, M, counters);
 }
 
 void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s) {

@@ -51,6 +51,12 @@ struct LQArgs {
   const double *duc;  // [nc] consensus step
   // outputs of the forward sweep
   double *dX, *dU;
+  // active-set mode of the fast forward sweep (null = off): per control status (0 free / 1 at lower / 2 at upper bound), its
+  // box, and per-particle counters {released, activated, NaN seen}; the base controls are `U`
+  int *as_act;
+  const double *as_lo, *as_hi;
+  int *as_cnt;
+  double as_big, as_tol_p, as_tol_l;
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
@@ -118,6 +124,10 @@ void launch_fwd_fast(const LQArgs &a, hipStream_t s);
 void launch_cond_fast(const LQArgs &a, hipStream_t s);  // off-diagonal blocks of the condensed consensus Hessian (Nc > 1)
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_grad_prep(const LQArgs &a, hipStream_t s);
+// active-set rounds on the fast path: base point <- base + last (clamped) step (add_step), held controls exactly on their
+// bounds, Du = big on them, and the gradient pre-pass arrays of the factor sweep at that point (replaces launch_grad_prep)
+void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s);
+void launch_as_reduce(const int *cnt_part, int M, int *counters, hipStream_t s);  // counters[0..2] = column sums / max
 // J[i] = 1/2 z_i' P_i z_i + q_i' z_i + r_i of PMPC.jl/src/qp_utils.jl:60-162 at (X, U) (unweighted), any dims / slew
 void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s);
 

@@ -147,7 +147,7 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
-  DevBuf as_act, as_cnt;  // active-set iteration: status per bounded control (int), counters
+  DevBuf as_act, as_cnt, as_cntp;  // active-set iteration: status per bounded control (int), counters, per-particle counters
   long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
   double as_scale = 1.0;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
@@ -341,7 +341,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -819,25 +819,40 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     b.X = Xtry; b.U = Utry; b.Dx = b.wx = nullptr; b.Du = su.D; b.wu = su.w; b.dX = w.dX.d(); b.dU = w.dU.d();
     Slab st = su;
     st.z = w.U.d(); st.dz = w.dU.d(); st.dz2 = nullptr;
+    if (fast) {
+      w.as_cntp.ensure((size_t)M * 3 * sizeof(int));
+      HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
+      b.as_act = act; b.as_lo = su.lo; b.as_hi = su.hi; b.as_cnt = (int *)w.as_cntp.p; b.as_big = big; b.as_tol_p = tol_p;
+    }
     int last_add = 1, last_changes = 0x7fffffff, stalls = 0;
     w.as_key = -1;
     for (int round = 0; round < max_rounds; round++) {
       // anti-cycling on (nearly) degenerate boxes — a control at its bound with a multiplier of a few ulps flips for ever —:
       // the sign tolerance of the multipliers widens tenfold per round after the fourth, up to 1e-8 of the dual scale
       const double tol_l = dual_scale * std::min(1e-8, 1e-11 * std::pow(10.0, std::max(0, round - 3)));
-      // a round that only RELEASED controls keeps its base point (a released control may start from its bound): no new
-      // rollout, and the gradient pre-pass arrays of the fast path are still valid; only D changes
-      const bool same_base = round > 0 && last_add == 0;
-      launch_as_setup(st, round == 0 ? mode : 0, same_base, act, Utry, big, s);
-      if (!same_base) {
-        if (fast) launch_rollout_fast(b, Utry, Xtry, s);
-        else launch_rollout(b, Utry, Xtry, s);
+      if (fast) {
+        // fast path: the forward sweep itself clamps, tests the held controls' multipliers and propagates the clamped step
+        // (k_fwd_fast<AS>), so base + step is the next round's base point: no rollout and no check pass after round 1
+        b.as_tol_l = tol_l;
+        if (round == 0) {
+          launch_as_setup(st, mode, 0, act, Utry, big, s);
+          launch_rollout_fast(b, Utry, Xtry, s);
+        }
+        launch_as_prep(b, round > 0, su.D, s);
+        structured_solve(c, b, true, true, /*prep_done=*/true);
+        launch_as_reduce((const int *)w.as_cntp.p, M, cnt, s);
+      } else {
+        // a round that only RELEASED controls keeps its base point (a released control may start from its bound): no new
+        // rollout; only D changes
+        const bool same_base = round > 0 && last_add == 0;
+        launch_as_setup(st, round == 0 ? mode : 0, same_base, act, Utry, big, s);
+        if (!same_base) launch_rollout(b, Utry, Xtry, s);
+        structured_solve(c, b, true, false);
+        HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
+        launch_as_check(st, act, Utry, big, tol_p, tol_l, cnt, worst_dev, s);
       }
-      structured_solve(c, b, true, fast, /*prep_done=*/same_base);
       inf.structured_solves++;
       inf.active_set_rounds++;
-      HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
-      launch_as_check(st, act, Utry, big, tol_p, tol_l, cnt, worst_dev, s);
       if (c->multi()) {
         allreduce(c, cnt, 3, ncclInt32, ncclSum);
         allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
