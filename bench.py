@@ -246,6 +246,7 @@ def main():
     timed = hist[args.warmup:]
     ipm_its = [h[1]["ipm_iters"] for h in timed]
     solves = [h[1]["structured_solves"] for h in timed]
+    as_rounds = [h[1]["active_set_rounds"] for h in timed]
 
     if rank == 0:
         value = args.steps / elapsed
@@ -271,6 +272,7 @@ def main():
                                    f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u" + (" + thrust cone per stage (config E constraints, fp64)" if args.soc else ""),
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",
                        "ipm_iters_per_step": float(np.mean(ipm_its)), "riccati_factorisations_per_step": float(np.mean(solves)),
+                       "active_set_rounds_per_step": float(np.mean(as_rounds)),
                        "fast_path": bool(timed[-1][1]["fast_path"]), "final_scp_residual": float(timed[-1][0].item()),
                        "aff_solve_only_cold_per_s": aff_only,
                        "ipm_warm_start": os.environ.get("PMPC_WARM_START", "1") != "0"},

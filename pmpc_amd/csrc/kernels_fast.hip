@@ -764,7 +764,10 @@ __global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double 
     Du[k] = act ? a.as_big : 0.0;
   }
 }
-__global__ void __launch_bounds__(256) k_as_reduce(const int *cnt_part, int M, int *counters) {
+// counters[0..2] = particle sums of {released, activated, NaN seen}, counters[3] = the solve's failure flag; single rank:
+// published straight into host-coherent memory (the host polls `seq`, as for the interior-point scalars)
+__global__ void __launch_bounds__(256) k_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt,
+                                                   unsigned long long *mirror_seq, unsigned long long seq) {
   __shared__ int sh[3][256];
   int r = 0, d = 0, b = 0;
   for (int i = threadIdx.x; i < M; i += 256) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
@@ -778,7 +781,26 @@ __global__ void __launch_bounds__(256) k_as_reduce(const int *cnt_part, int M, i
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { counters[0] = sh[0][0]; counters[1] = sh[1][0]; counters[2] = sh[2][0]; }
+  if (threadIdx.x == 0) {
+    const int f = *fail;
+    counters[0] = sh[0][0]; counters[1] = sh[1][0]; counters[2] = sh[2][0]; counters[3] = f;
+    if (mirror_cnt) {
+      mirror_cnt[0] = sh[0][0]; mirror_cnt[1] = sh[1][0]; mirror_cnt[2] = sh[2][0]; mirror_cnt[3] = f;
+      __threadfence_system();
+      *(volatile unsigned long long *)mirror_seq = seq;
+    }
+  }
+}
+// counters[3] <- failure flag (fail != null), and / or publication of counters[0..3] (mirror_cnt != null)
+__global__ void k_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq) {
+  if (threadIdx.x == 0) {
+    if (fail) counters[3] = *fail;
+    if (mirror_cnt) {
+      for (int k = 0; k < 4; k++) mirror_cnt[k] = counters[k];
+      __threadfence_system();
+      *(volatile unsigned long long *)mirror_seq = seq;
+    }
+  }
 }
 
 
@@ -937,8 +959,12 @@ void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s) {
   if (b > 2048) b = 2048;
   hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du);
 }
-void launch_as_reduce(const int *cnt_part, int M, int *counters, hipStream_t s) {
-  hipLaunchKernelGGL(k_as_reduce, dim3(1), dim3(256), 0, s, cnt_part, M, counters);
+void launch_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq,
+                      unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_reduce, dim3(1), dim3(256), 0, s, cnt_part, M, counters, fail, mirror_cnt, mirror_seq, seq);
+}
+void launch_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_publish, dim3(1), dim3(64), 0, s, counters, fail, mirror_cnt, mirror_seq, seq);
 }
 
 void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s) {

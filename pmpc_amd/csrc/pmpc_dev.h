@@ -127,7 +127,11 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s);
 // active-set rounds on the fast path: base point <- base + last (clamped) step (add_step), held controls exactly on their
 // bounds, Du = big on them, and the gradient pre-pass arrays of the factor sweep at that point (replaces launch_grad_prep)
 void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s);
-void launch_as_reduce(const int *cnt_part, int M, int *counters, hipStream_t s);  // counters[0..2] = column sums / max
+// counters[0..2] = {released, activated, NaN seen} over the particles, counters[3] = *fail; mirror_cnt != null: also published
+// to host-coherent memory with sequence number `seq`
+void launch_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq,
+                      unsigned long long seq, hipStream_t s);
+void launch_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s);
 // J[i] = 1/2 z_i' P_i z_i + q_i' z_i + r_i of PMPC.jl/src/qp_utils.jl:60-162 at (X, U) (unweighted), any dims / slew
 void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s);
 

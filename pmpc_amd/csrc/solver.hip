@@ -171,9 +171,9 @@ struct pmpc_ctx {
   IpmScal *sc_host = nullptr;  // host snapshot of the device scalars
   int *fail_host = nullptr;
   // host-coherent mapped mirror the exchange kernel publishes into (zero-copy; the host polls `seq`)
-  struct ScMirror { IpmScal sc; unsigned long long seq; };
+  struct ScMirror { IpmScal sc; unsigned long long seq; int as_cnt[4]; unsigned long long as_seq; };
   ScMirror *mirror = nullptr, *mirror_dev = nullptr;
-  unsigned long long seq = 0;
+  unsigned long long seq = 0, as_seq = 0;
   // RCCL
   ncclComm_t comm = nullptr;
   bool mock_comm = false;  // comm is a MockRank (test hook), not an RCCL communicator
@@ -222,23 +222,25 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
   }
 };
 
-void read_scalars(pmpc_ctx *c) {  // sc->status carries the (cross-rank) failure flag of the last exchange
-  // the last exchange kernel published the scalars + its sequence number into host-coherent memory: poll for it
-  // (a blit kernel + stream sync costs ~25 us of idle GPU per IPM iteration); fall back to a stream sync after ~2 s
-  volatile unsigned long long *seq = &c->mirror->seq;
+// wait until the device has published sequence number `want` into host-coherent memory: poll (a blit kernel + stream sync
+// costs ~25 us of idle GPU per read); fall back to a stream sync after ~2 s
+void wait_published(pmpc_ctx *c, volatile unsigned long long *seq, unsigned long long want) {
   bool seen = false;
   for (long long spin = 0; spin < (1LL << 31); spin++) {
-    if (*seq == c->seq) { seen = true; break; }
+    if (*seq == want) { seen = true; break; }
     __builtin_ia32_pause();
   }
   if (!seen) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (*seq != c->seq) {
-      fprintf(stderr, "pmpc_hip: scalar exchange was never published\n");
+    if (*seq != want) {
+      fprintf(stderr, "pmpc_hip: device scalars were never published\n");
       abort();
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+void read_scalars(pmpc_ctx *c) {  // sc->status carries the (cross-rank) failure flag of the last exchange
+  wait_published(c, &c->mirror->seq, c->seq);
   memcpy(c->sc_host, (const void *)&c->mirror->sc, sizeof(IpmScal));
   *c->fail_host = c->sc_host->status;
 }
@@ -840,7 +842,8 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         }
         launch_as_prep(b, round > 0, su.D, s);
         structured_solve(c, b, true, true, /*prep_done=*/true);
-        launch_as_reduce((const int *)w.as_cntp.p, M, cnt, s);
+        launch_as_reduce((const int *)w.as_cntp.p, M, cnt, (const int *)w.fail.p, c->multi() ? nullptr : c->mirror_dev->as_cnt,
+                         &c->mirror_dev->as_seq, ++c->as_seq, s);
       } else {
         // a round that only RELEASED controls keeps its base point (a released control may start from its bound): no new
         // rollout; only D changes
@@ -850,17 +853,22 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         structured_solve(c, b, true, false);
         HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
         launch_as_check(st, act, Utry, big, tol_p, tol_l, cnt, worst_dev, s);
+        launch_as_publish(cnt, (const int *)w.fail.p, c->multi() ? nullptr : c->mirror_dev->as_cnt, &c->mirror_dev->as_seq, ++c->as_seq, s);
       }
       inf.structured_solves++;
       inf.active_set_rounds++;
-      if (c->multi()) {
-        allreduce(c, cnt, 3, ncclInt32, ncclSum);
-        allreduce(c, w.fail.p, 1, ncclInt32, ncclMax);
+      if (c->multi()) {  // {released, activated, NaN, failure}: one sum for all four
+        allreduce(c, cnt, 4, ncclInt32, ncclSum);
+        launch_as_publish(cnt, nullptr, c->mirror_dev->as_cnt, &c->mirror_dev->as_seq, c->as_seq, s);
       }
-      struct { int rel, add, bad, pad; unsigned long long worst; int fail; } hc;
-      HIP_CHECK(hipMemcpyAsync(&hc, cnt, 4 * sizeof(int) + 8, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipMemcpyAsync(&hc.fail, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipStreamSynchronize(s));
+      wait_published(c, &c->mirror->as_seq, c->as_seq);
+      struct { int rel, add, bad, fail; unsigned long long worst; } hc;
+      memcpy(&hc, (const void *)c->mirror->as_cnt, 4 * sizeof(int));
+      hc.worst = 0;
+      if (verbose && !fast) {  // (diagnostic of the check pass only)
+        HIP_CHECK(hipMemcpyAsync(&hc.worst, worst_dev, 8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+      }
       double worst;
       memcpy(&worst, &hc.worst, sizeof(double));
       if (verbose)
