@@ -185,6 +185,11 @@ int pmpc_comm_world(pmpc_ctx *ctx);
 int pmpc_linearize_device(pmpc_ctx *ctx, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu);
 
+/* SCP residual of one iteration (pmpc/scp_mpc.py:397-403): *out (device, one double) = max over particles and stages of
+ * ||X - X_prev||_2 and ||U - U_prev||_2 (inf if a trajectory holds a NaN); asynchronous on pmpc_stream(). */
+int pmpc_scp_residual_device(pmpc_ctx *ctx, size_t xdim, size_t udim, size_t N, size_t M, const double *X, const double *X_prev,
+                             const double *U, const double *U_prev, double *out);
+
 /* Live kernel timing for bench.py: HIP events on pmpc_stream() around the launches of a class
  * (0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve).
  * level 0 = off, 1 = class 0 only (the dominant kernel; what bench.py's roofline needs), 2 = every class

@@ -148,3 +148,39 @@ void launch_linearize(int model, int N, int M, const double *x0, const double *X
   if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, s);
   else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, s);
 }
+
+// SCP residual of pmpc/scp_mpc.py:397-403: max over (particle, stage) of the 2-norms of X - X_prev and U - U_prev, in one
+// pass (rows of d doubles; one thread per row, block max, then an atomic max on the bit pattern of the non-negative result)
+namespace {
+__global__ void __launch_bounds__(256) k_scp_residual(const double *X, const double *Xp, long long rows_x, int x, const double *U,
+                                                      const double *Up, long long rows_u, int u, unsigned long long *out_bits) {
+  __shared__ double sh[256];
+  double m = 0.0;
+  for (long long r = blockIdx.x * 256LL + threadIdx.x; r < rows_x + rows_u; r += (long long)gridDim.x * 256) {
+    const bool isx = r < rows_x;
+    const long long rr = isx ? r : r - rows_x;
+    const int d = isx ? x : u;
+    const double *a = (isx ? X : U) + rr * d, *b = (isx ? Xp : Up) + rr * d;
+    double acc = 0.0;
+    for (int k = 0; k < d; k++) { const double t = a[k] - b[k]; acc = fma(t, t, acc); }
+    const double nrm = sqrt(acc);
+    m = (nrm == nrm) ? fmax(m, nrm) : INFINITY;  // a NaN trajectory must not look converged
+  }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(sh[0]));
+}
+}  // namespace
+
+void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
+                         double *out, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), s));
+  long long nb = (2 * rows + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_scp_residual, dim3((unsigned)nb), dim3(256), 0, s, X, Xp, rows, x, U, Up, rows, u, (unsigned long long *)out);
+}
+

@@ -188,3 +188,5 @@ void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStr
 // ---- dynamics.hip -------------------------------------------------------------------------------
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                       const double *params, double *f, double *fx, double *fu, hipStream_t s);
+void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
+                         double *out, hipStream_t s);

@@ -434,6 +434,13 @@ int pmpc_comm_init_mock(pmpc_ctx *c, int rank, int world, int group) {
 int pmpc_comm_rank(pmpc_ctx *c) { return c->rank; }
 int pmpc_comm_world(pmpc_ctx *c) { return c->world; }
 
+int pmpc_scp_residual_device(pmpc_ctx *c, size_t xdim, size_t udim, size_t N, size_t M, const double *X, const double *X_prev,
+                             const double *U, const double *U_prev, double *out) {
+  HIP_CHECK(hipSetDevice(c->device));
+  launch_scp_residual(X, X_prev, U, U_prev, (long long)M * (long long)N, (int)xdim, (int)udim, out, c->stream);
+  return 0;
+}
+
 int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu) {
   HIP_CHECK(hipSetDevice(c->device));

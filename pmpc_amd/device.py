@@ -166,6 +166,14 @@ class DeviceSolver:
                                        _p(fu))
         return f, fx, fu
 
+    def scp_residual(self, X, X_prev, U, U_prev, out=None):
+        """max(max_ij ||X - X_prev||_2, max_ij ||U - U_prev||_2) of pmpc/scp_mpc.py:397-403 as a one-element device tensor
+        (one fused pass on the solver's stream; inf if a trajectory holds a NaN)."""
+        M, N, x = X.shape
+        out = torch.empty((1,), dtype=torch.float64, device=X.device) if out is None else out
+        self.lib.pmpc_scp_residual_device(self.h, x, U.shape[-1], N, M, _p(X), _p(X_prev), _p(U), _p(U_prev), _p(out))
+        return out
+
     def sync(self):
         self.lib.pmpc_sync(self.h)
 

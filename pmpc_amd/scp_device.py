@@ -138,8 +138,7 @@ def scp_solve_device(f_fx_fu_fn: Optional[Callable], Q, R, x0, X_ref=None, U_ref
         else:
             _, _, status = s.lqp_solve(**kw)
         with torch.cuda.stream(s.stream):  # residual / objective row of scp_mpc.py:397-405 on the solver's stream
-            dX, dU = Xs - X_prev, Us - U_prev
-            res = torch.maximum(torch.linalg.vector_norm(dX, dim=-1).max(), torch.linalg.vector_norm(dU, dim=-1).max())
+            res = s.scp_residual(Xs, X_prev, Us, U_prev)[0]
             eX, eU = Xs - X_ref, Us - U_ref
             obj = (torch.sum(eX * torch.einsum("mnrt,mnt->mnr", Q, eX)) + torch.sum(eU * torch.einsum("mnrt,mnt->mnr", R, eU))) / N / M
             row = torch.stack([res, obj]).cpu()  # the only device->host read of the iteration (synchronises the stream)

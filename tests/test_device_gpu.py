@@ -186,3 +186,29 @@ def test_full_size_thrust_cones(solver):
             if cone(U2).min() < -1e-12:
                 continue
             assert _objective(prob, _rollout_np(prob, f, fx, fu, U2), U2) >= J0 * (1 - 1e-12)
+
+
+def test_scp_residual_kernel_matches_the_reference_formula():
+    """pmpc_scp_residual_device vs max(max_ij |dX_ij|_2, max_ij |dU_ij|_2) of pmpc/scp_mpc.py:397-403; NaN -> inf."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    s = DeviceSolver(0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (M, N, x, u) in [(1, 1, 1, 1), (7, 13, 12, 4), (300, 50, 4, 2)]:
+        X, Xp = (torch.randn((M, N, x), dtype=torch.float64, device="cuda", generator=g) for _ in range(2))
+        U, Up = (torch.randn((M, N, u), dtype=torch.float64, device="cuda", generator=g) for _ in range(2))
+        if M > 1:
+            U[M // 2, N // 3] += 40.0  # the maximum sits on the control side
+        torch.cuda.synchronize()
+        r = s.scp_residual(X, Xp, U, Up)
+        s.sync()
+        ref = torch.maximum(torch.linalg.vector_norm(X - Xp, dim=-1).max(), torch.linalg.vector_norm(U - Up, dim=-1).max())
+        assert abs(float(r[0]) - float(ref)) <= 1e-13 * float(ref)
+    X[0, 0, 0] = float("nan")
+    torch.cuda.synchronize()
+    r = s.scp_residual(X, Xp, U, Up)
+    s.sync()
+    assert float(r[0]) == float("inf")
+    s.close()
