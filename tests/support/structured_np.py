@@ -358,3 +358,60 @@ def ipm_solve(p: Problem, allreduce=None, allreduce_min=None, allreduce_max=None
         nu *= (1.0 - a)
         info = dict(iters=it, status="ipm", mu=mu, alpha=a)
     return X, U, info
+
+
+def active_set_solve(p: Problem, allreduce=None, act0=None, U0=None, max_rounds=25, verbose=False):
+    """numpy model of the device's primal-dual active-set iteration on the control boxes (solver.hip `active_set_solve`,
+    check-pass variant of the generic kernels): per round ONE structured solve from a dynamics-consistent base point whose
+    held controls sit ON their bounds, the held controls penalised by `big` on their step (-/+ big du is their multiplier),
+    then the KKT sign check and the active-set update.  Cross-shard reductions: the sums inside StructuredLQ ([Hc | gc]) and
+    ONE sum of the change counter per round — exactly what the GPU path all-reduces.  Cold start (act0 / U0 None): the
+    equality-only optimum, set = its violated boxes.  Returns X, U, info(rounds, act)."""
+    ar = allreduce or (lambda a: a)
+    M, N, u, Nc = p.M, p.N, p.u, p.Nc
+    assert p.has_ub and not p.has_xb
+    lq = StructuredLQ(p, allreduce=ar)
+    _, _, lu, uu = _bounds(p)
+    if Nc > 0:
+        lu[:, :Nc], uu[:, :Nc] = lu[0:1, :Nc], uu[0:1, :Nc]
+    owner = getattr(p, "owns_consensus", True)
+    big, tol_p, tol_l = 1e30, 1e-13, 1e-11
+
+    def newton(Xb, Ub, Du):
+        gx, gu, gc0 = p.gradient(Xb, Ub)
+        gce = np.zeros(Nc * u)
+        if Nc > 0:
+            gce[:u] = ar(gc0.sum(0))
+        Dc = None
+        if Nc > 0:  # a consensus bound is ONE constraint: its penalty enters the summed system once, from the owner shard
+            Dc = ar(Du[0, :Nc].reshape(-1) if owner else np.zeros(Nc * u))
+        lq.factor(None, Du, Dc)
+        return lq.solve(gx, gu, gce if Nc > 0 else None)
+
+    if U0 is None:
+        U0 = np.array(p.U_prev)
+        if Nc > 0:
+            U0[:, :Nc] = 0.0
+        X0 = p.rollout(U0)
+        dX, dU = newton(X0, U0, np.zeros((M, N, u)))
+        U0 = U0 + dU
+    if act0 is None:
+        act0 = np.where(U0 < lu, 1, np.where(U0 > uu, 2, 0))
+    act, Ufree = np.array(act0), np.clip(U0, lu, uu)
+    for r in range(max_rounds):
+        Ub = np.where(act == 1, lu, np.where(act == 2, uu, Ufree))
+        Xb = p.rollout(Ub)
+        dX, dU = newton(Xb, Ub, np.where(act > 0, big, 0.0))
+        lam = np.where(act == 1, -big * dU, big * dU)
+        zt = Ub + dU
+        rel = (act > 0) & (lam < -tol_l)
+        add_l = (act == 0) & (zt < lu - tol_p * np.maximum(1.0, np.abs(lu)))
+        add_u = (act == 0) & (zt > uu + tol_p * np.maximum(1.0, np.abs(uu)))
+        changes = int(ar(np.array([float(rel.sum() + add_l.sum() + add_u.sum())]))[0])
+        if verbose:
+            print(f"active set round {r + 1}: {int(rel.sum())} released, {int(add_l.sum() + add_u.sum())} activated")
+        if changes == 0:
+            return Xb + dX, np.where(act > 0, Ub, np.clip(zt, lu, uu)), dict(rounds=r + 1, act=act)
+        act = np.where(rel, 0, np.where(add_l, 1, np.where(add_u, 2, act)))
+        Ufree = np.where(act > 0, Ub, zt)  # (held controls are replaced by their bounds above)
+    raise RuntimeError("active set did not settle")

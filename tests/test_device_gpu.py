@@ -212,3 +212,48 @@ def test_scp_residual_kernel_matches_the_reference_formula():
     s.sync()
     assert float(r[0]) == float("inf")
     s.close()
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["fast", "generic"])
+@pytest.mark.parametrize("case", [(16, 12, 12, 4, 1), (9, 10, 4, 2, -1), (8, 9, 5, 3, 0)], ids=["quadrotor-dims-Nc1", "NcN", "Nc0"])
+def test_warm_active_set_sequence_is_exact(case, generic, oracle):
+    """SCP-like sequence of related sub-problems through ONE context: the first solve ends in the active-set finish of the
+    interior-point iteration, every later one starts from the previous accepted set and solution (no interior-point
+    iteration at all) and must land on the oracle's vertex — tolerance 1e-10, far inside the 1e-7 of the interior-point path.
+    A solve with the cold-start flag (interior-point path) agrees."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+    from tests.support.problems import rand_problem
+
+    M, N, x, u, Nc = case
+    rng = np.random.default_rng(77)
+    args, kw = rand_problem(rng, M, N, x, u, 0.25)
+    s = DeviceSolver(0)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    for t in range(4):
+        if t:
+            x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+            args = (x0, f + 0.03 * rng.standard_normal(f.shape), fx * (1 + 0.03 * rng.standard_normal(fx.shape)),
+                    fu * (1 + 0.03 * rng.standard_normal(fu.shape)), X_prev + 0.03 * rng.standard_normal(X_prev.shape),
+                    U_prev + 0.03 * rng.standard_normal(U_prev.shape), Q, R, X_ref, U_ref)
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+        Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+        opt = dict(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref),
+                   U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, symmetric_cost=True, lu=dev(kw["u_l"]),
+                   uu=dev(kw["u_u"]), force_generic=generic)
+        X, U, status = s.lqp_solve(**opt)
+        s.sync()
+        info = dict(s.last_info)
+        assert status == 0 and info["fast_path"] == (0 if generic else 1)
+        assert info["active_set_rounds"] >= 1, info
+        if t:
+            assert info["ipm_iters"] == 0, info  # warm start: the active-set rounds alone
+        assert rel(X.cpu().numpy(), Xo) < 1e-10 and rel(U.cpu().numpy(), Uo) < 1e-10, (t, info)
+        Xc, Uc, status = s.lqp_solve(cold_start=True, **opt)
+        s.sync()
+        assert status == 0 and rel(Xc.cpu().numpy(), Xo) < 1e-7 and rel(Uc.cpu().numpy(), Uo) < 1e-7
+        # (the cold solve's accepted set is as good a start for the next sub-problem as the warm one's)
+    s.close()

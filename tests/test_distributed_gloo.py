@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, active_set=False):
     sys.path.insert(0, str(ROOT))
     import torch
     import torch.distributed as dist
@@ -50,8 +50,12 @@ def _worker(rank, world, port, case, out_dir):
 
     p = snp.Problem(*largs[1:], Nc=Nc, **lkw)
     p.owns_consensus = rank == 0
-    X, U, info = snp.ipm_solve(p, allreduce=red(dist.ReduceOp.SUM), allreduce_min=red(dist.ReduceOp.MIN),
-                               allreduce_max=red(dist.ReduceOp.MAX))
+    if active_set:  # the primal-dual active-set iteration: [Hc | gc] sums + one change-counter sum per round
+        X, U, info = snp.active_set_solve(p, allreduce=red(dist.ReduceOp.SUM))
+        info["iters"] = info["rounds"]
+    else:
+        X, U, info = snp.ipm_solve(p, allreduce=red(dist.ReduceOp.SUM), allreduce_min=red(dist.ReduceOp.MIN),
+                                   allreduce_max=red(dist.ReduceOp.MAX))
     np.savez(Path(out_dir) / f"rank{rank}.npz", X=X, U=U, iters=info["iters"])
     dist.destroy_process_group()
 
@@ -59,20 +63,33 @@ def _worker(rank, world, port, case, out_dir):
 @pytest.mark.parametrize("case", [(6, 7, 3, 2, 1, 0.3, None), (6, 7, 3, 2, 3, 0.3, 6.0), (4, 6, 3, 2, -1, None, None), (8, 6, 4, 2, 0, 0.3, None)],
                          ids=["Nc1-ubox", "Nc3-ubox-xbox", "NcN-free", "Nc0-ubox"])
 def test_sharded_solve_equals_joint_solve(case, oracle, tmp_path):
+    _run_sharded(case, oracle, tmp_path, False)
+
+
+@pytest.mark.parametrize("case", [(6, 7, 3, 2, 1, 0.3, None), (6, 7, 3, 2, 3, 0.2, None), (4, 6, 3, 2, -1, 0.05, None), (8, 6, 4, 2, 0, 0.3, None)],
+                         ids=["Nc1-ubox", "Nc3-ubox", "NcN-ubox", "Nc0-ubox"])
+def test_sharded_active_set_iteration_equals_joint_solve(case, oracle, tmp_path):
+    """The active-set rounds of the GPU path (solver.hip `active_set_solve`) on 2 gloo ranks: the consensus controls' status
+    is decided identically on both ranks from all-reduced quantities only."""
+    _run_sharded(case, oracle, tmp_path, True)
+
+
+def _run_sharded(case, oracle, tmp_path, active_set):
     import torch.multiprocessing as mp
 
     from tests.support.problems import rand_problem
 
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path), active_set), nprocs=world, join=True)
     M, N, x, u, Nc, bu, bx = case
     args, kw = rand_problem(np.random.default_rng(7), M, N, x, u, bu, bx)
     Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
     parts = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     X, U = np.concatenate([p["X"] for p in parts]), np.concatenate([p["U"] for p in parts])
     assert parts[0]["iters"] == parts[1]["iters"]  # identical all-reduced scalars => identical control flow
-    assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-7
-    assert np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0) < 1e-7
+    tol = 1e-10 if active_set else 1e-7  # the accepted active-set point is the vertex itself
+    assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < tol
+    assert np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0) < tol
     k = N if Nc < 0 else Nc
     if k:
         assert np.all(U[:, :k] == U[0:1, :k])  # consensus across ranks, bitwise

@@ -101,3 +101,30 @@ def test_structured_cpu_baseline_matches_oracle(case):
     assert info["status"] == 0
     assert np.linalg.norm(X - Xo) <= 1e-7 * np.linalg.norm(Xo)
     assert np.linalg.norm(U - Uo) <= 1e-7 * max(1.0, np.linalg.norm(Uo))
+
+
+@pytest.mark.parametrize("case", [(5, 8, 4, 2, 1, 0.3), (3, 9, 5, 3, -1, 0.1), (6, 7, 3, 2, 0, 0.2), (4, 10, 12, 4, 2, 0.4)],
+                         ids=["Nc1", "NcN", "Nc0", "quadrotor-dims-Nc2"])
+def test_active_set_model_reaches_the_oracle_optimum(case, oracle):
+    """The numpy model of the device's primal-dual active-set iteration (penalty `big` on the step of the held controls,
+    multipliers = -/+ big du, KKT sign check) ends exactly on the oracle's optimum — cold, and warm-started from the set of a
+    perturbed problem (the SCP use)."""
+    from tests.support import structured_np as snp
+    from tests.support.problems import rand_problem
+
+    M, N, x, u, Nc, bu = case
+    rng = np.random.default_rng(31)
+    args, kw = rand_problem(rng, M, N, x, u, bu)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    p = snp.Problem(*args[1:], Nc=Nc, **kw)
+    X, U, info = snp.active_set_solve(p)
+    assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-10 and np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0) < 1e-10
+    assert (info["act"] > 0).any()  # the boxes are active in these cases
+    # next sub-problem of an SCP-like sequence: perturbed linearisation, warm start from the previous set and solution
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    args2 = (x0, f + 0.05 * rng.standard_normal(f.shape), fx * (1 + 0.05 * rng.standard_normal(fx.shape)),
+             fu * (1 + 0.05 * rng.standard_normal(fu.shape)), X_prev, U_prev, Q, R, X_ref, U_ref)
+    Xo2, Uo2 = oracle.lqp_solve_py(*args2, Nc=Nc, **kw)
+    p2 = snp.Problem(*args2[1:], Nc=Nc, **kw)
+    X2, U2, info2 = snp.active_set_solve(p2, act0=info["act"], U0=U)
+    assert np.linalg.norm(X2 - Xo2) / np.linalg.norm(Xo2) < 1e-10 and np.linalg.norm(U2 - Uo2) / max(np.linalg.norm(Uo2), 1.0) < 1e-10
