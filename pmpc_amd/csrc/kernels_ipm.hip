@@ -427,7 +427,10 @@ __global__ void __launch_bounds__(TB) k_as_setup(Slab s, int from_ipm, int keep_
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
     const double lo = s.lo[k], hi = s.hi[k], z = s.z[k];
     int a;
-    if (from_ipm) {
+    if (from_ipm == 2) {  // cold: the boxes the equality-only optimum violates
+      a = z < lo ? 1 : (z > hi ? 2 : 0);
+      act[k] = a;
+    } else if (from_ipm) {
       const double ll = s.ll[k], lu = s.lu[k];
       bool aL = isfinite(lo) && ll > z - lo, aU = isfinite(hi) && lu > hi - z;
       if (aL && aU) { aL = ll >= lu; aU = !aL; }

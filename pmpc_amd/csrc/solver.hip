@@ -879,7 +879,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       double worst;
       memcpy(&worst, &hc.worst, sizeof(double));
       if (verbose)
-        printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest %.2e)%s\n", mode ? "finish" : "warm", round + 1,
+        printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest %.2e)%s\n", mode == 2 ? "cold" : (mode ? "finish" : "warm"), round + 1,
                hc.rel, hc.add, worst, (hc.bad || hc.fail) ? " (numerical failure)" : "");
       if (hc.bad || hc.fail) return 2;
       last_add = hc.add;
@@ -912,6 +912,15 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
   if (!try_warm) {
     const int r = equality_phase();
     if (r != 1) return finish(r);
+    // cold start of the active-set iteration: the boxes the equality-only optimum violates are the first guess (the classical
+    // start of the primal-dual active-set method); the interior-point iteration below only runs if that does not settle
+    static const int cold_as_rounds = getenv("PMPC_AS_COLD") ? atoi(getenv("PMPC_AS_COLD")) : 10;
+    if (polish_on && cold_as_rounds > 0) {
+      const int q = active_set_solve(1.0, 2, cold_as_rounds);
+      if (q == 0) return finish(0);
+      if (q == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+      // (w.U still holds the equality-only optimum: the rounds work in their own buffers)
+    }
   }
 
   // ---- 2. Mehrotra predictor-corrector on the boxes ----------------------------------------------

@@ -56,3 +56,39 @@ def test_column_major_and_row_major_entries_agree(case, symmetric, oracle):
         X, U = backend.lqp_solve(*arrs)
         assert _rel(X, Xo) <= TOL, _rel(X, Xo)
         assert _rel(U, Uo, 1.0) <= TOL, _rel(U, Uo, 1.0)
+
+
+_IPM_ONLY_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from oracle import lqp_oracle as orc
+from pmpc_amd import backend
+from tests.support.problems import abi_args, rand_problem
+worst = 0.0
+for k, (M, N, x, u, Nc, bu) in enumerate([(8, 10, 12, 4, 1, 0.4), (6, 8, 5, 3, -1, 0.3), (8, 7, 4, 2, 3, 0.3), (5, 9, 13, 2, 0, 0.2), (1, 30, 2, 1, 1, 0.4)]):
+    args, kw = rand_problem(np.random.default_rng(900 + k), M, N, x, u, bu)
+    Xo, Uo = orc.lqp_solve_py(*args, Nc=Nc, **kw)
+    for rep in range(2):  # the second call is warm-started (interior-point warm start only: the active-set paths are off)
+        X, U = backend.lqp_solve(*abi_args(args, kw, Nc))
+        e = max(np.linalg.norm(X - Xo) / np.linalg.norm(Xo), np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0))
+        worst = max(worst, e)
+        print((M, N, x, u, Nc), rep, e, flush=True)
+assert worst < 1e-7, worst
+print("IPM_ONLY_OK")
+"""
+
+
+def test_interior_point_path_alone_still_matches_the_oracle():
+    """With PMPC_POLISH_MU=0 every active-set use is off and control boxes go through the Mehrotra interior-point
+    iteration to mu = 1e-12 again — the fallback of the active-set iteration must stay parity-green on its own.  Own
+    process: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    env = dict(os.environ, PMPC_POLISH_MU="0")
+    r = subprocess.run([sys.executable, "-c", _IPM_ONLY_SCRIPT], cwd=str(Path(__file__).resolve().parents[1]), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "IPM_ONLY_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
