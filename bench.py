@@ -278,6 +278,8 @@ def main():
                        "ipm_warm_start": os.environ.get("PMPC_WARM_START", "1") != "0"},
             "roofline": {"bound": "hbm", "kernel": "backward Riccati factor sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "full factor sweeps only (every particle x stage): later active-set rounds skip the settled particles "
+                                 "and are timed in a class of their own (bwd_factor_partial, --profile-all)",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * avg_s, "launches": int(n_f),
                          "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0}},
         }

@@ -196,6 +196,9 @@ int pmpc_scp_residual_device(pmpc_ctx *ctx, size_t xdim, size_t udim, size_t N, 
  * (each event pair costs a few microseconds of launch gap). */
 void pmpc_profile_enable(pmpc_ctx *ctx, int level);
 void pmpc_profile_read(pmpc_ctx *ctx, double *ms4, long long *n4);
+/* Factor sweeps of active-set rounds that skip the settled particles are timed in a class of their own (level 2 only) and
+ * never enter class 0, whose launches all process every (particle, stage): totals as of the last pmpc_profile_read. */
+void pmpc_profile_read_partial(pmpc_ctx *ctx, double *ms, long long *n);
 
 /* version / build probe used by the loader and the tests */
 const char *pmpc_version(void);

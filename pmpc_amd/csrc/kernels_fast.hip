@@ -178,12 +178,15 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const dou
 // DEEP: also the stage's mid/late data (Q_{j-1}, xm, gx, D) is loaded a full stage ahead — lowest per-stage
 // latency (few particles per GPU) at 144 VGPRs / 3 waves per SIMD; !DEEP issues those at the top of their own stage
 // and fits 4 waves per SIMD (128 VGPRs), which wins once there are > 3 waves per SIMD to run.
-template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP>
+// SKIP (active-set rounds after the first): particles flagged in a.as_settled_in leave at once — a kernel of its own name, so
+// that profiles of the full sweep (the roofline figure) never mix with launches that process a subset of the particles
+template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP, bool SKIP = false>
 __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
   constexpr bool PADX = (XD != XP);
   constexpr long long D8 = sizeof(double);
+  if (SKIP && a.as_settled_in[blockIdx.x]) return;  // active-set rounds: nothing of this particle changed
   const int lane = threadIdx.x;
   const LT L(lane);
   const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
@@ -660,6 +663,9 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         else dug = -row_allsum(Kreg * xcol) - kreg;
         const bool cnt_here = store_u && (j >= Nc || i == 0);
         int anew = actc;
+        // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
+        // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
+        if (store_u && j >= Nc) *(double *)((char *)a.kff + ou_g) = actc ? -dug : 0.0;
         if (gu) {
           if (!(dug == dug)) nbad |= 1;
           if (actc) {
@@ -735,6 +741,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
       a.as_cnt[3 * i + 0] = (int)r;
       a.as_cnt[3 * i + 1] = (int)d;
       a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
+      if (a.as_settled_out) a.as_settled_out[i] = (r == 0.0 && d == 0.0 && !(b > 0.0)) ? 1 : 0;
     }
   }
 }
@@ -763,6 +770,17 @@ __global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double 
     a.ud[k] = pw * a.reg_u * (U - a.U_prev[k]);
     Du[k] = act ? a.as_big : 0.0;
   }
+}
+__global__ void __launch_bounds__(256) k_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta,
+                                                      int M, int nc) {
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  if (idx >= (long long)M * nc) return;
+  const int i = (int)(idx / nc), r = (int)(idx % nc);
+  if (!settled[i]) return;
+  const double *H = Hc_part + (size_t)i * nc * nc;  // symmetric; diagonal blocks full, off-diagonal blocks in the upper triangle
+  double acc = 0.0;
+  for (int c = 0; c < nc; c++) acc = fma(H[(r < c ? r : c) + nc * (r < c ? c : r)], delta[c], acc);
+  gc_part[(size_t)i * nc + r] += acc;
 }
 // counters[0..2] = particle sums of {released, activated, NaN seen}, counters[3] = the solve's failure flag; single rank:
 // published straight into host-coherent memory (the host polls `seq`, as for the interior-point scalars)
@@ -823,6 +841,7 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
   const int lane = threadIdx.x;
   const LT L(lane);
   const int N = a.N, Nc = a.Nc, nc = Nc * UD, i = blockIdx.x, g = L.g, c = L.c;
+  if (a.as_settled_in && a.as_settled_in[i]) return;
   const size_t pbase = (size_t)i * N;
   const int t0 = blockIdx.y * COND_TPW;
   const int jstart = (16 * t0) / UD;  // first stage at which one of this wave's columns starts
@@ -878,7 +897,10 @@ void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
   const dim3 grd(a.M), blk(64);
 #define PMPC_BWD(F, XB, UB, DP) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB, DP>), grd, blk, 0, s, a)
 #define PMPC_BWD2(F, XB, UB) do { if (deep) PMPC_BWD(F, XB, UB, true); else PMPC_BWD(F, XB, UB, false); } while (0)
-  if (factor) {
+  if (factor && a.as_settled_in && !xb && ub) {  // (the active-set rounds run on control boxes only)
+    if (deep) hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, true>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, false, true>), grd, blk, 0, s, a);
+  } else if (factor) {
     if (xb && ub) PMPC_BWD2(true, true, true);
     else if (xb) PMPC_BWD2(true, true, false);
     else if (ub) PMPC_BWD2(true, false, true);
@@ -958,6 +980,11 @@ void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s) {
   long long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
   hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du);
+}
+void launch_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta, int M, int nc, hipStream_t s) {
+  if (nc <= 0) return;
+  const long long n = (long long)M * nc;
+  hipLaunchKernelGGL(k_as_gc_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gc_part, Hc_part, settled, delta, M, nc);
 }
 void launch_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq,
                       unsigned long long seq, hipStream_t s) {

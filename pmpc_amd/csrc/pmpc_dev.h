@@ -56,6 +56,10 @@ struct LQArgs {
   int *as_act;
   const double *as_lo, *as_hi;
   int *as_cnt;
+  // settled particles (no status change in the previous round, so their factors, condensed Hessian and feed-forward are
+  // still valid): the factor sweep / condensing skip them (as_settled_in), the forward sweep marks them (as_settled_out)
+  const int *as_settled_in;
+  int *as_settled_out;
   double as_big, as_tol_p, as_tol_l;
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
@@ -129,6 +133,8 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s);
 void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s);
 // counters[0..2] = {released, activated, NaN seen} over the particles, counters[3] = *fail; mirror_cnt != null: also published
 // to host-coherent memory with sequence number `seq`
+// settled particles: gc_part[i] += Hc_part[i] * delta (delta = the consensus step applied in the previous round, nc doubles)
+void launch_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta, int M, int nc, hipStream_t s);
 void launch_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq,
                       unsigned long long seq, hipStream_t s);
 void launch_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s);

@@ -147,7 +147,7 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
-  DevBuf as_act, as_cnt, as_cntp;  // active-set iteration: status per bounded control (int), counters, per-particle counters
+  DevBuf as_act, as_cnt, as_cntp, as_settled;  // active-set iteration: status per bounded control (int), counters, per-particle counters
   long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
   double as_scale = 1.0;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
@@ -164,7 +164,10 @@ struct ProfCat {
 
 struct pmpc_ctx {
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
-  ProfCat cat[4];  // 0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve
+  double partial_ms = 0.0;  // class 4 of the last pmpc_profile_read
+  long long partial_n = 0;
+  ProfCat cat[5];  // 0 backward+factor (all particles), 1 backward vector-only, 2 forward, 3 consensus reduce+solve,
+                   // 4 backward+factor of an active-set round that skips the settled particles (never part of the roofline figure)
   int device = 0;
   hipStream_t stream = nullptr;
   Workspace ws;
@@ -270,7 +273,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
   const int nc = a.Nc * a.u;
   if (fast && factor && !prep_done) launch_grad_prep(a, s);
   {
-    ProfScope ps(c, factor ? 0 : 1);
+    ProfScope ps(c, factor ? ((fast && a.as_settled_in) ? 4 : 0) : 1);
     if (fast) launch_bwd_fast(a, factor, s);
     else launch_bwd_generic(a, factor, s);
   }
@@ -343,7 +346,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -366,7 +369,7 @@ void pmpc_profile_enable(pmpc_ctx *c, int level) { c->prof = level < 0 ? 0 : lev
 // 0 backward+factor, 1 backward vector-only, 2 forward sweep, 3 consensus reduce + dense solve.
 void pmpc_profile_read(pmpc_ctx *c, double *ms4, long long *n4) {
   HIP_CHECK(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < 5; k++) {
     ProfCat &pc = c->cat[k];
     for (auto &ev : pc.pending) {
       float t = 0.f;
@@ -376,11 +379,17 @@ void pmpc_profile_read(pmpc_ctx *c, double *ms4, long long *n4) {
       pc.pool.push_back(ev);
     }
     pc.pending.clear();
-    ms4[k] = pc.ms;
-    n4[k] = pc.n;
+    if (k < 4) { ms4[k] = pc.ms; n4[k] = pc.n; }
+    else { c->partial_ms = pc.ms; c->partial_n = pc.n; }
     pc.ms = 0.0;
     pc.n = 0;
   }
+}
+
+// class 4 (factor sweeps of active-set rounds that skipped the settled particles) as of the last pmpc_profile_read
+void pmpc_profile_read_partial(pmpc_ctx *c, double *ms, long long *n) {
+  *ms = c->partial_ms;
+  *n = c->partial_n;
 }
 
 int pmpc_comm_unique_id(void *out128) {
@@ -812,6 +821,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
   // cannot be moved onto its bound without leaving the dynamics); not in barrier mode.
   static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
   static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
+  static const bool as_skip_on = !(getenv("PMPC_AS_SKIP") && atoi(getenv("PMPC_AS_SKIP")) == 0);
   const bool polish_on = polish_mu > 0.0 && has_ub && !has_xb && mu_target == 0.0;
   const long long as_key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0);
   // mode 1: guess from the interior-point iterate in (w.U, slacks, multipliers); mode 0: the stored set, base point = w.U
@@ -832,6 +842,8 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       w.as_cntp.ensure((size_t)M * 3 * sizeof(int));
       HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
       b.as_act = act; b.as_lo = su.lo; b.as_hi = su.hi; b.as_cnt = (int *)w.as_cntp.p; b.as_big = big; b.as_tol_p = tol_p;
+      w.as_settled.ensure((size_t)M * sizeof(int));
+      b.as_settled_out = (int *)w.as_settled.p;
     }
     int last_add = 1, last_changes = 0x7fffffff, stalls = 0;
     w.as_key = -1;
@@ -848,6 +860,11 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
           launch_rollout_fast(b, Utry, Xtry, s);
         }
         launch_as_prep(b, round > 0, su.D, s);
+        // particles without a status change in the previous round keep their factors, their condensed Hessian H_i and their
+        // conditional optimum: no factor sweep for them — g_i follows the applied consensus step, g_i += H_i delta
+        const bool skip = as_skip_on && round > 0 && nc <= 32;
+        b.as_settled_in = skip ? (const int *)w.as_settled.p : nullptr;
+        if (skip) launch_as_gc_update(w.gc_part.d(), w.Hc_part.d(), (const int *)w.as_settled.p, w.dU.d(), M, nc, s);
         structured_solve(c, b, true, true, /*prep_done=*/true);
         launch_as_reduce((const int *)w.as_cntp.p, M, cnt, (const int *)w.fail.p, c->multi() ? nullptr : c->mirror_dev->as_cnt,
                          &c->mirror_dev->as_seq, ++c->as_seq, s);

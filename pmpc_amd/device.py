@@ -187,7 +187,11 @@ class DeviceSolver:
         n = (ctypes.c_longlong * 4)()
         self.lib.pmpc_profile_read(self.h, ms, n)
         names = ("bwd_factor", "bwd_vec", "fwd", "consensus")
-        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+        out = {k: (ms[i], n[i]) for i, k in enumerate(names)}
+        pms, pn = ctypes.c_double(), ctypes.c_longlong()
+        self.lib.pmpc_profile_read_partial(self.h, ctypes.byref(pms), ctypes.byref(pn))
+        out["bwd_factor_partial"] = (pms.value, pn.value)  # active-set rounds that skip the settled particles (level 2 only)
+        return out
 
 
 def to_device_problem(prob: dict, device="cuda"):

@@ -36,8 +36,13 @@ read_factor = ax_read_true / ax_fetch
 ax_write = sum(write[key(write, "k_axpy(")]) / len(write[key(write, "k_axpy(")]) * 1024
 out = {"calibration": {"kernel": "k_axpy", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
                        "read_factor": read_factor, "true_write_bytes": 8 * (nx + nu) / 2, "WRITE_SIZE_bytes": ax_write}}
-for name, label in (("k_bwd_fast<12, 4, true", "bwd_factor"), ("k_bwd_fast<12, 4, false", "bwd_vec"), ("k_fwd_fast<12, 4, false", "fwd")):
-    kf, kw = key(fetch, name), key(write, name)
+# full factor sweep only: the SKIP instantiation (last template argument true) processes a subset of the particles
+for name, label in (("k_bwd_fast<12, 4, true, false, true, false, false>", "bwd_factor"), ("k_bwd_fast<12, 4, false", "bwd_vec"),
+                    ("k_fwd_fast<12, 4, false, false>", "fwd"), ("k_fwd_fast<12, 4, false, true>", "fwd_active_set")):
+    try:
+        kf, kw = key(fetch, name), key(write, name)
+    except StopIteration:
+        continue
     fb = sum(fetch[kf]) / len(fetch[kf]) * 1024
     wb = sum(write[kw]) / len(write[kw]) * 1024
     out[label] = {"FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb, "read_bytes_calibrated": fb * read_factor,
