@@ -150,23 +150,29 @@ void launch_linearize(int model, int N, int M, const double *x0, const double *X
 }
 
 // SCP residual of pmpc/scp_mpc.py:397-403: max over (particle, stage) of the 2-norms of X - X_prev and U - U_prev, in one
-// pass (rows of d doubles; one thread per row, block max, then an atomic max on the bit pattern of the non-negative result)
+// pass.  4 lanes share a row (each a contiguous quarter of it), 2-step quad sum; the maximum is taken over the SQUARED norms
+// (one square root per thread at the end, not per row), block max, then an atomic max on the bit pattern of the result.
 namespace {
 __global__ void __launch_bounds__(256) k_scp_residual(const double *X, const double *Xp, long long rows_x, int x, const double *U,
                                                       const double *Up, long long rows_u, int u, unsigned long long *out_bits) {
   __shared__ double sh[256];
+  const int sub = threadIdx.x & 3;
+  const long long grp = (blockIdx.x * 256LL + threadIdx.x) >> 2, ngrp = ((long long)gridDim.x * 256) >> 2;
+  const int qx = (x + 3) / 4, qu = (u + 3) / 4;
   double m = 0.0;
-  for (long long r = blockIdx.x * 256LL + threadIdx.x; r < rows_x + rows_u; r += (long long)gridDim.x * 256) {
+  for (long long r = grp; r < rows_x + rows_u; r += ngrp) {  // (the 4 lanes of a group run the same trip count)
     const bool isx = r < rows_x;
     const long long rr = isx ? r : r - rows_x;
-    const int d = isx ? x : u;
+    const int d = isx ? x : u, q = isx ? qx : qu;
     const double *a = (isx ? X : U) + rr * d, *b = (isx ? Xp : Up) + rr * d;
+    const int k1 = min(d, (sub + 1) * q);
     double acc = 0.0;
-    for (int k = 0; k < d; k++) { const double t = a[k] - b[k]; acc = fma(t, t, acc); }
-    const double nrm = sqrt(acc);
-    m = (nrm == nrm) ? fmax(m, nrm) : INFINITY;  // a NaN trajectory must not look converged
+    for (int k = sub * q; k < k1; k++) { const double t = a[k] - b[k]; acc = fma(t, t, acc); }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    m = (acc == acc) ? fmax(m, acc) : INFINITY;  // a NaN trajectory must not look converged
   }
-  sh[threadIdx.x] = m;
+  sh[threadIdx.x] = sqrt(m);
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
@@ -179,8 +185,7 @@ __global__ void __launch_bounds__(256) k_scp_residual(const double *X, const dou
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
                          double *out, hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), s));
-  long long nb = (2 * rows + 255) / 256;
-  if (nb > 2048) nb = 2048;
+  long long nb = (2 * rows * 4 + 255) / 256;
+  if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_scp_residual, dim3((unsigned)nb), dim3(256), 0, s, X, Xp, rows, x, U, Up, rows, u, (unsigned long long *)out);
 }
-
