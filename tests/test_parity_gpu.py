@@ -92,3 +92,19 @@ def test_interior_point_path_alone_still_matches_the_oracle():
     r = subprocess.run([sys.executable, "-c", _IPM_ONLY_SCRIPT], cwd=str(Path(__file__).resolve().parents[1]), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "IPM_ONLY_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_empty_box_fails_like_the_reference(oracle):
+    """lo > hi on one control: no feasible point.  The reference's OSQP reports infeasibility and the outputs are NaN
+    (osqp_solver.jl:65-71); the active-set rounds must not 'solve' it by holding the control on one side."""
+    from pmpc_amd import backend
+
+    args, kw = rand_problem(np.random.default_rng(5), 4, 6, 4, 2, 0.3)
+    kw["u_l"] = kw["u_l"].copy()
+    kw["u_l"][1, 2, 0] = kw["u_u"][1, 2, 0] + 0.5
+    X, U = backend.lqp_solve(*abi_args(args, kw, 1))
+    assert np.isnan(X).all() and np.isnan(U).all()
+    args2, kw2 = rand_problem(np.random.default_rng(5), 4, 6, 4, 2, 0.3)  # and the context recovers
+    Xo, Uo = oracle.lqp_solve_py(*args2, Nc=1, **kw2)
+    X, U = backend.lqp_solve(*abi_args(args2, kw2, 1))
+    assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-7 and np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0) < 1e-7
