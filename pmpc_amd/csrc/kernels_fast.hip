@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
   // active-set mode: status, box and base value of control g, per k-group (prefetched like k_j)
   int actn = 0, nrel = 0, nadd = 0, nbad = 0;
   double lon = 0.0, hin = 0.0, ubn = 0.0;
-  if (AS && gu) {
+  if (AS) {  // every lane loads (lanes of the k-groups g >= udim read control 0's entries and ignore them): no branch
     actn = *(const int *)((const char *)a.as_act + (ou_g >> 1));
     lon = ldo(a.as_lo, ou_g); hin = ldo(a.as_hi, ou_g); ubn = ldo(a.U, ou_g);
   }
@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         Kn = *pK;
         pk = badd(pk, sk);
         kn = *pk;
-        if (AS && gu) {
+        if (AS) {
           actn = *(const int *)((const char *)a.as_act + ((ou_g + SU) >> 1));
           lon = ldo(a.as_lo, ou_g + SU); hin = ldo(a.as_hi, ou_g + SU); ubn = ldo(a.U, ou_g + SU);
         }
@@ -662,27 +662,29 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         if (j < Nc) dug = gu ? a.duc[j * UD + g] : 0.0;
         else dug = -row_allsum(Kreg * xcol) - kreg;
         const bool cnt_here = store_u && (j >= Nc || i == 0);
-        int anew = actc;
-        // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
-        // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
-        if (store_u && j >= Nc) *(double *)((char *)a.kff + ou_g) = actc ? -dug : 0.0;
-        if (gu) {
-          if (!(dug == dug)) nbad |= 1;
-          if (actc) {
-            const double lam = actc == 1 ? -a.as_big * dug : a.as_big * dug;  // multiplier of the held side
-            if (lam < -a.as_tol_l) { anew = 0; nrel += cnt_here ? 1 : 0; }
-            dug = 0.0;  // held (a released control starts the next round from its bound)
-          } else {
-            const double zt = ubc + dug;
-            if (zt < loc - a.as_tol_p * fmax(1.0, fabs(loc))) { anew = 1; dug = loc - ubc; nadd += cnt_here ? 1 : 0; }
-            else if (zt > hic + a.as_tol_p * fmax(1.0, fabs(hic))) { anew = 2; dug = hic - ubc; nadd += cnt_here ? 1 : 0; }
-          }
-        }
+        // (selects only: the divergent form of this block cost 35 exec-mask branches per stage)
+        const double draw = dug;
+        const bool held = gu && actc != 0;
+        const double lam = actc == 1 ? -a.as_big * draw : a.as_big * draw;  // multiplier of the held side
+        const bool release = held && lam < -a.as_tol_l;
+        const double zt = ubc + draw;
+        const bool vlo = gu && !held && zt < loc - a.as_tol_p * fmax(1.0, fabs(loc));
+        const bool vhi = gu && !held && !vlo && zt > hic + a.as_tol_p * fmax(1.0, fabs(hic));
+        const int anew = release ? 0 : (vlo ? 1 : (vhi ? 2 : actc));
+        // held: no step (a released control starts the next round from its bound); a control that would leave its box is
+        // clamped onto the bound and held from now on
+        dug = held ? 0.0 : (vlo ? loc - ubc : (vhi ? hic - ubc : draw));
+        nbad |= (gu && !(draw == draw)) ? 1 : 0;
+        nrel += (cnt_here && release) ? 1 : 0;
+        nadd += (cnt_here && (vlo || vhi)) ? 1 : 0;
         const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
         du_c = L.cu ? t : 0.0;
         if (store_u) {
           *(double *)((char *)a.dU + ou_g) = dug;
           *(int *)((char *)a.as_act + (ou_g >> 1)) = anew;
+          // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
+          // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
+          if (j >= Nc) *(double *)((char *)a.kff + ou_g) = actc ? -draw : 0.0;
         }
       } else if (j < Nc) {
         du_c = *pdc;  // shared consensus step (zero off the control columns)
