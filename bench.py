@@ -7,7 +7,7 @@ One "step" = one full SCP iteration on synthetic particle batches, everything re
 Workload (BASELINE.json north_star / BASELINE.md config D): synthetic quadrotor xdim=12 udim=4,
 M=4096 particles, N=50, Nc=1 consensus, box constraints on the controls, fp64.  With --gpus N the
 4096 particles are sharded N ways (strong scaling), one process per GPU, RCCL all-reduce of the
-consensus Hessian/gradient and the IPM scalars only.
+consensus Hessian/gradient and of the active-set change counters (interior-point scalars on the fallback path) only.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 HIP-event timed on the solver's own stream) and `cpu_baseline` (oracle timed on a bounded sample).
