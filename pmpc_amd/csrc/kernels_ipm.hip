@@ -132,6 +132,20 @@ __global__ void __launch_bounds__(TB) k_violation(Slab s, double *part_max) {
   if (threadIdx.x == 0) part_max[blockIdx.x] = v;
 }
 
+// the same for the candidate point za + zb (state boxes of an active-set candidate, before anything is overwritten)
+__global__ void __launch_bounds__(TB) k_violation_sum(Slab s, const double *za, const double *zb, double *part_max) {
+  __shared__ double sh[TB];
+  double v = 0.0;
+  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
+    const double z = za[k] + zb[k], lo = s.lo[k], hi = s.hi[k];
+    if (isfinite(lo)) v = fmax(v, lo - z);
+    if (isfinite(hi)) v = fmax(v, z - hi);
+    if (!(z == z)) v = INFINITY;
+  }
+  v = block_max(v, sh);
+  if (threadIdx.x == 0) part_max[blockIdx.x] = v;
+}
+
 // pull the controls strictly inside their box so that control slack residuals start at zero
 __global__ void __launch_bounds__(TB) k_ipm_clip(Slab s) {
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
@@ -574,6 +588,9 @@ void launch_add(double *out, const double *a, const double *b, long long n, hipS
   long long nb = (n + TB - 1) / TB;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_add, dim3((unsigned)nb), dim3(TB), 0, s, out, a, b, n);
+}
+void launch_violation_sum(const Slab &sl, const double *za, const double *zb, double *part_max, hipStream_t s) {
+  hipLaunchKernelGGL(k_violation_sum, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, za, zb, part_max);
 }
 void launch_ipm_clip(const Slab &sl, hipStream_t s) {
   hipLaunchKernelGGL(k_ipm_clip, dim3(grid_for(sl.count)), dim3(TB), 0, s, sl);

@@ -150,6 +150,7 @@ void launch_fill(double *y, double v, long long n, hipStream_t s);
 void launch_cons_bounds(double *lo, double *hi, int M, int N, int u, int Nc, hipStream_t s);
 void launch_init_base(double *U, const double *U_prev, int M, int N, int u, int Nc, hipStream_t s);
 void launch_violation(const Slab &sl, double *part_max, hipStream_t s);
+void launch_violation_sum(const Slab &sl, const double *za, const double *zb, double *part_max, hipStream_t s);  // of za + zb
 void launch_ipm_clip(const Slab &sl, hipStream_t s);
 // primal-dual active-set finish (kernels_ipm.hip): act 0 free / 1 lower / 2 upper; counters = {released, activated, NaN seen}
 void launch_as_setup(const Slab &sl, int from_ipm, int keep_base, int *act, double *ztry, double big, hipStream_t s);

@@ -148,6 +148,7 @@ struct Workspace {
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
   DevBuf as_act, as_cnt, as_cntp, as_settled;  // active-set iteration: status per bounded control (int), counters, per-particle counters
+  long long xb_block_key = -1;  // shape whose state boxes were found active: no active-set attempts for it
   long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
   double as_scale = 1.0;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
@@ -819,11 +820,15 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
   // few hundred of ~1e6 entries) starts the next solve directly: no equality-only phase, no interior-point iteration.
   // If the set does not settle the interior-point iteration runs (on), its state untouched.  Control boxes only (a state
   // cannot be moved onto its bound without leaving the dynamics); not in barrier mode.
+  const long long as_key_pre = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0);
   static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
   static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
   static const bool as_skip_on = !(getenv("PMPC_AS_SKIP") && atoi(getenv("PMPC_AS_SKIP")) == 0);
-  const bool polish_on = polish_mu > 0.0 && has_ub && !has_xb && mu_target == 0.0;
-  const long long as_key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0);
+  // State boxes: a state cannot be held on its bound this way, but boxes that are there and INACTIVE at the optimum (loose
+  // limits, e.g. x in +-20 of the reference's tests/pmpcjl_test.py:164-219) change nothing: the accepted point only has to
+  // be checked against them.  A violated state box sends the solve (and later solves of this shape) to the interior-point path.
+  const bool polish_on = polish_mu > 0.0 && has_ub && mu_target == 0.0 && !(has_xb && w.xb_block_key == as_key_pre);
+  const long long as_key = as_key_pre;
   // mode 1: guess from the interior-point iterate in (w.U, slacks, multipliers); mode 0: the stored set, base point = w.U
   // (the previous solution).  Returns 0 accepted (w.X, w.U hold the optimum), 1 not settled, 2 numerical failure.
   auto active_set_solve = [&](double dual_scale, int mode, int max_rounds) -> int {
@@ -902,6 +907,17 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       last_add = hc.add;
       const int changes = hc.rel + hc.add;
       if (changes == 0) {
+        if (has_xb) {  // the candidate's states against their boxes, before anything of the interior-point state is overwritten
+          HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
+          launch_violation_sum(sx, Xtry, w.dX.d(), w.part_max.d(), s);
+          exchange(c, 1);
+          read_scalars(c);
+          if (*c->fail_host || !(c->sc_host->viol_max <= 1e-13)) {
+            if (verbose) printf("pmpc_hip: active set settled but a state box is violated by %.3e: interior-point path\n", c->sc_host->viol_max);
+            w.xb_block_key = as_key;
+            return 1;
+          }
+        }
         launch_as_accept(st, act, Utry, s);
         launch_add(w.X.d(), Xtry, w.dX.d(), (long long)nx, s);
         w.as_key = as_key;  // act + w.U start the next solve of this shape
@@ -932,7 +948,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     // cold start of the active-set iteration: the boxes the equality-only optimum violates are the first guess (the classical
     // start of the primal-dual active-set method); the interior-point iteration below only runs if that does not settle
     static const int cold_as_rounds = getenv("PMPC_AS_COLD") ? atoi(getenv("PMPC_AS_COLD")) : 10;
-    if (polish_on && cold_as_rounds > 0) {
+    if (polish_on && cold_as_rounds > 0 && !(has_xb && w.xb_block_key == as_key)) {
       const int q = active_set_solve(1.0, 2, cold_as_rounds);
       if (q == 0) return finish(0);
       if (q == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
@@ -1038,7 +1054,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       if (it == max_iter) break;
-      if (polish_on && it > 1 && h.mu <= polish_next * mu_peak) {
+      if (polish_on && it > 1 && h.mu <= polish_next * mu_peak && !(has_xb && w.xb_block_key == as_key)) {
         const double mu_now = h.mu;  // (h aliases the host snapshot)
         const int r = active_set_solve(std::max(1.0, mu_peak), 1, 6);
         if (r == 0) { inf.mu = 0.0; status = 0; break; }

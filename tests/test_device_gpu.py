@@ -258,3 +258,37 @@ def test_warm_active_set_sequence_is_exact(case, generic, oracle):
         assert status == 0 and rel(Xc.cpu().numpy(), Xo) < 1e-7 and rel(Uc.cpu().numpy(), Uo) < 1e-7
         # (the cold solve's accepted set is as good a start for the next sub-problem as the warm one's)
     s.close()
+
+
+def test_inactive_state_boxes_take_the_active_set_path_active_ones_the_interior_point_path(oracle):
+    """State boxes that do not bind leave the control-box active-set iteration in charge (its accepted point is checked
+    against them); binding ones send the solve — and later solves of the shape — to the interior-point iteration."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+    from tests.support.problems import rand_problem
+
+    M, N, x, u, Nc = 6, 10, 4, 2, 1
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    for bx, expect_as in ((1e3, True), (3.5, False)):  # |x| <= 3.5 binds at one state of this problem (max |x| = 3.68 without it)
+        args, kw = rand_problem(np.random.default_rng(12), M, N, x, u, 0.3, bx)
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+        Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+        assert (abs(np.abs(Xo).max() - bx) < 1e-9) != expect_as  # binding state box <=> interior-point path expected
+        s = DeviceSolver(0)
+        for rep in range(2):
+            X, U, status = s.lqp_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
+                                       X_ref=dev(X_ref), U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc,
+                                       symmetric_cost=True, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]), lx=dev(kw["x_l"]), ux=dev(kw["x_u"]))
+            s.sync()
+            info = dict(s.last_info)
+            assert status == 0 and rel(X.cpu().numpy(), Xo) < 1e-7 and rel(U.cpu().numpy(), Uo) < 1e-7, (bx, rep, info)
+            if expect_as:
+                assert info["ipm_iters"] == 0 and info["active_set_rounds"] >= 1, info
+            else:
+                assert info["ipm_iters"] > 0, info
+                if rep:
+                    assert info["active_set_rounds"] == 0, info  # remembered: no second attempt for this shape
+        s.close()
