@@ -900,8 +900,9 @@ void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
 #define PMPC_BWD(F, XB, UB, DP) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB, DP>), grd, blk, 0, s, a)
 #define PMPC_BWD2(F, XB, UB) do { if (deep) PMPC_BWD(F, XB, UB, true); else PMPC_BWD(F, XB, UB, false); } while (0)
   if (factor && a.as_settled_in && !xb && ub) {  // (the active-set rounds run on control boxes only)
-    if (deep) hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, true>), grd, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, false, true>), grd, blk, 0, s, a);
+    // few particles are left in these launches (the settled ones leave at once): occupancy is irrelevant, the deeper pipeline
+    // with its lower per-stage latency wins at every M
+    hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, true>), grd, blk, 0, s, a);
   } else if (factor) {
     if (xb && ub) PMPC_BWD2(true, true, true);
     else if (xb) PMPC_BWD2(true, true, false);
