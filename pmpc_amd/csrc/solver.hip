@@ -814,12 +814,14 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
   // Given a guess of the active set, ONE structured solve from a base point with those controls ON their bounds gives the
   // exact optimum on that set; a check pass verifies the KKT signs and, where they fail, applies the primal-dual active-set
   // update (release negative multipliers, hold violated boxes).  An unchanged set is the optimum of the QP, complementarity
-  // exactly zero.  Two uses: (a) FINISH of the interior-point iteration — once mu <= polish_mu * mu_peak its iterate names
-  // the set (l > slack), which replaces the last predictor-corrector iterations (4 sweeps each) by a few factor + forward
-  // sweeps; (b) WARM START — the accepted set of the previous solve of this shape (consecutive SCP sub-problems differ in a
-  // few hundred of ~1e6 entries) starts the next solve directly: no equality-only phase, no interior-point iteration.
-  // If the set does not settle the interior-point iteration runs (on), its state untouched.  Control boxes only (a state
-  // cannot be moved onto its bound without leaving the dynamics); not in barrier mode.
+  // exactly zero.  Three uses: (a) WARM START — the accepted set and solution of the previous solve of this shape (consecutive
+  // SCP sub-problems differ in a few hundred to a few thousand of ~1e6 entries) start the next solve directly: no equality-only
+  // phase, no interior-point iteration; (b) COLD START — without one, the boxes the equality-only optimum violates are the
+  // first guess; (c) FINISH of the interior-point iteration — once mu <= polish_mu * mu_peak its iterate names the set
+  // (l > slack), which replaces the last predictor-corrector iterations (4 sweeps each) by a few factor + forward sweeps.
+  // If the set does not settle the interior-point iteration runs (on), its state untouched.  The rounds act on the control
+  // boxes (a state cannot be moved onto its bound without leaving the dynamics; state boxes that do not bind are verified at
+  // acceptance, see below); not in barrier mode.  DESIGN.md section 2.4.
   const long long as_key_pre = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0);
   static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
   static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
