@@ -194,7 +194,8 @@ def main():
         _, _, status = solve_fn(**soc_kw, f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
                                         U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
                                         lu=d.get("lu"), uu=d.get("uu"), X_out=Xo, U_out=Uo, verbose=args.verbose,
-                                        force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False)
+                                        force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False,
+                                        static_cons_bounds=True)  # (an SCP loop: the boxes never change between its iterations)
         if status != 0 and not args.ignore_status:
             raise SystemExit(f"solver failed with status {status}")
         res = solver.scp_residual(Xo, Xp, Uo, Up)  # SCP residual of pmpc/scp_mpc.py:397-403: one fused pass on the solver's stream

@@ -97,6 +97,10 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
 
 #define PMPC_COLD_START 64u /* do not start the interior-point iteration from the iterate remembered from the previous
                                solve of the same shape (see "warm start" in DESIGN.md section 2) */
+#define PMPC_STATIC_CONS_BOUNDS 128u /* sharded runs: the caller guarantees that the bounds of the consensus controls (global
+                                       particle 0's lu / uu on the stages < Nc) are the ones of the previous solve of this shape,
+                                       as inside an SCP loop (pmpc/scp_mpc.py passes the same u_l / u_u every iteration): the
+                                       library reuses the copy it broadcast then instead of two collectives per solve */
 
 typedef struct pmpc_problem {
   size_t xdim, udim, N, M; /* M = particles held by THIS rank */

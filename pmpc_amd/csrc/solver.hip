@@ -148,6 +148,8 @@ struct Workspace {
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
   DevBuf as_act, as_cnt, as_cntp, as_settled;  // active-set iteration: status per bounded control (int), counters, per-particle counters
+  DevBuf cons_lo, cons_hi;  // sharded runs: the consensus controls' bounds as last broadcast (PMPC_STATIC_CONS_BOUNDS)
+  long long cons_key = -1;
   long long xb_block_key = -1;  // shape whose state boxes were found active: no active-set attempts for it
   long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
   double as_scale = 1.0;
@@ -347,7 +349,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -602,8 +604,21 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
       HIP_CHECK(hipMemcpyAsync(w.su.lo.p, p->lu, nu * D8, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipMemcpyAsync(w.su.hi.p, p->uu, nu * D8, hipMemcpyDeviceToDevice, s));
       if (c->multi()) {
-        g_rccl.Broadcast(w.su.lo.p, w.su.lo.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
-        g_rccl.Broadcast(w.su.hi.p, w.su.hi.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
+        // rank 0's bounds of the consensus controls reach every rank: two small broadcasts — or, when the caller vouches that
+        // they are the previous solve's (PMPC_STATIC_CONS_BOUNDS: an SCP loop), the copy kept from then (each tiny
+        // collective costs tens of microseconds over xGMI, a tenth of a sharded solve)
+        const long long bkey = ((((long long)u * 131 + N) * 1000003 + M) * 131 + Nc);
+        if ((p->flags & PMPC_STATIC_CONS_BOUNDS) && w.cons_key == bkey) {
+          HIP_CHECK(hipMemcpyAsync(w.su.lo.p, w.cons_lo.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.su.hi.p, w.cons_hi.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
+        } else {
+          g_rccl.Broadcast(w.su.lo.p, w.su.lo.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
+          g_rccl.Broadcast(w.su.hi.p, w.su.hi.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
+          w.cons_lo.ensure((size_t)nc * D8); w.cons_hi.ensure((size_t)nc * D8);
+          HIP_CHECK(hipMemcpyAsync(w.cons_lo.p, w.su.lo.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.cons_hi.p, w.su.hi.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
+          w.cons_key = bkey;
+        }
       }
       launch_cons_bounds(w.su.lo.d(), w.su.hi.d(), M, N, u, Nc, s);
       lo = w.su.lo.d(); hi = w.su.hi.d();

@@ -46,7 +46,8 @@ def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None):
                 opt.update(slew_reg=dev(kw["slew_reg"]))
             if "slew_reg0" in kw:
                 opt.update(slew_reg0=dev(kw["slew_reg0"]), slew_um1=dev(kw["slew_um1"]))
-            for _ in range(repeats):  # repeats > 1: the second solve is warm-started on every rank
+            for rep in range(repeats):  # repeats > 1: the second solve is warm-started on every rank, and reuses the
+                opt["static_cons_bounds"] = rep > 0  # consensus bounds broadcast for the first (PMPC_STATIC_CONS_BOUNDS)
                 if soc is not None:
                     full = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device="cuda")
                     opt.update(soc_W=full(soc["W"]), soc_w0=full(soc["w0"]), soc_v=full(soc["v"]), soc_v0=soc["v0"],
@@ -180,8 +181,8 @@ for k, (M, N, x, u, Nc, kind) in enumerate([(8, 9, 12, 4, 1, "qp"), (6, 8, 5, 3,
         opt.update(soc_W=dev(W), soc_w0=dev(np.zeros(2)), soc_v=dev(np.array([0.5, 0, 0])), soc_v0=0.05, soc_u_interior=dev(np.array([0.2, 0, 0])))
     res = []
     for s in (plain, rccl):
-        for _ in range(2):  # the second solve is warm-started
-            X, U, status = getattr(s, {"qp": "lqp_solve", "cone": "lcone_solve", "soc": "lsoc_solve"}[kind])(**opt)
+        for rep in range(2):  # the second solve is warm-started and reuses the broadcast consensus bounds
+            X, U, status = getattr(s, {"qp": "lqp_solve", "cone": "lcone_solve", "soc": "lsoc_solve"}[kind])(static_cons_bounds=rep > 0, **opt)
             s.sync()
             assert status == 0, (kind, status)
         res.append((X.cpu().numpy(), U.cpu().numpy()))
