@@ -195,7 +195,8 @@ def main():
                                         U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
                                         lu=d.get("lu"), uu=d.get("uu"), X_out=Xo, U_out=Uo, verbose=args.verbose,
                                         force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False,
-                                        static_cons_bounds=True)  # (an SCP loop: the boxes never change between its iterations)
+                                        static_cons_bounds=True, prev_is_last_solution=len(hist) > 0)  # (an SCP loop: same boxes,
+                                        # and X_prev / U_prev are the previous iteration's solution)
         if status != 0 and not args.ignore_status:
             raise SystemExit(f"solver failed with status {status}")
         res = solver.scp_residual(Xo, Xp, Uo, Up)  # SCP residual of pmpc/scp_mpc.py:397-403: one fused pass on the solver's stream

@@ -101,6 +101,13 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                                        particle 0's lu / uu on the stages < Nc) are the ones of the previous solve of this shape,
                                        as inside an SCP loop (pmpc/scp_mpc.py passes the same u_l / u_u every iteration): the
                                        library reuses the copy it broadcast then instead of two collectives per solve */
+#define PMPC_PREV_IS_LAST_SOLUTION 256u /* the caller guarantees that X_prev / U_prev ARE the X_out / U_out of the previous solve
+                                          of this shape and that lu / uu are unchanged, as in an SCP loop
+                                          (pmpc/scp_mpc.py:313,430: X_prev, U_prev = X, U).  A warm-started solve then takes
+                                          the linearisation point itself as its first base point — its dynamics defect is
+                                          f - X_prev, elementwise — instead of rolling the old controls out again (one
+                                          sequential sweep less).  Checked on the device: a broken promise costs time, not
+                                          correctness. */
 
 typedef struct pmpc_problem {
   size_t xdim, udim, N, M; /* M = particles held by THIS rank */

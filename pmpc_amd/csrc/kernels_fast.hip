@@ -180,7 +180,8 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const dou
 // and fits 4 waves per SIMD (128 VGPRs), which wins once there are > 3 waves per SIMD to run.
 // SKIP (active-set rounds after the first): particles flagged in a.as_settled_in leave at once — a kernel of its own name, so
 // that profiles of the full sweep (the roofline figure) never mix with launches that process a subset of the particles
-template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP, bool SKIP = false>
+// DEFECT: the base point has the dynamics defect a.defect (see LQArgs): s_j += S_j r_j before h = F' s
+template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP, bool SKIP = false, bool DEFECT = false>
 __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
@@ -235,6 +236,11 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   unsigned ou_g = (unsigned)(((pbase + N - 1) * UD + (gu ? g : 0)) * D8);
   unsigned ou_0 = (unsigned)(((pbase + N - 1) * UD) * D8);
   constexpr unsigned SX = XD * D8, SU = UD * D8;
+  // dynamics defect of the base point on the state columns (DEFECT), stage by stage
+  const bool fdf = DEFECT && L.cxv;
+  const double *pdf = fdf ? a.defect + (pbase + N - 1) * XD + L.oc : Z;
+  const int sdf = fdf ? -(int)D8 * XD : 0;
+  double dfn = DEFECT ? *pdf : 0.0;
   double *pRec = a.K + (pbase + N - 1) * 64 + lane;  // factor record of stage N-1, this lane's slot
   const bool frec = (L.cxv || L.cu) && gu;           // lanes whose slot carries a value
 
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     double Fr[KS], Qc[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
-    const double Rc = Rn, um_g = umn;
+    const double Rc = Rn, um_g = umn, df_c = dfn;
     double gu_c = gun, rec = recn;  // rec: this lane's slot of the stage's factor record
     if (!FACTOR && HUB && cons && !own0) gu_c = 0.0;  // consensus shift counted once, on the owner's particle 0
     if (j == 0) {  // stage 0 has no incoming state: A~_0 = 0
@@ -353,6 +359,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       pgu = badd(pgu, sgu);
       gun = *pgu;
       ou_g -= SU;
+      if (DEFECT) { pdf = badd(pdf, sdf); dfn = *pdf; }
       if (FACTOR) {
         pR = badd(pR, sR);
         Rn = *pR;
@@ -363,6 +370,10 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       }
     }
 
+    if (DEFECT) {  // x_j = F [x_{j-1}; u_j] + r_j: the cost-to-go gradient seen through the stage is s + S r
+#pragma unroll
+      for (int r = 0; r < KS; r++) s_row[r] += row_allsum(S[r] * df_c);
+    }
     // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
     double hp = Rc * um_g;
 #pragma unroll
@@ -554,7 +565,8 @@ __global__ void __launch_bounds__(256) k_particle_cost(LQArgs a, const double *X
 // dynamics-consistent base point with every held control exactly on its bound (later stages react to the clamped state
 // through their feedback gains, as in a control-limited DDP forward pass).  With no change anywhere the step is the exact
 // optimum on the current set.  Writes the new statuses and per-particle change counters.
-template <int XD, int UD, bool ROLLOUT, bool AS = false>
+// DEFECT (with AS): the base point's dynamics defect enters the state recursion, dx_j = F [dx_{j-1}; du_j] + r_j
+template <int XD, int UD, bool ROLLOUT, bool AS = false, bool DEFECT = false>
 __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, double *Xout) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
@@ -607,6 +619,13 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
     lon = ldo(a.as_lo, ou_g); hin = ldo(a.as_hi, ou_g); ubn = ldo(a.U, ou_g);
   }
   un = ROLLOUT ? *pu - *pup : 0.0;
+  if (DEFECT) {
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const bool rv = !PADX || (L.row0 + r < XD);
+      fn[r] = rv ? ldo(a.defect, ox_row + (rv ? r * 8u : 0u)) : 0.0;
+    }
+  }
   if (ROLLOUT) {
 #pragma unroll
     for (int r = 0; r < KS; r++) {
@@ -647,6 +666,13 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         if (AS) {
           actn = *(const int *)((const char *)a.as_act + ((ou_g + SU) >> 1));
           lon = ldo(a.as_lo, ou_g + SU); hin = ldo(a.as_hi, ou_g + SU); ubn = ldo(a.U, ou_g + SU);
+        }
+        if (DEFECT) {
+#pragma unroll
+          for (int r = 0; r < KS; r++) {
+            const bool rv = !PADX || (L.row0 + r < XD);
+            fn[r] = rv ? ldo(a.defect, ox_row + SX + (rv ? r * 8u : 0u)) : 0.0;
+          }
         }
       }
     }
@@ -709,6 +735,10 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
     double xr[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) xr[r] = row_allsum(Fr[r] * ycol);
+    if (DEFECT) {
+#pragma unroll
+      for (int r = 0; r < KS; r++) xr[r] += fr[r];
+    }
     if (ROLLOUT) {
       // X_j = f_j + fx (X_{j-1} - Xp_{j-1}) + fu (U_j - Up_j); the next column state is X_j - X_prev_j
 #pragma unroll
@@ -749,7 +779,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
 }
 
 // base point of an active-set round and everything the factor sweep needs at it (see launch_as_prep in pmpc_dev.h)
-__global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double *Du) {
+__global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double *Du, int defect_mode) {
   const long long nx = (long long)a.M * a.N * a.x, nu = (long long)a.M * a.N * a.u;
   const long long stride = (long long)gridDim.x * 256;
   const long long perx = (long long)a.N * a.x, peru = (long long)a.N * a.u;
@@ -757,6 +787,11 @@ __global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double 
   for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nx; k += stride) {
     double X = Xb[k];
     if (add_step) { X += a.dX[k]; Xb[k] = X; }
+    if (defect_mode) {  // base states = the linearisation point itself; its defect is f - X_prev, no matrix product needed
+      X = a.X_prev[k];
+      Xb[k] = X;
+      const_cast<double *>(a.defect)[k] = a.f[k] - X;
+    }
     const double pw = a.pw ? a.pw[k / perx] : 1.0;
     a.xm[k] = pw * (X - a.X_ref[k]);
     a.xd[k] = pw * a.reg_x * (X - a.X_prev[k]);
@@ -766,6 +801,7 @@ __global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double 
     double U = Ub[k];
     if (add_step) U += a.dU[k];
     if (act) U = act == 1 ? a.as_lo[k] : a.as_hi[k];  // exactly on the bound
+    if (defect_mode && U != a.U_prev[k]) *a.fail = 2;  // the base controls are not the linearisation point's: promise broken
     if (add_step || act) Ub[k] = U;
     const double pw = a.pw ? a.pw[k / peru] : 1.0;
     a.um[k] = pw * (U - a.U_ref[k]);
@@ -899,7 +935,10 @@ void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
   const dim3 grd(a.M), blk(64);
 #define PMPC_BWD(F, XB, UB, DP) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB, DP>), grd, blk, 0, s, a)
 #define PMPC_BWD2(F, XB, UB) do { if (deep) PMPC_BWD(F, XB, UB, true); else PMPC_BWD(F, XB, UB, false); } while (0)
-  if (factor && a.as_settled_in && !xb && ub) {  // (the active-set rounds run on control boxes only)
+  if (factor && a.defect && !xb && ub) {  // first round of a warm start with a defective base point (no rollout)
+    if (deep) hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, false, true>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, false, false, true>), grd, blk, 0, s, a);
+  } else if (factor && a.as_settled_in && !xb && ub) {  // (the active-set rounds run on control boxes only)
     // few particles are left in these launches (the settled ones leave at once): occupancy is irrelevant, the deeper pipeline
     // with its lower per-stage latency wins at every M
     hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, true>), grd, blk, 0, s, a);
@@ -924,7 +963,8 @@ void launch_cond_t(const LQArgs &a, hipStream_t s) {
 }
 template <int XD, int UD>
 void launch_fwd_t(const LQArgs &a, hipStream_t s) {
-  if (a.as_act) hipLaunchKernelGGL((k_fwd_fast<XD, UD, false, true>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
+  if (a.as_act && a.defect) hipLaunchKernelGGL((k_fwd_fast<XD, UD, false, true, true>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
+  else if (a.as_act) hipLaunchKernelGGL((k_fwd_fast<XD, UD, false, true>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
   else hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
 }
 template <int XD, int UD>
@@ -978,11 +1018,11 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_grad_prep, dim3((unsigned)b), dim3(256), 0, s, a);
 }
 
-void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s) {
+void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode) {
   long long n = (long long)a.M * a.N * a.x;
   long long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du);
+  hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du, defect_mode);
 }
 void launch_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta, int M, int nc, hipStream_t s) {
   if (nc <= 0) return;

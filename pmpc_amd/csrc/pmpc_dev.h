@@ -56,6 +56,10 @@ struct LQArgs {
   int *as_act;
   const double *as_lo, *as_hi;
   int *as_cnt;
+  // first round of a warm start inside an SCP loop: the base point (X_prev, snapped U_prev) is NOT rolled out — its dynamics
+  // defect r_j = f_j - X_prev_j (elementwise, since base == linearisation point) rides through the sweeps instead:
+  // backward s_j += S_j r_j, forward dx_j += r_j.  Non-null selects the DEFECT kernel variants.
+  const double *defect;
   // settled particles (no status change in the previous round, so their factors, condensed Hessian and feed-forward are
   // still valid): the factor sweep / condensing skip them (as_settled_in), the forward sweep marks them (as_settled_out)
   const int *as_settled_in;
@@ -130,7 +134,9 @@ void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_
 void launch_grad_prep(const LQArgs &a, hipStream_t s);
 // active-set rounds on the fast path: base point <- base + last (clamped) step (add_step), held controls exactly on their
 // bounds, Du = big on them, and the gradient pre-pass arrays of the factor sweep at that point (replaces launch_grad_prep)
-void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s);
+// defect_mode (with a.defect set, add_step 0): base states <- X_prev, a.defect <- f - X_prev, and the check that the base
+// controls ARE U_prev (else *a.fail = 2: the caller's promise was wrong, the solve falls back)
+void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode = 0);
 // counters[0..2] = {released, activated, NaN seen} over the particles, counters[3] = *fail; mirror_cnt != null: also published
 // to host-coherent memory with sequence number `seq`
 // settled particles: gc_part[i] += Hc_part[i] * delta (delta = the consensus step applied in the previous round, nc doubles)

@@ -147,7 +147,7 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
-  DevBuf as_act, as_cnt, as_cntp, as_settled;  // active-set iteration: status per bounded control (int), counters, per-particle counters
+  DevBuf as_act, as_cnt, as_cntp, as_settled, defect;  // active-set iteration: status per bounded control (int), counters, per-particle counters
   DevBuf cons_lo, cons_hi;  // sharded runs: the consensus controls' bounds as last broadcast (PMPC_STATIC_CONS_BOUNDS)
   long long cons_key = -1;
   long long xb_block_key = -1;  // shape whose state boxes were found active: no active-set attempts for it
@@ -349,7 +349,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.defect};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -841,6 +841,7 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
   static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
   static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
   static const bool as_skip_on = !(getenv("PMPC_AS_SKIP") && atoi(getenv("PMPC_AS_SKIP")) == 0);
+  static const bool as_defect_on = !(getenv("PMPC_AS_DEFECT") && atoi(getenv("PMPC_AS_DEFECT")) == 0);
   // State boxes: a state cannot be held on its bound this way, but boxes that are there and INACTIVE at the optimum (loose
   // limits, e.g. x in +-20 of the reference's tests/pmpcjl_test.py:164-219) change nothing: the accepted point only has to
   // be checked against them.  A violated state box sends the solve (and later solves of this shape) to the interior-point path.
@@ -877,11 +878,21 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         // fast path: the forward sweep itself clamps, tests the held controls' multipliers and propagates the clamped step
         // (k_fwd_fast<AS>), so base + step is the next round's base point: no rollout and no check pass after round 1
         b.as_tol_l = tol_l;
+        // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
+        // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout
+        const bool use_defect = round == 0 && mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
         if (round == 0) {
           launch_as_setup(st, mode, 0, act, Utry, big, s);
-          launch_rollout_fast(b, Utry, Xtry, s);
+          if (!use_defect) launch_rollout_fast(b, Utry, Xtry, s);
         }
-        launch_as_prep(b, round > 0, su.D, s);
+        if (use_defect) {
+          w.defect.ensure(nx * D8);
+          b.defect = w.defect.d();
+          launch_as_prep(b, 0, su.D, s, /*defect_mode=*/1);
+        } else {
+          b.defect = nullptr;
+          launch_as_prep(b, round > 0, su.D, s);
+        }
         // particles without a status change in the previous round keep their factors, their condensed Hessian H_i and their
         // conditional optimum: no factor sweep for them — g_i follows the applied consensus step, g_i += H_i delta
         const bool skip = as_skip_on && round > 0 && nc <= 32;

@@ -75,7 +75,7 @@ class DeviceSolver:
     # ---- solve -----------------------------------------------------------------------------------------
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
-                 barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, static_cons_bounds=False, soc_W=None, soc_w0=None,
+                 barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, static_cons_bounds=False, prev_is_last_solution=False, soc_W=None, soc_w0=None,
                  soc_v=None, soc_v0=0.0, soc_u_interior=None):
         M, N, x = f.shape
         u = U_prev.shape[-1]
@@ -100,6 +100,8 @@ class DeviceSolver:
             flags |= _lib.COLD_START
         if static_cons_bounds:  # sharded SCP loops: the consensus controls' bounds are those of the previous solve (no re-broadcast)
             flags |= _lib.STATIC_CONS_BOUNDS
+        if prev_is_last_solution:  # SCP loops: X_prev / U_prev are the previous solve's outputs, boxes unchanged (no rollout)
+            flags |= _lib.PREV_IS_LAST_SOLUTION
         if symmetric_cost:  # Q_j, R_j exactly symmetric (enables the register-resident MFMA path)
             flags |= _lib.SYMMETRIC_COST
         prob = _lib.PmpcProblem(

@@ -131,7 +131,8 @@ def scp_solve_device(f_fx_fu_fn: Optional[Callable], Q, R, x0, X_ref=None, U_ref
         kw = dict(f=f, fx=fxa, fu=fua, X_prev=X_prev, U_prev=U_prev, Q=Qa, R=Ra, X_ref=X_ref, U_ref=U_ref, reg_x=float(reg_x),
                   reg_u=float(reg_u), Nc=Nc, x0=x0c, lx=lx, ux=ux, lu=lu, uu=uu, slew_reg=slew, slew_reg0=slew0, slew_um1=um1,
                   X_out=Xs, U_out=Us, symmetric_cost=sym, verbose=bool(settings.get("verbose", False)),
-                  static_cons_bounds=it > 0)  # the boxes are the same in every iteration of this loop (scp_mpc.py:338-376)
+                  static_cons_bounds=it > 0,  # the boxes are the same in every iteration of this loop (scp_mpc.py:338-376)
+                  prev_is_last_solution=it > 0)  # and X_prev, U_prev are the previous iteration's X, U (scp_mpc.py:430)
         if soc is not None:
             _, _, status = s.lsoc_solve(**soc_kw, **kw)
         elif cone:

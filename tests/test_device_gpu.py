@@ -292,3 +292,46 @@ def test_inactive_state_boxes_take_the_active_set_path_active_ones_the_interior_
                 if rep:
                     assert info["active_set_rounds"] == 0, info  # remembered: no second attempt for this shape
         s.close()
+
+
+@pytest.mark.parametrize("case", [(16, 12, 12, 4, 1), (9, 10, 4, 2, 3), (8, 9, 5, 3, 0)], ids=["quadrotor-dims-Nc1", "Nc3", "Nc0"])
+def test_scp_like_sequence_without_rollout(case, oracle):
+    """PMPC_PREV_IS_LAST_SOLUTION: each sub-problem's X_prev / U_prev are the previous solve's outputs (an SCP loop), so the
+    warm start takes the linearisation point as its base and carries the dynamics defect f - X_prev through the sweeps
+    instead of a rollout.  Exact against the oracle; a broken promise (X_prev / U_prev perturbed) is detected on the device
+    and still ends on the optimum."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+    from tests.support.problems import rand_problem
+
+    M, N, x, u, Nc = case
+    rng = np.random.default_rng(101)
+    args, kw = rand_problem(rng, M, N, x, u, 0.25)
+    s = DeviceSolver(0)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    Xl = Ul = None
+    for t in range(5):
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+        promise = t > 0
+        if t:  # next SCP iteration: re-linearised dynamics around the last solution
+            f = f + 0.03 * rng.standard_normal(f.shape)
+            fx = fx * (1 + 0.03 * rng.standard_normal(fx.shape))
+            fu = fu * (1 + 0.03 * rng.standard_normal(fu.shape))
+            X_prev, U_prev = Xl, Ul
+            if t == 3:  # a caller that breaks the promise (keeps the flag, feeds something else back)
+                U_prev = Ul + 1e-3 * rng.standard_normal(Ul.shape)
+        args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
+        Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+        X, U, status = s.lqp_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R),
+                                   X_ref=dev(X_ref), U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, symmetric_cost=True,
+                                   lu=dev(kw["u_l"]), uu=dev(kw["u_u"]), prev_is_last_solution=promise)
+        s.sync()
+        info = dict(s.last_info)
+        Xl, Ul = X.cpu().numpy(), U.cpu().numpy()
+        assert status == 0 and rel(Xl, Xo) < 1e-9 and rel(Ul, Uo) < 1e-9, (t, info, rel(Xl, Xo), rel(Ul, Uo))
+        if t in (1, 2, 4):
+            assert info["ipm_iters"] == 0 and info["active_set_rounds"] >= 1, (t, info)
+    s.close()
