@@ -235,7 +235,8 @@ def main():
     # outside the timed region: the convex sub-problem alone (SURVEY.md section 8d asks for the aff_solve-only rate next
     # to the full-iteration rate) — same linearisation re-solved from a COLD start (re-solving an identical problem
     # warm would flatter the number), no dynamics / residual kernels
-    solver.profile(False)
+    solver.profile(1)  # (the cold solves' factor sweeps are the PLAIN full sweeps: equality-only solve + first active-set round)
+    solver.profile_read()
     k2 = max(1, min(args.steps, 10))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -245,6 +246,8 @@ def main():
                          force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False, cold_start=True)
     solver.sync()
     aff_only = k2 / (time.perf_counter() - t1)
+    prof_cold = solver.profile_read()
+    solver.profile(False)
     timed = hist[args.warmup:]
     ipm_its = [h[1]["ipm_iters"] for h in timed]
     solves = [h[1]["structured_solves"] for h in timed]
@@ -257,6 +260,12 @@ def main():
         alg_bytes = unit_bytes * M_loc * N  # per launch: every (particle, stage) of this rank's shard
         avg_s = (ms_f / max(n_f, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if n_f else 0.0
+        ms_c, n_c = prof_cold["bwd_factor"]
+        plain = None
+        if n_c:
+            avg_c = ms_c / n_c * 1e-3
+            plain = {"avg_launch_ms": 1e3 * avg_c, "achieved": alg_bytes / avg_c / 1e9, "frac": alg_bytes / avg_c / 1e9 / HBM_PEAK_GBS,
+                     "launches": int(n_c)}
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
@@ -280,8 +289,12 @@ def main():
                        "ipm_warm_start": os.environ.get("PMPC_WARM_START", "1") != "0"},
             "roofline": {"bound": "hbm", "kernel": "backward Riccati factor sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "note": "full factor sweeps only (every particle x stage): later active-set rounds skip the settled particles "
-                                 "and are timed in a class of their own (bwd_factor_partial, --profile-all)",
+                         "note": "full factor sweeps of the timed region only (every particle x stage): later active-set rounds skip the "
+                                 "settled particles and are timed in a class of their own (bwd_factor_partial, --profile-all). Inside the "
+                                 "SCP loop the full sweep is the DEFECT instantiation (it also carries the base point's dynamics defect, "
+                                 "which replaces a separate rollout kernel; 136 VGPRs -> 3 waves per SIMD); plain_full_sweep = the "
+                                 "same figure for the plain instantiation, measured over the cold solves after the timed region",
+                         "plain_full_sweep": plain,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * avg_s, "launches": int(n_f),
                          "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0}},
         }
