@@ -270,7 +270,11 @@ def main():
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
             try:
-                traffic = json.loads(tf.read_text()).get("bwd_factor_bytes_per_launch")
+                tj = json.loads(tf.read_text())
+                # timed region = DEFECT instantiation once the SCP loop runs (second step on); plain instantiation otherwise
+                traffic = tj.get("bwd_factor_defect_bytes_per_launch", tj.get("bwd_factor_bytes_per_launch"))
+                if plain is not None:
+                    plain["traffic"] = tj.get("bwd_factor_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

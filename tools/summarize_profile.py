@@ -37,8 +37,11 @@ ax_write = sum(write[key(write, "k_axpy(")]) / len(write[key(write, "k_axpy(")])
 out = {"calibration": {"kernel": "k_axpy", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
                        "read_factor": read_factor, "true_write_bytes": 8 * (nx + nu) / 2, "WRITE_SIZE_bytes": ax_write}}
 # full factor sweep only: the SKIP instantiation (last template argument true) processes a subset of the particles
-for name, label in (("k_bwd_fast<12, 4, true, false, true, false, false>", "bwd_factor"), ("k_bwd_fast<12, 4, false", "bwd_vec"),
-                    ("k_fwd_fast<12, 4, false, false>", "fwd"), ("k_fwd_fast<12, 4, false, true>", "fwd_active_set")):
+# template arguments: <x, u, FACTOR, HXB, HUB, DEEP, SKIP, DEFECT>
+for name, label in (("k_bwd_fast<12, 4, true, false, true, false, false, false>", "bwd_factor"),
+                    ("k_bwd_fast<12, 4, true, false, true, false, false, true>", "bwd_factor_defect"), ("k_bwd_fast<12, 4, false", "bwd_vec"),
+                    ("k_fwd_fast<12, 4, false, false, false>", "fwd"), ("k_fwd_fast<12, 4, false, true, false>", "fwd_active_set"),
+                    ("k_fwd_fast<12, 4, false, true, true>", "fwd_active_set_defect")):
     try:
         kf, kw = key(fetch, name), key(write, name)
     except StopIteration:
