@@ -500,6 +500,24 @@ __global__ void __launch_bounds__(TB) k_as_accept(Slab s, const int *act, const 
     s.z[k] = a == 1 ? lo : (a == 2 ? hi : fmin(fmax(ztry[k] + s.dz[k], lo), hi));
   }
 }
+// accepted active-set point in ONE pass: controls (bound on the active set, base + step kept inside the box elsewhere) and
+// states (base + step), each written to the workspace (the next solve's warm start) AND to the caller's output
+__global__ void __launch_bounds__(TB) k_as_accept_all(Slab s, const int *act, const double *ztry, double *Uout, const double *xtry,
+                                                      const double *dx, long long nx, double *Xws, double *Xout) {
+  const long long stride = (long long)gridDim.x * TB, t0 = blockIdx.x * (long long)TB + threadIdx.x;
+  for (long long k = t0; k < s.count; k += stride) {
+    const int a = act[k];
+    const double lo = s.lo[k], hi = s.hi[k];
+    const double z = a == 1 ? lo : (a == 2 ? hi : fmin(fmax(ztry[k] + s.dz[k], lo), hi));
+    s.z[k] = z;
+    Uout[k] = z;
+  }
+  for (long long k = t0; k < nx; k += stride) {
+    const double x = xtry[k] + dx[k];
+    Xws[k] = x;
+    Xout[k] = x;
+  }
+}
 __global__ void __launch_bounds__(TB) k_add(double *out, const double *a, const double *b, long long n) {
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) out[k] = a[k] + b[k];
 }
@@ -583,6 +601,10 @@ void launch_as_check(const Slab &sl, int *act, const double *ztry, double big, d
 }
 void launch_as_accept(const Slab &sl, const int *act, const double *ztry, hipStream_t s) {
   hipLaunchKernelGGL(k_as_accept, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry);
+}
+void launch_as_accept_all(const Slab &sl, const int *act, const double *ztry, double *Uout, const double *xtry, const double *dx,
+                          long long nx, double *Xws, double *Xout, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_accept_all, dim3(2 * PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry, Uout, xtry, dx, nx, Xws, Xout);
 }
 void launch_add(double *out, const double *a, const double *b, long long n, hipStream_t s) {
   long long nb = (n + TB - 1) / TB;

@@ -572,11 +572,14 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
     launch_axpy(w.U.d(), w.dU.d(), 1.0, (long long)nu, s);
   };
 
+  bool outputs_written = false;
   auto finish = [&](int status) {
     inf.status = status;
     if (status == 0) {
-      HIP_CHECK(hipMemcpyAsync(p->X_out, w.X.p, nx * D8, hipMemcpyDeviceToDevice, s));
-      HIP_CHECK(hipMemcpyAsync(p->U_out, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      if (!outputs_written) {  // (an accepted active-set point is written to the outputs by its own kernel)
+        HIP_CHECK(hipMemcpyAsync(p->X_out, w.X.p, nx * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(p->U_out, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      }
     } else {
       fill_nan_outputs(c, p);
     }
@@ -946,8 +949,8 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
             return 1;
           }
         }
-        launch_as_accept(st, act, Utry, s);
-        launch_add(w.X.d(), Xtry, w.dX.d(), (long long)nx, s);
+        launch_as_accept_all(st, act, Utry, p->U_out, Xtry, w.dX.d(), (long long)nx, w.X.d(), p->X_out, s);
+        outputs_written = true;
         w.as_key = as_key;  // act + w.U start the next solve of this shape
         w.as_scale = dual_scale;
         return 0;
