@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
 }
 
 // base point of an active-set round and everything the factor sweep needs at it (see launch_as_prep in pmpc_dev.h)
-__global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double *Du, int defect_mode) {
+__global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double *Du, int defect_mode, const double *ubase) {
   const long long nx = (long long)a.M * a.N * a.x, nu = (long long)a.M * a.N * a.u;
   const long long stride = (long long)gridDim.x * 256;
   const long long perx = (long long)a.N * a.x, peru = (long long)a.N * a.u;
@@ -800,9 +800,13 @@ __global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double 
     const int act = a.as_act[k];
     double U = Ub[k];
     if (add_step) U += a.dU[k];
+    if (ubase) {  // defect mode: this pass also takes the first base point from the previous solution (k_as_setup's job)
+      const double lo = a.as_lo[k], hi = a.as_hi[k];
+      U = lo > hi ? NAN : fmin(fmax(ubase[k], lo), hi);  // (an empty box ends the solve through the NaN counter)
+    }
     if (act) U = act == 1 ? a.as_lo[k] : a.as_hi[k];  // exactly on the bound
     if (defect_mode && U != a.U_prev[k]) *a.fail = 2;  // the base controls are not the linearisation point's: promise broken
-    if (add_step || act) Ub[k] = U;
+    if (add_step || act || ubase) Ub[k] = U;
     const double pw = a.pw ? a.pw[k / peru] : 1.0;
     a.um[k] = pw * (U - a.U_ref[k]);
     a.ud[k] = pw * a.reg_u * (U - a.U_prev[k]);
@@ -1018,11 +1022,11 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_grad_prep, dim3((unsigned)b), dim3(256), 0, s, a);
 }
 
-void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode) {
+void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode, const double *ubase) {
   long long n = (long long)a.M * a.N * a.x;
   long long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du, defect_mode);
+  hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du, defect_mode, ubase);
 }
 void launch_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta, int M, int nc, hipStream_t s) {
   if (nc <= 0) return;

@@ -136,7 +136,8 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s);
 // bounds, Du = big on them, and the gradient pre-pass arrays of the factor sweep at that point (replaces launch_grad_prep)
 // defect_mode (with a.defect set, add_step 0): base states <- X_prev, a.defect <- f - X_prev, and the check that the base
 // controls ARE U_prev (else *a.fail = 2: the caller's promise was wrong, the solve falls back)
-void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode = 0);
+// ubase (defect mode): the previous solution's controls — the pass also snaps them into the boxes (first base point)
+void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode = 0, const double *ubase = nullptr);
 // counters[0..2] = {released, activated, NaN seen} over the particles, counters[3] = *fail; mirror_cnt != null: also published
 // to host-coherent memory with sequence number `seq`
 // settled particles: gc_part[i] += Hc_part[i] * delta (delta = the consensus step applied in the previous round, nc doubles)

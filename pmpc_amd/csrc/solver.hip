@@ -884,14 +884,14 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
         // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
         // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout
         const bool use_defect = round == 0 && mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
-        if (round == 0) {
+        if (round == 0 && !use_defect) {
           launch_as_setup(st, mode, 0, act, Utry, big, s);
-          if (!use_defect) launch_rollout_fast(b, Utry, Xtry, s);
+          launch_rollout_fast(b, Utry, Xtry, s);
         }
-        if (use_defect) {
+        if (use_defect) {  // one pass: base point from the previous solution (stored set, boxes), defect, gradient arrays, D
           w.defect.ensure(nx * D8);
           b.defect = w.defect.d();
-          launch_as_prep(b, 0, su.D, s, /*defect_mode=*/1);
+          launch_as_prep(b, 0, su.D, s, /*defect_mode=*/1, /*ubase=*/w.U.d());
         } else {
           b.defect = nullptr;
           launch_as_prep(b, round > 0, su.D, s);
