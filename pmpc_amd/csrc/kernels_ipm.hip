@@ -492,14 +492,6 @@ __global__ void __launch_bounds__(TB) k_as_check(Slab s, int *act, const double 
   }
 }
 
-// accepted: z <- bound on the active set, base + step (kept inside the box against round-off) elsewhere
-__global__ void __launch_bounds__(TB) k_as_accept(Slab s, const int *act, const double *ztry) {
-  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
-    const int a = act[k];
-    const double lo = s.lo[k], hi = s.hi[k];
-    s.z[k] = a == 1 ? lo : (a == 2 ? hi : fmin(fmax(ztry[k] + s.dz[k], lo), hi));
-  }
-}
 // accepted active-set point in ONE pass: controls (bound on the active set, base + step kept inside the box elsewhere) and
 // states (base + step), each written to the workspace (the next solve's warm start) AND to the caller's output
 __global__ void __launch_bounds__(TB) k_as_accept_all(Slab s, const int *act, const double *ztry, double *Uout, const double *xtry,
@@ -517,9 +509,6 @@ __global__ void __launch_bounds__(TB) k_as_accept_all(Slab s, const int *act, co
     Xws[k] = x;
     Xout[k] = x;
   }
-}
-__global__ void __launch_bounds__(TB) k_add(double *out, const double *a, const double *b, long long n) {
-  for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < n; k += (long long)gridDim.x * TB) out[k] = a[k] + b[k];
 }
 
 // Input checks of the host-pointer ABI, on the device after the upload (the host would scan ~320 MB per call at config D):
@@ -599,17 +588,9 @@ void launch_as_check(const Slab &sl, int *act, const double *ztry, double big, d
                      unsigned long long *worst_bits, hipStream_t s) {
   hipLaunchKernelGGL(k_as_check, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry, big, tol_p, tol_l, counters, worst_bits);
 }
-void launch_as_accept(const Slab &sl, const int *act, const double *ztry, hipStream_t s) {
-  hipLaunchKernelGGL(k_as_accept, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry);
-}
 void launch_as_accept_all(const Slab &sl, const int *act, const double *ztry, double *Uout, const double *xtry, const double *dx,
                           long long nx, double *Xws, double *Xout, hipStream_t s) {
   hipLaunchKernelGGL(k_as_accept_all, dim3(2 * PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, act, ztry, Uout, xtry, dx, nx, Xws, Xout);
-}
-void launch_add(double *out, const double *a, const double *b, long long n, hipStream_t s) {
-  long long nb = (n + TB - 1) / TB;
-  if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_add, dim3((unsigned)nb), dim3(TB), 0, s, out, a, b, n);
 }
 void launch_violation_sum(const Slab &sl, const double *za, const double *zb, double *part_max, hipStream_t s) {
   hipLaunchKernelGGL(k_violation_sum, dim3(PMPC_RED_BLOCKS), dim3(TB), 0, s, sl, za, zb, part_max);

@@ -163,10 +163,8 @@ void launch_ipm_clip(const Slab &sl, hipStream_t s);
 void launch_as_setup(const Slab &sl, int from_ipm, int keep_base, int *act, double *ztry, double big, hipStream_t s);
 void launch_as_check(const Slab &sl, int *act, const double *ztry, double big, double tol_p, double tol_l, int *counters,
                      unsigned long long *worst_bits, hipStream_t s);
-void launch_as_accept(const Slab &sl, const int *act, const double *ztry, hipStream_t s);
 void launch_as_accept_all(const Slab &sl, const int *act, const double *ztry, double *Uout, const double *xtry, const double *dx,
                           long long nx, double *Xws, double *Xout, hipStream_t s);  // accepted point -> workspace + caller's outputs
-void launch_add(double *out, const double *a, const double *b, long long n, hipStream_t s);
 void launch_ipm_init_slack(const Slab &sl, double mu0, hipStream_t s, double thr_frac = 1e-2);
 void launch_ipm_prepare(const Slab &sl, int corrector, const IpmScal *sc, double *part_sum, double *part_cnt,
                         double *part_max, hipStream_t s);
