@@ -108,3 +108,27 @@ def test_empty_box_fails_like_the_reference(oracle):
     Xo, Uo = oracle.lqp_solve_py(*args2, Nc=1, **kw2)
     X, U = backend.lqp_solve(*abi_args(args2, kw2, 1))
     assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-7 and np.linalg.norm(U - Uo) / max(np.linalg.norm(Uo), 1.0) < 1e-7
+
+
+def test_host_abi_notices_in_place_changes_of_arrays_it_did_not_resend(oracle):
+    """The host-pointer ABI skips the upload of chunks whose bytes equal the previous call's (Q, R, references, boxes inside
+    an SCP loop).  The comparison is exact: a single entry changed IN PLACE in the caller's own array must reach the solve."""
+    from pmpc_amd import backend
+
+    args, kw = rand_problem(np.random.default_rng(8), 6, 8, 4, 2, 0.3)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    a = list(abi_args(args, kw, 1))
+    for step in range(4):
+        if step == 1:  # a new linearisation, everything else untouched (the SCP case: those chunks are not sent again)
+            a[2] = a[2] + 0.01
+            args = (args[0], args[1] + 0.01) + tuple(args[2:])
+        if step == 2:  # one cost entry changed in place, same array object, same address
+            Q = args[6]
+            Q[2, 3, 1, 1] += 0.5
+            a[7][...] = abi_args(args, kw, 1)[7]
+        if step == 3:  # and one bound
+            kw["u_u"][1, 2, 0] *= 0.5
+            a[14][...] = abi_args(args, kw, 1)[14]
+        Xo, Uo = oracle.lqp_solve_py(*args, Nc=1, **kw)
+        X, U = backend.lqp_solve(*a)
+        assert rel(X, Xo) < 1e-7 and rel(U, Uo) < 1e-7, step
