@@ -335,3 +335,30 @@ def test_scp_like_sequence_without_rollout(case, oracle):
         if t in (1, 2, 4):
             assert info["ipm_iters"] == 0 and info["active_set_rounds"] >= 1, (t, info)
     s.close()
+
+
+def test_bench_line_keeps_the_driver_contract():
+    """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver reads, the metric / unit of
+    BASELINE.json, and the `roofline` and `cpu_baseline` objects (small sizes here: the contract, not the numbers)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--M", "64", "--N", "12"],
+                       cwd=str(root), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "SCP iterations/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
