@@ -210,3 +210,15 @@ def test_real_rccl_calls_on_a_one_rank_communicator():
     r = subprocess.run([sys.executable, "-c", _RCCL_SINGLE_SCRIPT], cwd=str(Path(__file__).resolve().parents[1]), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_SINGLE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_bench_calling_pattern_sharded_over_mock_ranks():
+    """bench.py's loop (outputs fed back as X_prev / U_prev, PMPC_STATIC_CONS_BOUNDS + PMPC_PREV_IS_LAST_SOLUTION from the second
+    iteration) on 2 / 4 / 8 in-process ranks against one rank: tools/debug/sharded_scp_loop.py, in its own process."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, "tools/debug/sharded_scp_loop.py", "64"], cwd=str(root), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "SHARDED_SCP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
