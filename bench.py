@@ -138,8 +138,28 @@ def cpu_baseline_structured(model, M_total, N, Nc, budget_s=6.0):
                         f"{info['solve_s']:.2f}s; scaled x{M_total / Ms:g}"))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) through
+    torch.distributed.run and relay their output (rank 0 prints the JSON line).  Runs before this process touches torch or
+    the GPU; the children are ordinary subprocesses (no exec of a GPU-initialised process)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks were launched")
     import torch
     import torch.distributed as dist
 
@@ -190,7 +210,7 @@ def main():
     solve_fn = solver.lsoc_solve if args.soc else solver.lqp_solve
 
     def step(Xp, Up, Xo, Uo):
-        solver.linearize(model, d["x0"], Xp, Up, d["params"], f, fx, fu)
+        solver.linearize(model, d["x0"], Xp, Up, d["params"], f, fx, fu, wait_current_stream=False)
         _, _, status = solve_fn(**soc_kw, f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
                                         U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
                                         lu=d.get("lu"), uu=d.get("uu"), X_out=Xo, U_out=Uo, verbose=args.verbose,
@@ -199,7 +219,7 @@ def main():
                                         # and X_prev / U_prev are the previous iteration's solution)
         if status != 0 and not args.ignore_status:
             raise SystemExit(f"solver failed with status {status}")
-        res = solver.scp_residual(Xo, Xp, Uo, Up)  # SCP residual of pmpc/scp_mpc.py:397-403: one fused pass on the solver's stream
+        res = solver.scp_residual(Xo, Xp, Uo, Up, wait_current_stream=False)  # SCP residual of pmpc/scp_mpc.py:397-403: one fused pass on the solver's stream
         if world > 1:
             with torch.cuda.stream(solver.stream):
                 dist.all_reduce(res, op=dist.ReduceOp.MAX)

@@ -511,7 +511,9 @@ def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, 
     eps = COST_ANCHOR_EPS
     bmu = 1.0 / smooth_alpha if smooth_alpha == smooth_alpha and smooth_alpha > 0 else 0.0
     M = np.shape(f)[0]
-    assert 2 * eps * M < 1 + eps, "threshold rank > 1: the reference's minimiser is not unique"
+    if 2 * eps * M >= 1 + eps:
+        return _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=reg_x, reg_u=reg_u, Nc=Nc,
+                                     return_info=return_info, bmu=bmu, **kw)
     args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
     ckw = dict(reg_x=reg_x, reg_u=reg_u, slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
 
@@ -551,6 +553,76 @@ def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, 
                 if min(J[a], J[b]) <= np.min(J) + tol(J):
                     return (X, U, dict(weights=w, J=J, qp=info, kink=True, theta=th)) if return_info else (X, U)
     raise RuntimeError("cone oracle: no consistent threshold particle / pair found")
+
+
+def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc, return_info, bmu, w_floor=1e-10, **kw):
+    """Cone path for M >= (1+eps)/(2 eps) ~ 500 particles (main.jl:204-238, k = M).  KKT conditions of the epigraph problem
+    min (1+eps) sum y_i + (1-eps) M t  s.t.  J_i(z) <= y_i + t, y >= 0  with multipliers lambda_i of the cone rows:
+    lambda_i = 1+eps where J_i > t, 0 where J_i < t, in between on J_i = t, and sum lambda_i = (1-eps) M; stationarity in z
+    is that of the weighted QP sum lambda_i J_i.  So with m* = ceil(2 eps M / (1+eps)) the m*-1 cheapest particles carry NO
+    weight, the m*-th carries (1+eps) m* - 2 eps M, the rest 1+eps.  A zero-weight particle's free variables do not enter
+    the objective at all: the reference's minimiser is not unique in them.  STATED SEMANTICS of this restatement (and of
+    the device solver, which uses the floor 1e-4): among the minimisers, the one where every zero-weight particle
+    minimises its own J_i given the shared controls — the limit w -> 0+ of a floor weight, here `w_floor` = 1e-10 in an
+    exact sparse solve.  Found by fixed-point iteration on the ranking, 2-cycles resolved on the kink J_a = J_b by root
+    finding in the interpolation parameter; the returned certificate checks the multiplier conditions above."""
+    from scipy.optimize import brentq
+
+    eps, M = COST_ANCHOR_EPS, np.shape(f)[0]
+    hi = 1 + eps
+    mstar = max(1, int(np.ceil(2 * eps * M / hi - 1e-12)))
+    w_thr = hi * mstar - 2 * eps * M
+    args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
+    ckw = dict(reg_x=reg_x, reg_u=reg_u, slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
+
+    def solve(w):
+        X, U, info = lqp_solve_py(*args, reg_x=reg_x, reg_u=reg_u, Nc=Nc, weights=w, return_info=True, barrier_mu=bmu, **kw)
+        return X, U, particle_costs_py(X, U, X_prev, U_prev, Q, R, X_ref, U_ref, **ckw), info
+
+    def weights_of(J):
+        order = np.lexsort((np.arange(M), J))[:mstar]  # ascending cost, ties by index (as the device solver ranks)
+        w = np.full(M, hi)
+        w[order[:-1]] = w_floor
+        w[order[-1]] = max(w_thr, w_floor)
+        return w
+
+    def certificate(w, J):
+        t = float(np.max(J[w < hi])) if np.any(w < hi) else float(np.min(J))
+        tol = 1e-9 * max(1.0, abs(t))
+        lam = np.where(w <= w_floor, 0.0, w)
+        return dict(sum_lambda=float(abs(np.sum(lam) - (1 - eps) * M)), full_below=float(max(0.0, np.max(t - J[w >= hi], initial=0.0)) / max(1.0, abs(t))),
+                    ok=bool(abs(np.sum(lam) - (1 - eps) * M) <= 1e-9 * M and np.all(J[w >= hi] >= t - tol)))
+
+    X, U, J, _ = solve(np.full(M, hi))
+    w1, w_prev = weights_of(J), None
+    for _ in range(12):
+        X, U, J, info = solve(w1)
+        w2 = weights_of(J)
+        if np.array_equal(w2, w1):
+            cert = certificate(w1, J)
+            assert cert["ok"], cert
+            return (X, U, dict(weights=w1, J=J, qp=info, kink=False, cone_cert=cert)) if return_info else (X, U)
+        if w_prev is not None and np.array_equal(w2, w_prev):
+            d = w1 - w2
+            a, b = int(np.argmin(d)), int(np.argmax(d))
+
+            def gap(th):
+                _, _, Jt, _ = solve(th * w1 + (1 - th) * w2)
+                return Jt[a] - Jt[b]
+
+            th = brentq(gap, 0.0, 1.0, xtol=1e-14, rtol=1e-14)
+            w = th * w1 + (1 - th) * w2
+            X, U, J, info = solve(w)
+            lam = np.where(w <= w_floor, 0.0, w)
+            jk = 0.5 * (J[a] + J[b])
+            others = np.ones(M, bool)
+            others[[a, b]] = False
+            tol = 1e-9 * max(1.0, abs(jk))
+            ok = abs(np.sum(lam) - (1 - eps) * M) <= 1e-9 * M and np.all(J[others & (w >= hi)] >= jk - tol) and np.all(J[others & (w < hi)] <= jk + tol)
+            assert ok, "cone oracle: the kink between two rankings is not a KKT point"
+            return (X, U, dict(weights=w, J=J, qp=info, kink=True, theta=th)) if return_info else (X, U)
+        w_prev, w1 = w1, w2
+    raise RuntimeError("cone oracle: the threshold set did not settle")
 
 
 def aff_solve(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l,

@@ -10,14 +10,29 @@
 #include <cstdio>
 #include <cstdlib>
 
+// A failed HIP / RCCL call on a solve path must not take the host process down: the drop-in ABI's failure convention is
+// NaN outputs (PMPC.jl/src/osqp_solver.jl:65-71 -> (None, None, None) in pmpc/scp_mpc.py:391-394).  HIP_CHECK reports and
+// throws; every extern "C" entry point catches, fills its outputs with NaN where it still can and returns status 2.
+struct PmpcHipError {
+  int code;
+  const char *what, *file;
+  int line;
+};
 #define HIP_CHECK(expr)                                                                       \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \
     if (_e != hipSuccess) {                                                                   \
       fprintf(stderr, "pmpc_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, \
               __LINE__, #expr);                                                               \
-      abort();                                                                                \
+      throw PmpcHipError{(int)_e, #expr, __FILE__, __LINE__};                                 \
     }                                                                                         \
+  } while (0)
+// destructors and clean-up paths: report, never throw
+#define HIP_WARN(expr)                                                                        \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      fprintf(stderr, "pmpc_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
   } while (0)
 
 // Arguments of the structured LQ kernels (Riccati factor / vector sweeps / forward sweep).

@@ -117,11 +117,14 @@ ncclResult_t mock_broadcast(const void *send, void *recv, size_t n, ncclDataType
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
-  void ensure(size_t b) {
-    if (b <= bytes) return;
-    if (p) HIP_CHECK(hipFree(p));
-    HIP_CHECK(hipMalloc(&p, b ? b : 8));
+  bool ensure(size_t b) {  // true: the buffer was (re)allocated — whatever it held is gone
+    if (b <= bytes) return false;
+    if (p) HIP_WARN(hipFree(p));
+    p = nullptr;
+    bytes = 0;
+    HIP_CHECK(hipMalloc(&p, b ? b : 8));  // (throws on failure, e.g. out of memory at a large M: the solve returns status 2)
     bytes = b;
+    return true;
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -202,7 +205,14 @@ void allreduce(pmpc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t 
   ncclResult_t r = g_rccl.AllReduce(buf, buf, n, dt, op, c->comm, c->stream);
   if (r != ncclSuccess) {
     fprintf(stderr, "pmpc_hip: ncclAllReduce failed (%d)\n", (int)r);
-    abort();
+    throw PmpcHipError{(int)r, "ncclAllReduce", __FILE__, __LINE__};
+  }
+}
+void broadcast(pmpc_ctx *c, void *buf, size_t n, ncclDataType_t dt, int root) {
+  ncclResult_t r = g_rccl.Broadcast(buf, buf, n, dt, root, c->comm, c->stream);
+  if (r != ncclSuccess) {
+    fprintf(stderr, "pmpc_hip: ncclBroadcast failed (%d)\n", (int)r);
+    throw PmpcHipError{(int)r, "ncclBroadcast", __FILE__, __LINE__};
   }
 }
 
@@ -225,7 +235,7 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
   }
   ~ProfScope() {
     if (!on) return;
-    HIP_CHECK(hipEventRecord(ev.second, c->stream));
+    HIP_WARN(hipEventRecord(ev.second, c->stream));
     c->cat[k].pending.push_back(ev);
   }
 };
@@ -242,7 +252,7 @@ void wait_published(pmpc_ctx *c, volatile unsigned long long *seq, unsigned long
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (*seq != want) {
       fprintf(stderr, "pmpc_hip: device scalars were never published\n");
-      abort();
+      throw PmpcHipError{-1, "wait_published", __FILE__, __LINE__};
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -307,6 +317,29 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
   else launch_fwd_generic(a, s);
 }
 
+// epilogue of a solve that threw (failed HIP / RCCL call, out of memory): forget every warm-start memory, NaN outputs if the
+// device still takes work, status 2.  Never throws.
+int fail_after_error(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info) {
+  Workspace &w = c->ws;
+  w.as_key = w.warm_key = w.soc_key = w.cons_key = w.xb_block_key = -1;
+  c->staged.clear();
+  (void)hipGetLastError();
+  try {
+    if (p && p->X_out && p->U_out) {
+      const double nan = std::numeric_limits<double>::quiet_NaN();
+      launch_fill(p->X_out, nan, (long long)p->M * p->N * p->xdim, c->stream);
+      launch_fill(p->U_out, nan, (long long)p->M * p->N * p->udim, c->stream);
+    }
+    HIP_WARN(hipStreamSynchronize(c->stream));
+  } catch (...) {
+  }
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    info->status = 2;
+  }
+  return 2;
+}
+
 void fill_nan_outputs(pmpc_ctx *c, const pmpc_problem *p) {
   const double nan = std::numeric_limits<double>::quiet_NaN();
   launch_fill(p->X_out, nan, (long long)p->M * p->N * p->xdim, c->stream);
@@ -329,13 +362,20 @@ int pmpc_create(pmpc_ctx **out, int device) {
   }
   pmpc_ctx *c = new pmpc_ctx();
   c->device = device;
-  HIP_CHECK(hipSetDevice(device));
-  HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  c->sc_host = (IpmScal *)calloc(1, sizeof(IpmScal));
-  c->fail_host = (int *)calloc(1, sizeof(int));
-  HIP_CHECK(hipHostMalloc((void **)&c->mirror, sizeof(pmpc_ctx::ScMirror), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(c->mirror, 0, sizeof(pmpc_ctx::ScMirror));
-  HIP_CHECK(hipHostGetDevicePointer((void **)&c->mirror_dev, c->mirror, 0));
+  try {
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->sc_host = (IpmScal *)calloc(1, sizeof(IpmScal));
+    c->fail_host = (int *)calloc(1, sizeof(int));
+    HIP_CHECK(hipHostMalloc((void **)&c->mirror, sizeof(pmpc_ctx::ScMirror), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->mirror, 0, sizeof(pmpc_ctx::ScMirror));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&c->mirror_dev, c->mirror, 0));
+  } catch (const PmpcHipError &) {
+    free(c->sc_host);
+    free(c->fail_host);
+    delete c;
+    return 1;
+  }
   *out = c;
   return 0;
 }
@@ -366,19 +406,19 @@ void pmpc_destroy(pmpc_ctx *c) {
 }
 
 void *pmpc_stream(pmpc_ctx *c) { return (void *)c->stream; }
-void pmpc_sync(pmpc_ctx *c) { HIP_CHECK(hipStreamSynchronize(c->stream)); }
+void pmpc_sync(pmpc_ctx *c) { HIP_WARN(hipStreamSynchronize(c->stream)); }
 
 void pmpc_profile_enable(pmpc_ctx *c, int level) { c->prof = level < 0 ? 0 : level; }
 
 // Sums of HIP-event durations (ms) and launch counts per kernel class since the last read:
 // 0 backward+factor, 1 backward vector-only, 2 forward sweep, 3 consensus reduce + dense solve.
 void pmpc_profile_read(pmpc_ctx *c, double *ms4, long long *n4) {
-  HIP_CHECK(hipStreamSynchronize(c->stream));
+  HIP_WARN(hipStreamSynchronize(c->stream));
   for (int k = 0; k < 5; k++) {
     ProfCat &pc = c->cat[k];
     for (auto &ev : pc.pending) {
       float t = 0.f;
-      HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second));
+      HIP_WARN(hipEventElapsedTime(&t, ev.first, ev.second));
       pc.ms += t;
       pc.n++;
       pc.pool.push_back(ev);
@@ -417,7 +457,7 @@ int pmpc_comm_init(pmpc_ctx *c, int rank, int world, const void *id128) {
   }
   if (world <= 1) { world = 1; rank = 0; c->single_rank_comm = true; }
   if (!g_rccl.load()) return 1;
-  HIP_CHECK(hipSetDevice(c->device));
+  if (hipSetDevice(c->device) != hipSuccess) return 3;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) return 2;
@@ -450,20 +490,39 @@ int pmpc_comm_world(pmpc_ctx *c) { return c->world; }
 
 int pmpc_scp_residual_device(pmpc_ctx *c, size_t xdim, size_t udim, size_t N, size_t M, const double *X, const double *X_prev,
                              const double *U, const double *U_prev, double *out) {
-  HIP_CHECK(hipSetDevice(c->device));
-  launch_scp_residual(X, X_prev, U, U_prev, (long long)M * (long long)N, (int)xdim, (int)udim, out, c->stream);
+  try {
+    HIP_CHECK(hipSetDevice(c->device));
+    launch_scp_residual(X, X_prev, U, U_prev, (long long)M * (long long)N, (int)xdim, (int)udim, out, c->stream);
+    HIP_CHECK(hipGetLastError());
+  } catch (const PmpcHipError &) {
+    return 2;
+  }
   return 0;
 }
 
 int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu) {
-  HIP_CHECK(hipSetDevice(c->device));
-  launch_linearize(model, (int)N, (int)M, x0, X_prev, U_prev, params, f, fx, fu, c->stream);
+  try {
+    HIP_CHECK(hipSetDevice(c->device));
+    launch_linearize(model, (int)N, (int)M, x0, X_prev, U_prev, params, f, fx, fu, c->stream);
+    HIP_CHECK(hipGetLastError());
+  } catch (const PmpcHipError &) {
+    return 2;
+  }
   return 0;
 }
 
 // -------------------------------------------------------------------------------------------------
-static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc);
+static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc);
+static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
+  try {
+    const int st = solve_impl_body(c, p, info, verbose, soc);
+    HIP_CHECK(hipGetLastError());  // a kernel launch that was refused (bad configuration, lost device) is a failed solve
+    return st;
+  } catch (const PmpcHipError &) {
+    return fail_after_error(c, p, info);
+  }
+}
 
 int pmpc_lqp_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
   return solve_impl(c, p, info, verbose, false);
@@ -472,19 +531,22 @@ int pmpc_lsoc_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   return solve_impl(c, p, info, verbose, true);
 }
 
-static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
+static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
   const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
-  const int Nc = p->Nc < 0 ? N : (p->Nc > (long long)N ? N : (int)p->Nc);  // main.jl:127-128
+  const int Nc = p->Nc < 0 ? N : (int)std::min<long long>(p->Nc, (long long)N);  // main.jl:127-128 (Nc > N is refused below)
   const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
   const bool has_slew = p->flags & PMPC_HAS_SLEW, has_slew0 = p->flags & PMPC_HAS_SLEW0;
   const int nc = Nc * u;
   pmpc_info inf;
   memset(&inf, 0, sizeof(inf));
-  if (x <= 0 || u <= 0 || N <= 0 || M <= 0) {
+  if (x <= 0 || u <= 0 || N <= 0 || M <= 0 || p->Nc > (long long)N) {
+    // Nc > N: the reference indexes U[:, 1:Nc] out of bounds (lqp_utils.jl:17-61 -> BoundsError); here: a failed solve
+    if (p->Nc > (long long)N) fprintf(stderr, "pmpc_hip: consensus horizon Nc = %lld exceeds N = %d\n", p->Nc, N);
     inf.status = 2;
+    if (x > 0 && u > 0 && N > 0 && M > 0 && p->X_out && p->U_out) fill_nan_outputs(c, p);
     if (info) *info = inf;
     return inf.status;
   }
@@ -617,8 +679,8 @@ static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int v
           HIP_CHECK(hipMemcpyAsync(w.su.lo.p, w.cons_lo.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
           HIP_CHECK(hipMemcpyAsync(w.su.hi.p, w.cons_hi.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
         } else {
-          g_rccl.Broadcast(w.su.lo.p, w.su.lo.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
-          g_rccl.Broadcast(w.su.hi.p, w.su.hi.p, (size_t)nc, ncclFloat64, 0, c->comm, s);
+          broadcast(c, w.su.lo.p, (size_t)nc, ncclFloat64, 0);
+          broadcast(c, w.su.hi.p, (size_t)nc, ncclFloat64, 0);
           w.cons_lo.ensure((size_t)nc * D8); w.cons_hi.ensure((size_t)nc * D8);
           HIP_CHECK(hipMemcpyAsync(w.cons_lo.p, w.su.lo.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
           HIP_CHECK(hipMemcpyAsync(w.cons_hi.p, w.su.hi.p, (size_t)nc * D8, hipMemcpyDeviceToDevice, s));
@@ -1169,7 +1231,15 @@ int pmpc_particle_costs_device(pmpc_ctx *c, const pmpc_problem *p, const double 
   return 0;
 }
 
+static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose);
 int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose) {
+  try {
+    return lcone_body(c, p, smooth_alpha, info, verbose);
+  } catch (const PmpcHipError &) {
+    return fail_after_error(c, p, info);
+  }
+}
+static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose) {
   HIP_CHECK(hipSetDevice(c->device));
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
@@ -1199,6 +1269,11 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
     HIP_CHECK(hipStreamSynchronize(s));
     if (cnt[0] != -cnt[1]) {
       fprintf(stderr, "pmpc_hip: pmpc_lcone_solve_device needs the same number of particles on every rank\n");
+      fill_nan_outputs(c, p);
+      if (info) {
+        memset(info, 0, sizeof(*info));
+        info->status = 2;
+      }
       return 2;
     }
   }
@@ -1258,25 +1333,38 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
   }
   int st = solve_with(rw);  // uniform weights: the QP optimum ranks the particles
   if (st != 0) return finish(st);
-  std::vector<size_t> low, low_new, low_prev;
+  // fixed-point iteration on the WEIGHT assignment the ranking implies (the order inside the floor-weight group is irrelevant)
+  std::vector<size_t> low;
+  std::vector<double> rw1(M), rw2(M), rw_prev;
   cheapest(low);
+  rank_weights(low, rw1);
   bool settled = false;
   for (int it = 0; it < 12 && !settled; it++) {
-    rank_weights(low, rw);
+    rw = rw1;
     st = solve_with(rw);
     if (st != 0) return finish(st);
-    cheapest(low_new);
-    if (verbose) printf("pmpc_hip: cone outer %d  threshold particle %zu -> %zu  J_thr %.9e\n", it + 1, low.back(), low_new.back(), J[low_new.back()]);
-    if (low_new == low) { settled = true; break; }
-    if (mstar == 1 && !low_prev.empty() && low_new == low_prev) {
-      // 2-cycle a <-> b: the optimum sits on the kink J_a = J_b; split the 2 eps M deficit theta : (1 - theta)
-      const size_t a_ = low[0], b_ = low_new[0];
-      double lo = 0.0, hi = 1.0;  // theta = 1: a fully down-weighted (then J_a > J_b), theta = 0: b
+    const size_t thr_old = low.back();
+    cheapest(low);
+    rank_weights(low, rw2);
+    if (verbose) printf("pmpc_hip: cone outer %d  threshold particle %zu -> %zu  J_thr %.9e\n", it + 1, thr_old, low.back(), J[low.back()]);
+    if (rw2 == rw1) { settled = true; break; }
+    if (!rw_prev.empty() && rw2 == rw_prev) {
+      // 2-cycle between two rankings: the optimum sits on a kink J_a = J_b between the particles a, b whose weights differ
+      // most between the two assignments; on the segment rw(theta) = theta rw1 + (1 - theta) rw2 the gap J_a - J_b is
+      // monotone in theta (a loses weight as theta grows, so its cost rises relative to b's): bisection.  mstar = 1: a and
+      // b share the deficit 2 eps M; mstar > 1: they swap the threshold / floor weights.
+      size_t a_ = 0, b_ = 0;
+      double da = 0.0, db = 0.0;
+      for (size_t i = 0; i < M; i++) {
+        const double dlt = rw1[i] - rw2[i];
+        if (dlt < da) { da = dlt; a_ = i; }  // lighter under assignment 1
+        if (dlt > db) { db = dlt; b_ = i; }  // lighter under assignment 2
+      }
+      if (!(da < 0.0 && db > 0.0)) break;  // (cannot happen: the assignments differ)
+      double lo = 0.0, hi = 1.0;  // theta = 1: assignment 1 (a light, then J_a > J_b), theta = 0: assignment 2
       for (int bis = 0; bis < 60; bis++) {
         const double th = 0.5 * (lo + hi);
-        std::fill(rw.begin(), rw.end(), w_hi);
-        rw[a_] = w_hi - 2.0 * eps * (double)M * th;
-        rw[b_] = w_hi - 2.0 * eps * (double)M * (1.0 - th);
+        for (size_t i = 0; i < M; i++) rw[i] = th * rw1[i] + (1.0 - th) * rw2[i];
         st = solve_with(rw);
         if (st != 0) return finish(st);
         const double gap = J[a_] - J[b_];
@@ -1284,17 +1372,26 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
         if (std::fabs(gap) <= 1e-11 * std::max(1.0, std::fabs(J[a_]))) break;
         if (gap > 0.0) hi = th; else lo = th;
       }
-      const double jmin = std::min(J[a_], J[b_]);
-      settled = true;
-      for (size_t i = 0; i < M; i++)
-        if (i != a_ && i != b_ && J[i] < jmin - 1e-9 * std::max(1.0, std::fabs(jmin))) settled = false;  // a third particle dips below
+      // accept if the weights are consistent with the ranking at the kink: every particle lighter than the threshold pair is
+      // cheaper than it, every full-weight particle costlier (KKT of the epigraph problem, multipliers lambda_i = w_i)
+      const double jk = 0.5 * (J[a_] + J[b_]), tolj = 1e-9 * std::max(1.0, std::fabs(jk));
+      settled = std::fabs(J[a_] - J[b_]) <= 1e-8 * std::max(1.0, std::fabs(jk));
+      for (size_t i = 0; i < M && settled; i++) {
+        if (i == a_ || i == b_) continue;
+        if (rw[i] >= w_hi && J[i] < jk - tolj) settled = false;  // a full-weight particle dips below the threshold cost
+        if (rw[i] < w_hi && J[i] > jk + tolj) settled = false;   // a down-weighted particle rises above it
+      }
       break;
     }
-    low_prev = low;
-    low = low_new;
+    rw_prev = rw1;
+    rw1 = rw2;
   }
-  if (!settled && verbose) printf("pmpc_hip: cone objective: the threshold set did not settle\n");
-  return finish(settled || mstar > 1 ? 0 : 1);
+  if (!settled) {
+    // no consistent threshold set within the outer iteration limit: a failed solve (NaN outputs), never an unverified iterate
+    if (verbose) printf("pmpc_hip: cone objective: the threshold set did not settle\n");
+    return finish(1);
+  }
+  return finish(0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1328,10 +1425,12 @@ static void upload_all(pmpc_ctx *c, const std::vector<UploadItem> &items) {
       total += (b + 255) & ~(size_t)255;
     }
   if (total > c->pinned_bytes) {
-    if (c->pinned) HIP_CHECK(hipHostFree(c->pinned));
+    c->staged.clear();
+    if (c->pinned) HIP_WARN(hipHostFree(c->pinned));
+    c->pinned = nullptr;
+    c->pinned_bytes = 0;
     HIP_CHECK(hipHostMalloc(&c->pinned, total, hipHostMallocDefault));
     c->pinned_bytes = total;
-    c->staged.clear();
   }
   static const bool reuse_on = !(getenv("PMPC_HOST_REUSE") && atoi(getenv("PMPC_HOST_REUSE")) == 0);
   const std::vector<pmpc_ctx::StagedChunk> &prev = c->staged;
@@ -1339,6 +1438,7 @@ static void upload_all(pmpc_ctx *c, const std::vector<UploadItem> &items) {
   nthreads = std::max(1u, std::min(nthreads ? nthreads : 4u, 16u));
   if (chunks.size() < 4) nthreads = 1;
   std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};  // (an exception must not leave a worker thread)
   auto work = [&]() {
     (void)hipSetDevice(c->device);
     for (size_t k = next++; k < chunks.size(); k = next++) {
@@ -1347,13 +1447,18 @@ static void upload_all(pmpc_ctx *c, const std::vector<UploadItem> &items) {
           memcmp((const char *)c->pinned + ch.off, ch.src, ch.bytes) == 0)
         continue;  // the device copy of the previous call is still current
       memcpy((char *)c->pinned + ch.off, ch.src, ch.bytes);
-      HIP_CHECK(hipMemcpyAsync(ch.dst, (char *)c->pinned + ch.off, ch.bytes, hipMemcpyHostToDevice, c->stream));
+      if (hipMemcpyAsync(ch.dst, (char *)c->pinned + ch.off, ch.bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) failed = 1;
     }
   };
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(work);
   work();
   for (std::thread &t : pool) t.join();
+  if (failed) {
+    c->staged.clear();
+    fprintf(stderr, "pmpc_hip: host -> device upload failed\n");
+    throw PmpcHipError{-1, "hipMemcpyAsync (upload)", __FILE__, __LINE__};
+  }
   c->staged.clear();
   for (const Chunk &ch : chunks) c->staged.push_back({ch.dst, ch.bytes, ch.off});
 }
@@ -1375,6 +1480,7 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
     return;
   }
   pmpc_ctx *c = g_ctx;
+  try {
   HIP_CHECK(hipSetDevice(c->device));
   pmpc_problem p;
   memset(&p, 0, sizeof(p));
@@ -1395,11 +1501,15 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
                    (bool)(p.flags & PMPC_HAS_SLEW), (bool)(p.flags & PMPC_HAS_SLEW0), (bool)(p.flags & PMPC_HAS_SLEW0),
                    true, true};
   std::vector<UploadItem> items;
+  bool realloc_any = false;
   for (int k = 0; k < 19; k++) {
     if (!used[k]) continue;
-    c->stage[k].ensure(cnt[k] * sizeof(double));
+    realloc_any |= c->stage[k].ensure(cnt[k] * sizeof(double));
     if (src[k]) items.push_back({c->stage[k].p, src[k], cnt[k] * sizeof(double)});
   }
+  // a reallocated staging buffer holds nothing, even if the allocator hands the same address out again: the record of what
+  // the previous call uploaded (upload_all's skip test) is void
+  if (realloc_any) c->staged.clear();
   upload_all(c, items);
   // NaN sentinels of the boxes and exact symmetry of the cost blocks: checked on the device (one pass over what was uploaded)
   c->host_flags.ensure(4 * sizeof(int));
@@ -1444,6 +1554,10 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
   if (verbose)
     printf("pmpc_hip: status %d, ipm iterations %d, structured solves %d, fast path %d\n", info.status, info.ipm_iters,
            info.structured_solves, info.fast_path);
+  } catch (const PmpcHipError &) {  // failed HIP call / out of memory: the reference's failure convention, not an abort
+    fail_after_error(c, nullptr, nullptr);
+    fail_out();
+  }
 }
 
 void c_lqp_solve(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc, double *x0,

@@ -72,6 +72,20 @@ class DeviceSolver:
             raise RuntimeError(f"pmpc_comm_init failed ({rc})")
         self.rank, self.world = rank, world
 
+    # ---- stream contract -----------------------------------------------------------------------------
+    # The solver runs on its own non-blocking HIP stream.  By default every entry point orders that stream BEHIND the
+    # caller's current torch stream before it enqueues (inputs produced by torch ops are complete when read) and orders the
+    # caller's current stream behind the solver stream when it returns (outputs can be consumed by torch ops / .cpu()
+    # straight away).  `wait_current_stream=False` drops both edges for callers that stay on `self.stream` themselves
+    # (bench.py's loop: every producer and consumer is a library call on the solver's stream) and `sync()` at the end.
+    def _before(self, on=True):
+        if on:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _after(self, on=True):
+        if on:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
     # ---- solve -----------------------------------------------------------------------------------------
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
@@ -119,10 +133,10 @@ class DeviceSolver:
         cost weights (the reference's `weights` setting, PMPC.jl/src/main.jl:96-112)."""
         prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
-        if wait_current_stream:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._before(wait_current_stream)
         status = self.lib.pmpc_lqp_solve_device(self.h, ctypes.byref(prob), ctypes.byref(info), int(verbose))
         self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
+        self._after(wait_current_stream)
         return X_out, U_out, status
 
     def lcone_solve(self, *, smooth_alpha=float("nan"), verbose=False, wait_current_stream=True, **kw):
@@ -130,10 +144,10 @@ class DeviceSolver:
         every buffer in HBM; same tensor conventions as `lqp_solve`."""
         prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
-        if wait_current_stream:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._before(wait_current_stream)
         status = self.lib.pmpc_lcone_solve_device(self.h, ctypes.byref(prob), float(smooth_alpha), ctypes.byref(info), int(verbose))
         self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
+        self._after(wait_current_stream)
         return X_out, U_out, status
 
     def lsoc_solve(self, *, verbose=False, wait_current_stream=True, **kw):
@@ -143,10 +157,10 @@ class DeviceSolver:
         pyjulia-only `extra_cstrs` (README.md:219-239)."""
         prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
-        if wait_current_stream:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._before(wait_current_stream)
         status = self.lib.pmpc_lsoc_solve_device(self.h, ctypes.byref(prob), ctypes.byref(info), int(verbose))
         self.last_info = {k: getattr(info, k) for k, _ in _lib.PmpcInfo._fields_}
+        self._after(wait_current_stream)
         return X_out, U_out, status
 
     def particle_costs(self, X, U, **kw):
@@ -158,7 +172,7 @@ class DeviceSolver:
         self.sync()
         return J
 
-    def linearize(self, model: int, x0, X_prev, U_prev, params, f=None, fx=None, fu=None):
+    def linearize(self, model: int, x0, X_prev, U_prev, params, f=None, fx=None, fu=None, wait_current_stream=True):
         """f, fx, fu (ABI layout) at X_ = [x0, X_prev[:-1]], U_prev for a built-in model."""
         M, N, x = X_prev.shape
         u = U_prev.shape[-1]
@@ -166,16 +180,20 @@ class DeviceSolver:
         f = torch.empty((M, N, x), dtype=torch.float64, device=dev) if f is None else f
         fx = torch.empty((M, N, x, x), dtype=torch.float64, device=dev) if fx is None else fx
         fu = torch.empty((M, N, u, x), dtype=torch.float64, device=dev) if fu is None else fu
+        self._before(wait_current_stream)
         self.lib.pmpc_linearize_device(self.h, int(model), N, M, _p(x0), _p(X_prev), _p(U_prev), _p(params), _p(f), _p(fx),
                                        _p(fu))
+        self._after(wait_current_stream)
         return f, fx, fu
 
-    def scp_residual(self, X, X_prev, U, U_prev, out=None):
+    def scp_residual(self, X, X_prev, U, U_prev, out=None, wait_current_stream=True):
         """max(max_ij ||X - X_prev||_2, max_ij ||U - U_prev||_2) of pmpc/scp_mpc.py:397-403 as a one-element device tensor
         (one fused pass on the solver's stream; inf if a trajectory holds a NaN)."""
         M, N, x = X.shape
         out = torch.empty((1,), dtype=torch.float64, device=X.device) if out is None else out
+        self._before(wait_current_stream)
         self.lib.pmpc_scp_residual_device(self.h, x, U.shape[-1], N, M, _p(X), _p(X_prev), _p(U), _p(U_prev), _p(out))
+        self._after(wait_current_stream)
         return out
 
     def sync(self):

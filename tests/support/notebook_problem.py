@@ -40,3 +40,78 @@ def check_rows(hist, table):
     late[:13] = False
     late[[29, 30]] = False
     np.testing.assert_allclose(got[late, 2], table[late, 2], rtol=3e-2)
+
+
+# ---- further tables of the reference's own solver stack (tests/golden/make_golden.py: more_notebook_tables) -------------
+TABLES = {
+    # name: (rows compared, obj rtol, resid rtol over those rows, what the table pins)
+    "ref_root_testing_single": ("all", 6e-4, 6e-4, "M=1, slew_rate 1e2, log-barrier smoothing alpha 0.1 (solver ecos)"),
+    "ref_root_testing_consensus": ("all", 6e-4, 2.5e-3, "M=20 consensus Nc=5 (shared controls, eps-anchored particle weights), slew 1e2, log barrier alpha 1"),
+    "ref_logbarrier_tests": ("all", 1e-3, 2e-2, "M=1, N=30, |u| <= 0.2, log barrier alpha 0.1"),
+}
+# tables whose EARLY rows cannot be reproduced by anyone (see check_fixed_point): only row 1 and the fixed point are compared
+FIXED_POINT_TABLES = ("ref_experimental_cpu", "ref_demo_cost_convex", "ref_demo_cost_external")
+
+
+def load_table(name):
+    """(args, kw, solver_settings, table) of one `ref_*.npz` table: the problem the notebook cell defined, in this
+    repository's `scp_solve` call surface."""
+    z = np.load(GOLD.parent / f"{name}.npz")
+    from pmpc_amd import dynamics as dyn
+
+    N, M, xdim, udim = int(z["N"]), int(z["M"]), 4, 2
+    params, eps = z["params"], float(z["car_eps"])
+    p = params[0] if M == 1 else params[:, None, :]  # (3,) or one row per particle, broadcast over the stages
+
+    def f_fx_fu_fn(X, U):
+        return dyn.unicycle(X, U, p, eps=eps)
+
+    u_lim = float(z["u_lim"])
+    Q, R = np.tile(np.eye(xdim), (N, 1, 1)), np.tile(float(z["R_diag"]) * np.eye(udim), (N, 1, 1))
+    x0, X_ref = np.ones(xdim), float(z["x_ref"]) * np.ones((N, xdim))
+    zx, zu = np.zeros((N, xdim)), np.zeros((N, udim))
+    u_l, u_u = -u_lim * np.ones((N, udim)), u_lim * np.ones((N, udim))
+    arrs = [Q, R, x0, X_ref, zu.copy(), zx, zu]
+    if M > 1:
+        arrs = [np.tile(a, (M,) + (1,) * a.ndim) for a in arrs]
+        u_l, u_u = np.tile(u_l, (M, 1, 1)), np.tile(u_u, (M, 1, 1))
+    kw = dict(u_l=u_l, u_u=u_u, reg_x=float(z["reg_x"]), reg_u=float(z["reg_u"]), max_it=len(z["table"]), verbose=False, res_tol=0.0,
+              slew_rate=float(z["slew_rate"]))
+    lc = float(z["lin_cost_xref"])
+    if lc == lc:  # tests/demo_cost_jax.ipynb cell 2: float32 gradient of 1/2 |X - 0.4|^2, no control term
+        kw["lin_cost_fn"] = lambda X, U, *a, **k: ((np.asarray(X, np.float32) - np.float32(lc)).astype(np.float32), None)
+    settings = dict(solver="ecos", smooth_alpha=float(z["smooth_alpha"]))
+    if int(z["Nc"]) >= 0:
+        settings["Nc"] = int(z["Nc"])
+    return (f_fx_fu_fn, *arrs), kw, settings, z["table"]
+
+
+def hist_rows(hist):
+    return np.array([[h["it"], h["obj"], h["resid"], h["reg_x"], h["reg_u"]] for h in hist])
+
+
+def check_table(name, hist, table):
+    """Row-by-row comparison with a table the reference printed (4 significant digits; the residual of late rows is a
+    difference of two ECOS solutions and carries ECOS's own tolerance)."""
+    _, rt_obj, rt_res, _ = TABLES[name]
+    got = hist_rows(hist)
+    assert got.shape == table.shape
+    np.testing.assert_array_equal(got[:, [0, 3, 4]], table[:, [0, 3, 4]])
+    np.testing.assert_allclose(got[:, 1], table[:, 1], rtol=rt_obj)
+    np.testing.assert_allclose(got[:, 2], table[:, 2], rtol=rt_res)
+
+
+def check_fixed_point(name, hist, table):
+    """Tables whose early rows are not reproducible: tests/experimental.ipynb's CPU run starts from a JAX-solver result
+    that is not stored; the two tests/demo_cost_jax.ipynb runs start at U = 0, where the unicycle divides by
+    (u2 + 1e-6)^3 — Jacobian round-off of ~1e-4 that the bang-bang solution (R = 0) amplifies to percent level (the
+    reference's own torch-autograd Jacobians give yet another row 2 than the closed form).  Compared: row 1 (cold runs:
+    fully determined by the data), the objective at the fixed point to the 4 printed digits, and the asymptotic
+    contraction factor of the residual."""
+    got = hist_rows(hist)
+    if name != "ref_experimental_cpu":
+        np.testing.assert_allclose(got[0, 1:3], table[0, 1:3], rtol=6e-4)
+        r_ref = table[-1, 2] / table[-2, 2]
+        r_got = got[len(table) - 1, 2] / got[len(table) - 2, 2]
+        np.testing.assert_allclose(r_got, r_ref, rtol=2e-2)
+    np.testing.assert_allclose(got[-1, 1], table[-1, 1], rtol=5.1e-4 / 1.0)  # 4 printed digits

@@ -164,3 +164,30 @@ def test_device_loop_with_thrust_cones():
     assert (0.3 * U[..., 0] - np.linalg.norm(U[..., 1:3], axis=-1)).min() > -1e-9
     assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9) and np.all(U[:, 0] == U[0:1, 0])
     assert data["hist"][-1]["resid"] < data["hist"][0]["resid"]
+
+
+@pytest.mark.parametrize("name", ["ref_root_testing_single", "ref_root_testing_consensus", "ref_logbarrier_tests"])
+def test_scp_on_gpu_reproduces_reference_tables_on_consensus_slew_and_smoothing(name):
+    """The HIP back end (`c_lcone_solve` through `pmpc_amd.solve`) against the tables the reference's Julia stack printed in
+    tests/root_testing.ipynb (M = 1: slew + log barrier; M = 20: consensus Nc = 5 + slew + log barrier + eps-anchored
+    particle weights) and tests/logbarrier_tests.ipynb — row by row, 4 printed digits (tolerances in notebook_problem)."""
+    import pmpc_amd
+    from tests.support import notebook_problem as nbp
+
+    args, kw, settings, table = nbp.load_table(name)
+    X, U, data = pmpc_amd.solve(*args, solver_settings=settings, **kw)
+    assert X is not None, "solver failed"
+    nbp.check_table(name, data["hist"], table)
+
+
+@pytest.mark.parametrize("name", ["ref_experimental_cpu", "ref_demo_cost_convex", "ref_demo_cost_external"])
+def test_scp_on_gpu_reaches_the_fixed_points_of_the_remaining_reference_tables(name):
+    import pmpc_amd
+    from tests.support import notebook_problem as nbp
+
+    args, kw, settings, table = nbp.load_table(name)
+    if name == "ref_experimental_cpu":
+        kw["max_it"] = 150
+    X, U, data = pmpc_amd.solve(*args, solver_settings=settings, **kw)
+    assert X is not None, "solver failed"
+    nbp.check_fixed_point(name, data["hist"], table)
