@@ -21,32 +21,45 @@ _PLAIN_KEYS = ["solver_settings", "reg_x", "reg_u", "max_it", "res_tol", "verbos
 _OPTIONAL_KEYS = ["lin_cost_fn", "extra_cstrs_fns"]
 
 
+def _array_defaults(N: int, x: int, u: int) -> Dict[str, object]:
+    """Per-particle defaults of the array fields (what pmpc/problem_struct.py:88-102 fills in): identity state cost,
+    0.1 I control cost, everything else zero, no boxes."""
+    zeros = {"x0": (x,), "X_ref": (N, x), "U_ref": (N, u), "X_prev": (N, x), "U_prev": (N, u)}
+    out: Dict[str, object] = {k: np.zeros(shape) for k, shape in zeros.items()}
+    out["Q"] = np.broadcast_to(np.eye(x), (N, x, x)).copy()
+    out["R"] = np.broadcast_to(0.1 * np.eye(u), (N, u, u)).copy()
+    out.update(dict.fromkeys(("u_l", "u_u", "x_l", "x_u")))
+    return out
+
+
+# scalar / option fields and their defaults
+_OPTION_DEFAULTS = dict(reg_x=1.0, reg_u=1.0, max_it=30, res_tol=1e-6, verbose=True, slew_rate=None, P=None)
+_DIM_KEYS = ("N", "xdim", "udim", "M")
+
+
 class Problem(Mapping):
     dim_map = _DIM_MAP
 
     def __init__(self, **kw):
         object.__setattr__(self, "_arrays", {})
         self._dims = self._infer_dims(kw)
-        self.M = kw.get("M", None)
-        N, x, u = self._dims["N"], self._dims["xdim"], self._dims["udim"]
-        # defaults (problem_struct.py:88-102)
-        self._arrays.update(
-            Q=np.tile(np.eye(x), (N, 1, 1)), R=np.tile(0.1 * np.eye(u), (N, 1, 1)), x0=np.zeros(x),
-            X_ref=np.zeros((N, x)), U_ref=np.zeros((N, u)), X_prev=np.zeros((N, x)), U_prev=np.zeros((N, u)),
-            u_l=None, u_u=None, x_l=None, x_u=None)
-        self.solver_settings = dict()
-        self.reg_x, self.reg_u, self.max_it, self.res_tol, self.verbose = 1e0, 1e0, 30, 1e-6, True
-        self.slew_rate = None
-        self.P = None
-        for k, v in kw.items():
-            if k.startswith("_"):
-                warn(f"Cannot set private attribute {k}")
-            elif k not in ("N", "xdim", "udim", "M"):
-                setattr(self, k, v)
-        for k in _DIM_MAP:  # tile the defaults over the particle axis
-            setattr(self, k, self._arrays[k])
-        if not hasattr(self, "Nc"):
-            self.Nc = 0
+        self.M = kw.get("M")
+        self.solver_settings = {}
+        for name, value in _OPTION_DEFAULTS.items():
+            object.__setattr__(self, name, value)
+        # array fields: the caller's value where given, the default otherwise — both go through __setattr__, which checks the
+        # shape against the inferred dimensions and tiles over the particle axis
+        fields = _array_defaults(self._dims["N"], self._dims["xdim"], self._dims["udim"])
+        for name, value in kw.items():
+            if name.startswith("_"):
+                warn(f"Cannot set private attribute {name}")
+            elif name in fields:
+                fields[name] = value
+            elif name not in _DIM_KEYS:
+                setattr(self, name, value)
+        for name in _DIM_MAP:
+            setattr(self, name, fields[name])
+        self.__dict__.setdefault("Nc", 0)
 
     # ---- dimensions ------------------------------------------------------------------------------------
     @staticmethod
@@ -71,7 +84,9 @@ class Problem(Mapping):
     udim = property(lambda self: self._dims["udim"])
 
     def __repr__(self):
-        return f"Problem({self._dims}, id={abs(hash(str(id(self))))})"
+        d = self._dims
+        batch = "" if self.M is None else f"M={self.M}, "
+        return f"Problem({batch}N={d['N']}, xdim={d['xdim']}, udim={d['udim']}) at {id(self):#x}"
 
     # ---- shape-checked, M-tiled array attributes ------------------------------------------------------
     def __setattr__(self, k, v):

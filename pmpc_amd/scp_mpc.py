@@ -138,15 +138,18 @@ def scp_solve(
         assert x0.ndim == 2 and R.ndim == 4 and Q.ndim == 4
     M, N, xdim, udim = Q.shape[:3] + R.shape[-1:]
 
-    X_ref = np.zeros((M, N, xdim)) if X_ref is None else np.array(to_numpy_f64(X_ref))
-    U_ref = np.zeros((M, N, udim)) if U_ref is None else np.array(to_numpy_f64(U_ref))
-    X_prev = np.array(to_numpy_f64(X_prev)) if X_prev is not None else X_ref  # default: X_ref (:313)
-    U_prev = np.array(to_numpy_f64(U_prev)) if U_prev is not None else U_ref
-    X_prev, U_prev = X_prev.reshape((M, N, xdim)), U_prev.reshape((M, N, udim))
-    X_ref, U_ref = X_ref.reshape((M, N, xdim)), U_ref.reshape((M, N, udim))
-    x_l, x_u, u_l, u_u = [np.array(z) if z is not None else np.zeros((0, 0, 0)) for z in (x_l, x_u, u_l, u_u)]
-    slew_rate = slew_rate if slew_rate is None else float(slew_rate)
-    u0_slew = np.array(u0_slew) if u0_slew is not None else None
+    # references default to zero, the previous iterate to the references (pmpc/scp_mpc.py:311-321); everything in (M, N, d)
+    def batch(z, d, fallback):
+        return fallback if z is None else np.array(to_numpy_f64(z)).reshape((M, N, d))
+
+    X_ref, U_ref = batch(X_ref, xdim, np.zeros((M, N, xdim))), batch(U_ref, udim, np.zeros((M, N, udim)))
+    X_prev, U_prev = batch(X_prev, xdim, X_ref), batch(U_prev, udim, U_ref)
+    no_box = np.zeros((0, 0, 0))  # "absent" as the back end understands it (size 0 -> NaN sentinels at the ABI)
+    x_l, x_u, u_l, u_u = (no_box if z is None else np.array(z) for z in (x_l, x_u, u_l, u_u))
+    if slew_rate is not None:
+        slew_rate = float(slew_rate)
+    if u0_slew is not None:
+        u0_slew = np.array(u0_slew)
 
     data: Dict[str, Any] = dict(solver_data=[], hist=[], sol_hist=[])
     field_names = ["it", "elaps", "obj", "resid", "reg_x", "reg_u"]
@@ -171,11 +174,11 @@ def scp_solve(
                         slew_rate=slew_rate, u0_slew=u0_slew, x_l=x_l, x_u=x_u, u_l=u_l, u_u=u_u, Q=Q, R=R,
                         X_ref=X_ref, U_ref=U_ref)
         X_ref_, U_ref_ = _augment_cost(lin_cost_fn, X_prev, U_prev, Q, R, X_ref, U_ref, problems)
-        if extra_cstrs_fns is not None:
-            solver_settings["extra_cstrs"] = tuple(extra_cstrs_fns(X_prev, U_prev, problems))
-        if "extra_cstrs" in solver_settings:
-            solver_settings["extra_cstrs"] = tuple(
-                [(a.tolist() if hasattr(a, "tolist") else a) for a in cstr] for cstr in solver_settings["extra_cstrs"])
+        # user cones: re-evaluated about the current iterate when given as a callback; numpy / scipy members become plain
+        # nested lists, the form the pyjulia transport of the reference needs (:353-361) and the back end here accepts
+        cstrs = solver_settings.get("extra_cstrs") if extra_cstrs_fns is None else extra_cstrs_fns(X_prev, U_prev, problems)
+        if cstrs is not None:
+            solver_settings["extra_cstrs"] = tuple([m.tolist() if hasattr(m, "tolist") else m for m in c] for c in cstrs)
         solver_settings["solver_state"] = solver_state
 
         # -- convex sub-problem (:369-371) -----------------------------------------------------------
