@@ -80,7 +80,8 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                            double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
                            double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
                            double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
-                           long long verbose, double smooth_alpha, unsigned rowmajor);
+                           long long verbose, double smooth_alpha, unsigned rowmajor, long long cone_k);
+/* (cone_k: the reference's `k` setting, see pmpc_problem.cone_k; <= 0 = M) */
 
 /* ---------------------------------------------------------------------------------------------
  * Part 2 — device-resident extension
@@ -134,6 +135,11 @@ typedef struct pmpc_problem {
   const double *soc_W, *soc_w0, *soc_v;
   double soc_v0;
   const double *soc_u_interior;
+  /* cone path only (pmpc_lcone_solve_device): the reference's `k` setting (PMPC.jl/src/main.jl:204-227), the weight
+   * (1 - eps) k of the epigraph offset t in  (1 + eps) sum_i y_i + (1 - eps) k t,  J_i <= y_i + t,  y >= 0.  k = M (the
+   * default, and the only value its C ABI reaches) is the sum of the particle costs up to the eps-anchoring; k < M is a
+   * worst-k objective: only about k (1 - eps) / (1 + eps) costliest particles carry weight.  <= 0 or >= M (all ranks' particles): k = M. */
+  long long cone_k;
 } pmpc_problem;
 
 typedef struct pmpc_info {
@@ -210,6 +216,9 @@ void pmpc_profile_read(pmpc_ctx *ctx, double *ms4, long long *n4);
 /* Factor sweeps of active-set rounds that skip the settled particles are timed in a class of their own (level 2 only) and
  * never enter class 0, whose launches all process every (particle, stage): totals as of the last pmpc_profile_read. */
 void pmpc_profile_read_partial(pmpc_ctx *ctx, double *ms, long long *n);
+/* every launch class as of the last pmpc_profile_read: 0 full factor sweep, 1 vector sweep, 2 forward sweep, 3 consensus
+ * reduce + solve, 4 factor sweeps that skip settled particles, 5 active-set bookkeeping, 6 linearisation, 7 SCP residual */
+void pmpc_profile_read_all(pmpc_ctx *ctx, double *ms, long long *launches, int count);
 
 /* version / build probe used by the loader and the tests */
 const char *pmpc_version(void);

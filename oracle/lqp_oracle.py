@@ -101,7 +101,9 @@ def build_structured_cpu(force: bool = False) -> Path:
 def structured_cpu_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x_l=None, x_u=None, u_l=None,
                             u_u=None, threads=0):
     """The same QP as `lqp_solve_py` (py layout in, py layout out) through oracle/structured_cpu.c: Riccati + condensing +
-    Mehrotra on the boxes, OpenMP over particles.  No slew terms.  Returns X (M,N,x), U (M,N,u), info."""
+    Mehrotra on the boxes, OpenMP over particles, and — control boxes only — one exact Newton step on the active set the
+    interior-point iterate names (`polished`: the answer then agrees with the exact oracle to ~1e-15 instead of the ~1e-6 an
+    interior-point iterate leaves at weakly active boxes).  No slew terms.  Returns X (M,N,x), U (M,N,u), info."""
     global _lib_cpu
     if _lib_cpu is None:
         build_structured_cpu()
@@ -121,7 +123,8 @@ def structured_cpu_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, r
         ctypes.c_int(x), ctypes.c_int(u), ctypes.c_int(N), ctypes.c_int(M), ctypes.c_longlong(int(Nc)), *[_p(a) for a in arrs],
         *[None if b is None else _p(b) for b in bnd], ctypes.c_double(reg_x), ctypes.c_double(reg_u), ctypes.c_int(int(threads)),
         _p(X), _p(U), ctypes.byref(iters))
-    return X, U, dict(status=int(st), iters=int(iters.value), solve_s=time.perf_counter() - t0)
+    it = int(iters.value)
+    return X, U, dict(status=int(st), iters=it % 1000, polished=it >= 1000, solve_s=time.perf_counter() - t0)
 
 
 def _f64(a):
@@ -511,9 +514,11 @@ def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, 
     eps = COST_ANCHOR_EPS
     bmu = 1.0 / smooth_alpha if smooth_alpha == smooth_alpha and smooth_alpha > 0 else 0.0
     M = np.shape(f)[0]
-    if 2 * eps * M >= 1 + eps:
+    k = kw.pop("k", None)
+    k = M if k is None or k <= 0 or k >= M else int(k)
+    if 2 * eps * M >= 1 + eps or k < M:
         return _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=reg_x, reg_u=reg_u, Nc=Nc,
-                                     return_info=return_info, bmu=bmu, **kw)
+                                     return_info=return_info, bmu=bmu, k=k, **kw)
     args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
     ckw = dict(reg_x=reg_x, reg_u=reg_u, slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
 
@@ -555,7 +560,7 @@ def lcone_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, 
     raise RuntimeError("cone oracle: no consistent threshold particle / pair found")
 
 
-def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc, return_info, bmu, w_floor=1e-10, **kw):
+def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc, return_info, bmu, w_floor=1e-10, k=None, **kw):
     """Cone path for M >= (1+eps)/(2 eps) ~ 500 particles (main.jl:204-238, k = M).  KKT conditions of the epigraph problem
     min (1+eps) sum y_i + (1-eps) M t  s.t.  J_i(z) <= y_i + t, y >= 0  with multipliers lambda_i of the cone rows:
     lambda_i = 1+eps where J_i > t, 0 where J_i < t, in between on J_i = t, and sum lambda_i = (1-eps) M; stationarity in z
@@ -570,8 +575,10 @@ def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, 
 
     eps, M = COST_ANCHOR_EPS, np.shape(f)[0]
     hi = 1 + eps
-    mstar = max(1, int(np.ceil(2 * eps * M / hi - 1e-12)))
-    w_thr = hi * mstar - 2 * eps * M
+    k = M if k is None else k  # the `k` setting (main.jl:204-227): sum of the multipliers = (1 - eps) k
+    n_hi = int(np.floor((1 - eps) * k / hi + 1e-12))  # particles at full weight (the costliest ones)
+    mstar = max(1, M - n_hi)
+    w_thr = (1 - eps) * k - hi * n_hi
     args = (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)
     ckw = dict(reg_x=reg_x, reg_u=reg_u, slew_reg=kw.get("slew_reg"), slew_reg0=kw.get("slew_reg0"), slew_um1=kw.get("slew_um1"))
 
@@ -590,8 +597,8 @@ def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, 
         t = float(np.max(J[w < hi])) if np.any(w < hi) else float(np.min(J))
         tol = 1e-9 * max(1.0, abs(t))
         lam = np.where(w <= w_floor, 0.0, w)
-        return dict(sum_lambda=float(abs(np.sum(lam) - (1 - eps) * M)), full_below=float(max(0.0, np.max(t - J[w >= hi], initial=0.0)) / max(1.0, abs(t))),
-                    ok=bool(abs(np.sum(lam) - (1 - eps) * M) <= 1e-9 * M and np.all(J[w >= hi] >= t - tol)))
+        return dict(sum_lambda=float(abs(np.sum(lam) - (1 - eps) * k)), full_below=float(max(0.0, np.max(t - J[w >= hi], initial=0.0)) / max(1.0, abs(t))),
+                    ok=bool(abs(np.sum(lam) - (1 - eps) * k) <= 1e-9 * M and np.all(J[w >= hi] >= t - tol)))
 
     X, U, J, _ = solve(np.full(M, hi))
     w1, w_prev = weights_of(J), None
@@ -618,7 +625,7 @@ def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, 
             others = np.ones(M, bool)
             others[[a, b]] = False
             tol = 1e-9 * max(1.0, abs(jk))
-            ok = abs(np.sum(lam) - (1 - eps) * M) <= 1e-9 * M and np.all(J[others & (w >= hi)] >= jk - tol) and np.all(J[others & (w < hi)] <= jk + tol)
+            ok = abs(np.sum(lam) - (1 - eps) * k) <= 1e-9 * M and np.all(J[others & (w >= hi)] >= jk - tol) and np.all(J[others & (w < hi)] <= jk + tol)
             assert ok, "cone oracle: the kink between two rankings is not a KKT point"
             return (X, U, dict(weights=w, J=J, qp=info, kink=True, theta=th)) if return_info else (X, U)
         w_prev, w1 = w1, w2

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_lqp_solve_host", "pmpc_lcone_solve_host", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
-    "pmpc_scp_residual_device", "pmpc_profile_read_partial",
+    "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all",
 ]
 
 
@@ -35,7 +35,7 @@ class PmpcProblem(ctypes.Structure):
         + [(k, ctypes.c_void_p) for k in ("x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref",
                                           "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out", "weights")]
         + [("barrier_mu", ctypes.c_double), ("soc_q", ctypes.c_size_t), ("soc_W", ctypes.c_void_p), ("soc_w0", ctypes.c_void_p),
-           ("soc_v", ctypes.c_void_p), ("soc_v0", ctypes.c_double), ("soc_u_interior", ctypes.c_void_p)]
+           ("soc_v", ctypes.c_void_p), ("soc_v0", ctypes.c_double), ("soc_u_interior", ctypes.c_void_p), ("cone_k", ctypes.c_longlong)]
     )
 
 
@@ -62,7 +62,7 @@ def load():
     lib.c_lcone_solve.restype = None
     lib.pmpc_lqp_solve_host.argtypes = common + [ctypes.c_uint]
     lib.pmpc_lqp_solve_host.restype = None
-    lib.pmpc_lcone_solve_host.argtypes = common + [dbl, ctypes.c_uint]
+    lib.pmpc_lcone_solve_host.argtypes = common + [dbl, ctypes.c_uint, ll]
     lib.pmpc_lcone_solve_host.restype = None
     lib.pmpc_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.pmpc_create.restype = ctypes.c_int
@@ -100,6 +100,8 @@ def load():
     lib.pmpc_profile_read.restype = None
     lib.pmpc_profile_read_partial.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
     lib.pmpc_profile_read_partial.restype = None
+    lib.pmpc_profile_read_all.argtypes = [vp, c_dp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
+    lib.pmpc_profile_read_all.restype = None
     lib.pmpc_version.argtypes = []
     lib.pmpc_version.restype = ctypes.c_char_p
     _lib = lib

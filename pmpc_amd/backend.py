@@ -71,7 +71,7 @@ def _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu,
 
 
 def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
-          slew_um1, verbose, extra=()):
+          slew_um1, verbose, extra=(), cone_k=None):
     lib = _lib.load()
     xdim, udim, N, M = _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg,
                                      slew_reg0, slew_um1)
@@ -88,9 +88,12 @@ def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, 
             arrs.append(np.asfortranarray(z))
     X_out, U_out = np.empty(xdim * N * M), np.empty(udim * N * M)
     ptr = lambda a: a.ctypes.data_as(_lib.c_dp)
-    if rowmajor:
+    cone_k = int(cone_k) if cone_k is not None else 0
+    if rowmajor or cone_k > 0:
         entry = {"c_lqp_solve": "pmpc_lqp_solve_host", "c_lcone_solve": "pmpc_lcone_solve_host"}[entry]
         extra = tuple(extra[:1]) + (rowmajor,)  # the `solver` string only selects the conic back end upstream
+        if entry == "pmpc_lcone_solve_host":
+            extra = extra + (cone_k,)  # the `k` setting cannot cross the reference's C ABI; the extension entry carries it
     getattr(lib, entry)(ptr(X_out), ptr(U_out), xdim, udim, N, M, int(Nc), *[ptr(a) for a in arrs[:14]], float(reg_x),
                         float(reg_u), *[ptr(a) for a in arrs[14:]], int(verbose), *extra)
     # pmpc/static_backend.py:103
@@ -105,11 +108,12 @@ def lqp_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu,
 
 
 def lcone_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
-                slew_um1, smooth_alpha=1e1, verbose=False, solver="ecos"):
-    """pmpc/static_backend.py:107-191."""
+                slew_um1, smooth_alpha=1e1, verbose=False, solver="ecos", k=None):
+    """pmpc/static_backend.py:107-191.  `k` (the reference's worst-k setting, PMPC.jl/src/main.jl:204-227) is reachable only
+    through pyjulia upstream; here it rides on the extension entry point `pmpc_lcone_solve_host`."""
     extra = (float(smooth_alpha), str(solver).encode())
     return _call("c_lcone_solve", Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
-                 slew_reg, slew_reg0, slew_um1, verbose, extra)
+                 slew_reg, slew_reg0, slew_um1, verbose, extra, cone_k=k)
 
 
 def aff_solve(
@@ -158,6 +162,6 @@ def aff_solve(
     if method == "qp":
         X, U = lqp_solve(*args, verbose=verbose)
     else:
-        X, U = lcone_solve(*args, smooth_alpha, verbose=verbose, solver=solver_settings["solver"])
+        X, U = lcone_solve(*args, smooth_alpha, verbose=verbose, solver=solver_settings["solver"], k=solver_settings.get("k"))
     X_traj = np.concatenate([np.swapaxes(x0, -1, -2)[:, None, :], X], -2)  # static_backend.py:311
     return X_traj, U, dict()

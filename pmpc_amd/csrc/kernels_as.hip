@@ -1,0 +1,654 @@
+// kernels_as.hip — the sweeps of the primal-dual active-set rounds on the control boxes (gfx950 / CDNA4), register-resident
+// MFMA layout of kernels_fast.hip (fast_common.h).  These are the kernels bench.py's SCP loop spends its time in.
+//
+// What a round is (solver.hip, active_set_solve): with a guess of the active set, ONE structured solve from a base point whose
+// held controls sit exactly on their bounds is the exact optimum on that set; the forward sweep tests the KKT signs as it goes,
+// clamps / releases, propagates the clamped step and leaves base + step as the next base point.  Differences from the sweeps of
+// kernels_fast.hip, all of them about memory passes and launches that the rounds do not need:
+//   * no gradient pre-pass: the backward sweep forms  x - x_ref,  reg_x (x - x_prev),  u - u_ref,  reg_u (u - u_prev)  and the
+//     penalty diagonal of the held controls itself, from the base point (a.Xb, a.Ub), the references and the status array;
+//   * the forward sweep reads the base point and writes the NEW base point (absolute states and controls, a.Xo / a.Uo — the
+//     caller's output buffers), so an accepted round needs no copy and a continued round no "base += step" pass;
+//   * DEFECT (first round of a warm start inside an SCP loop): the base point is the linearisation point (X_prev, U_prev)
+//     itself, whose dynamics defect f - X_prev is elementwise and rides through the sweeps (backward s += S r, forward
+//     dx += r): no rollout, and nothing of the base point has to be written before the sweep;
+//   * SKIP (later rounds): particles whose set did not change keep their factors; the wave only refreshes its condensed
+//     consensus gradient, g_i += H_i delta, and leaves;
+//   * every kernel returns at once when *a.done is set: the host enqueues several rounds ahead without reading anything
+//     back, the device decides (k_as_ctl) whether the later ones still have work.
+//
+// Reference semantics: the QP of PMPC.jl/src/lqp_utils.jl:2-393 restricted to an active set (same Newton system as kernels_fast.hip).
+#include <type_traits>
+
+#include "fast_common.h"
+
+#ifndef PMPC_AS_LEAN_WAVES
+#define PMPC_AS_LEAN_WAVES 4  // occupancy the lean backward sweep is compiled for (A/B builds: -DPMPC_AS_LEAN_WAVES=1 lifts the cap)
+#endif
+#ifndef PMPC_AS_DEEP_WAVES
+#define PMPC_AS_DEEP_WAVES 3  // occupancy of the deep-pipeline variant
+#endif
+#ifndef PMPC_AS_DEEP2_MAXM
+#define PMPC_AS_DEEP2_MAXM 0  // particles per GPU up to which the two-stages-ahead variant runs (0: never — at x12 u4 its three
+                              // register sets do not fit 256 registers without spilling, and it lost to the one-stage variant)
+#endif
+#ifndef PMPC_AS_PINGPONG
+#define PMPC_AS_PINGPONG 0    // main loop: two stages per trip, the prefetch register sets swap roles (0: one stage + rotation moves)
+#endif
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// backward (factor) sweep of an active-set round
+// ------------------------------------------------------------------------------------------------
+// Loop structure: the free stages j >= 1 (the bulk of the horizon) run in a branch-free MAIN body, two stages per loop trip
+// with the two prefetch register sets swapping roles (no rotation moves); the consensus stages and stage 0 (no incoming
+// state) go through the general body afterwards.
+// MODE — how far ahead a stage's data is requested:
+//   0 lean   early data (F, R, um, gu, df) one stage ahead, mid / late data (Q, xm, gx, Du) behind the Cholesky phase of the
+//            stage above: <= 128 registers, 4 waves per SIMD (more than 3072 particles per GPU: the waves hide each other's latency)
+//   1 deep   everything one full stage ahead (3 waves per SIMD)
+//   2 deep2  everything TWO stages ahead (2 waves per SIMD): with at most two waves per SIMD — small shards, the few unsettled
+//            particles of the later rounds — a stage is shorter than the HBM latency, and data requested one stage ahead would
+//            pin every stage to that latency
+template <int XD, int UD, int MODE, bool SKIP, bool DEFECT>
+__global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_WAVES : PMPC_AS_LEAN_WAVES)) k_bwd_as(LQArgs a) {
+  typedef Lane<XD, UD> LT;
+  constexpr int KS = LT::KS, XP = LT::XP;
+  constexpr bool PADX = (XD != XP);
+  constexpr long long D8 = sizeof(double);
+  constexpr bool DEEP = MODE != 0, SCHOL = !DEEP;
+  if (a.done && *a.done) return;
+  const int lane = threadIdx.x;
+  const int N = a.N, Nc = a.Nc, i = blockIdx.x;
+  if (SKIP && a.as_settled_in[i]) {
+    // nothing of this particle changed: factors, condensed Hessian H_i and conditional optimum stand; its reduced consensus
+    // gradient follows the consensus step that was applied, g_i += H_i delta (exact: the QP is quadratic).  nc <= 32 here.
+    const int nc = Nc * UD;
+    if (lane < nc) {
+      const double *H = a.Hc_part + (size_t)i * nc * nc;  // symmetric; off-diagonal blocks live in the upper triangle
+      double acc = 0.0;
+      for (int cc = 0; cc < nc; cc++) acc = fma(H[(lane < cc ? lane : cc) + nc * (lane < cc ? cc : lane)], a.as_delta[cc], acc);
+      a.gc_part[(size_t)i * nc + lane] += acc;
+    }
+    return;
+  }
+  const LT L(lane);
+  const int g = L.g, c = L.c;
+  const size_t pbase = (size_t)i * N;
+  const bool own0 = (i == 0 && a.owner);
+  const bool gu = g < UD;
+  const double *Z = a.zeros;
+  const double pwt = a.pw ? a.pw[i] : 1.0;
+  const double regx = pwt * a.reg_x, regu = pwt * a.reg_u;
+  // base point of the round
+  const double *Xb = DEFECT ? a.X_prev : a.Xb, *Ub = DEFECT ? a.U_prev : a.Ub;
+
+  // F = [fx | fu]: per-lane pointer at stage N-1 and per-lane byte stride (0 for lanes that read the zero buffer)
+  const bool fF = L.cxv || L.cu;
+  const double *pF = L.cxv ? a.fx + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0
+                           : (L.cu ? a.fu + (pbase + N - 1) * (XD * UD) + XD * L.cb + L.row0 : Z);
+  const int sF = fF ? -(int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
+  // everything else: UNIFORM stage base (scalar registers, advanced by the scalar unit) + a per-lane constant byte offset.
+  // Lanes without an entry read entry 0 of the stage block (finite data) and are masked by a zero factor or a select.
+  const unsigned lQ = (unsigned)((L.cxv ? XD * L.oc + L.row0 : 0) * D8);
+  const double pwt_x = L.cxv ? pwt : 0.0;  // cost weight on the state columns, zero elsewhere (masks Q)
+  const bool fR = L.cu && gu;
+  const unsigned lR = (unsigned)((fR ? g + UD * L.cb : 0) * D8);
+  const unsigned lxr = (unsigned)(L.row0 * D8), lxc = (unsigned)((L.cxv ? L.oc : 0) * D8);
+  const unsigned lug = (unsigned)((gu ? g : 0) * D8), luc = (unsigned)((L.cu ? L.cb : 0) * D8);
+  const double regx_c = L.cxv ? regx : 0.0, regu_c = L.cu ? regu : 0.0;
+  const bool umask = L.cu && g == L.cb;
+  const bool diag_x = L.cxv && ((c & 3) == g);
+  bool dmask[KS];
+#pragma unroll
+  for (int r = 0; r < KS; r++) dmask[r] = diag_x && (c >> 2) == r;
+  // particle-local bases once (scalar registers); per stage only `stage index * block size` is added on the scalar unit
+  const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
+  const double *Xb_ = ubase(Xb, px), *Xr_ = ubase(a.X_ref, px), *Xp_ = ubase(a.X_prev, px), *f_ = ubase(a.f, px);
+  const double *Ub_ = ubase(Ub, pu), *Ur_ = ubase(a.U_ref, pu), *Up_ = ubase(a.U_prev, pu), *kff_ = ubase(a.kff, pu);
+  const double *act_ = ubase((const double *)a.as_act, pu >> 1);
+  const double *Q_ = ubase(a.Q, (long long)(pbase * (XD * XD)) * D8), *R_ = ubase(a.R, (long long)(pbase * (UD * UD)) * D8);
+  const double *K_ = ubase(a.K, (long long)(pbase * 64) * D8);
+  auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
+  auto uoff = [&](int jj) { return (long long)(jj * (int)(UD * D8)); };
+  auto ld_Q = [&](int jj, double *dst) {  // Q_jj, rows g + 4r of column c (garbage on the control columns: masked by pwt_x)
+    const double *q = ubase(Q_, (long long)(jj * (int)(XD * XD * D8)));
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const bool rv = !PADX || (L.row0 + r < XD);
+      const double v = ldo(q, rv ? lQ + r * 8u : 0u);
+      dst[r] = rv ? v : 0.0;
+    }
+  };
+  auto ld_xm = [&](int jj, double *dst) {  // pw (x - x_ref) of stage jj, row-distributed
+    const double *xb = ubase(Xb_, xoff(jj)), *xr = ubase(Xr_, xoff(jj));
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const bool rv = !PADX || (L.row0 + r < XD);
+      const unsigned o = rv ? lxr + r * 8u : 0u;
+      const double v = pwt * (ldo(xb, o) - ldo(xr, o));
+      dst[r] = rv ? v : 0.0;
+    }
+  };
+  auto ld_gx = [&](int jj) -> double {  // pw reg_x (x - x_prev) on the state columns (the defect base IS x_prev)
+    if (DEFECT) return 0.0;
+    return regx_c * (ldo(ubase(Xb_, xoff(jj)), lxc) - ldo(ubase(Xp_, xoff(jj)), lxc));
+  };
+  auto ld_df = [&](int jj) -> double {  // dynamics defect of the base point on the state columns
+    if (!DEFECT) return 0.0;
+    const double d = ldo(ubase(f_, xoff(jj)), lxc) - ldo(ubase(Xp_, xoff(jj)), lxc);
+    return L.cxv ? d : 0.0;
+  };
+  auto ld_um = [&](int jj) -> double {  // pw (u - u_ref), k-group g (groups >= udim read control 0; R is zero on their lanes)
+    return pwt * (ldo(ubase(Ub_, uoff(jj)), lug) - ldo(ubase(Ur_, uoff(jj)), lug));
+  };
+  auto ld_gu = [&](int jj) -> double {  // pw reg_u (u - u_prev) on the control columns
+    if (DEFECT) return 0.0;
+    return regu_c * (ldo(ubase(Ub_, uoff(jj)), luc) - ldo(ubase(Up_, uoff(jj)), luc));
+  };
+  auto ld_Du = [&](int jj) -> double {  // penalty of a held control, on the diagonal lanes (XP + b, b)
+    const int act = *(const int *)((const char *)ubase(act_, uoff(jj) >> 1) + (luc >> 1));
+    return (umask && act) ? a.as_big : 0.0;
+  };
+  auto ld_R = [&](int jj) -> double {
+    const double v = ldo(ubase(R_, (long long)(jj * (int)(UD * UD * D8))), lR);
+    return fR ? v : 0.0;
+  };
+  const bool frec = (L.cxv || L.cu) && gu;
+  const unsigned lrec = (unsigned)(lane * D8);
+  auto st_rec = [&](int jj, double v) {  // this lane's slot of the stage's factor record: one coalesced 512-byte store
+    *(double *)((char *)ubase(K_, (long long)(jj * (int)(64 * D8))) + lrec) = v;
+  };
+
+  // prefetch register set of one stage: what it needs the moment it starts (F, R, um, gu, df of the stage) and — DEEP — its
+  // mid / late data (Q, xm, gx of the stage BELOW it, its own Du) as well
+  struct Pipe { double F[KS], R, um, gu, df, Q[KS], xm[KS], gx, Du; };
+  int jF = N - 1;  // stage pF points at
+  auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves pF alone)
+    if (jj < jF) { pF = badd(pF, sF); jF = jj; }
+#pragma unroll
+    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? pF[r] : 0.0;
+    q.R = ld_R(jj);
+    q.um = ld_um(jj);
+    q.gu = ld_gu(jj);
+    q.df = ld_df(jj);
+  };
+  auto fetch_late = [&](int jj, int jbelow, Pipe &q) {  // Du of stage jj; Q, xm, gx of stage jbelow (= jj - 1, clamped at 0)
+    q.Du = ld_Du(jj);
+    q.gx = ld_gx(jbelow);
+    ld_Q(jbelow, q.Q);
+    ld_xm(jbelow, q.xm);
+  };
+
+  double S[KS], s_row[KS], s_col;
+  bool bad = false;  // a pivot of some Huu was not positive
+  // ---- terminal: S = Q~_{N-1}, s = g_x,N-1 ---------------------------------------------------------------------
+  {
+    double Q0[KS], xm0[KS], part = 0.0;
+    ld_Q(N - 1, Q0);
+    ld_xm(N - 1, xm0);
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      part = fma(Q0[r], xm0[r], part);
+      S[r] = fma(pwt_x, Q0[r], dmask[r] ? regx : 0.0);
+    }
+    part = grp_allsum(part);
+    s_col = L.cxv ? part + ld_gx(N - 1) : 0.0;
+    col_to_row<KS>(s_col, g, s_row);
+  }
+
+  // one stage.  MAIN: a free stage with j >= 1 (no branches).  Returns nothing; the caller stops after stage 0.
+  auto stage = [&](auto main_tag, const int j, const Pipe &cur, Pipe &nxt) {
+    constexpr bool MAIN = decltype(main_tag)::value;
+    const bool cons = MAIN ? false : j < Nc;
+    const bool below = MAIN ? true : j > 0;  // a stage j - 1 exists
+    double Fr[KS], Qc[KS], xm_row[KS], gx_c, Du_c;
+#pragma unroll
+    for (int r = 0; r < KS; r++) Fr[r] = (!MAIN && j == 0 && L.cxv) ? 0.0 : cur.F[r];  // stage 0 has no incoming state: A~_0 = 0
+    const double Rc = cur.R, um_g = cur.um, df_c = cur.df, gu_c = cur.gu;
+    gx_c = cur.gx; Du_c = cur.Du;
+#pragma unroll
+    for (int r = 0; r < KS; r++) { xm_row[r] = cur.xm[r]; Qc[r] = cur.Q[r]; }
+    // mid / late data of the stage below: DEEP issues it now (a full stage ahead: lowest latency, most registers), the lean
+    // variant behind the Cholesky phase of this stage (its registers are free again by then; the loads still have the rest of
+    // this stage and the head of the next to land — with 4 waves per SIMD interleaved that covers the memory latency)
+    auto late_pf = [&]() { if (below) fetch_late(j - 1, j >= 2 ? j - 2 : 0, nxt); };
+    if (MODE == 1) late_pf();
+    if (MODE != 2 && below) fetch_early(j - 1, nxt);  // (deep2: the caller's ring has requested stage j - 2 already)
+
+    if (DEFECT) {  // x_j = F [x_{j-1}; u_j] + r_j: the cost-to-go gradient seen through the stage is s + S r
+#pragma unroll
+      for (int r = 0; r < KS; r++) s_row[r] += row_allsum(S[r] * df_c);
+    }
+    // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
+    double hp = Rc * um_g;
+#pragma unroll
+    for (int r = 0; r < KS; r++) hp = fma(Fr[r], s_row[r], hp);
+    const double h_col = grp_allsum(hp) + gu_c;
+    double hu[UD];
+#pragma unroll
+    for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
+
+    // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) ------------------------------------------------------
+    v4d H = {0.0, 0.0, 0.0, 0.0};
+    double p2q = 0.0;  // Q_{j-1} xm_{j-1} part of s_{j-1}, formed now: Qc / xm_row are dead before the Cholesky phase (registers)
+    if (below) {
+#pragma unroll
+      for (int r = 0; r < KS; r++) {
+        H[r] = fma(pwt_x, Qc[r], dmask[r] ? regx : 0.0);
+        p2q = fma(Qc[r], xm_row[r], p2q);
+      }
+    }
+    H[KS] = fma(pwt, Rc, (umask ? regu : 0.0) + (cons ? 0.0 : Du_c));
+    v4d G = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
+#pragma unroll
+    for (int r = 0; r < KS; r++) H = mfma(Fr[r], G[r], H);
+
+    if (!DEEP && !MAIN) late_pf();
+    if (!MAIN && cons) {
+      // consensus stage: no minimisation.  Export the condensed gradient block and the diagonal Hessian block Huu; keep
+      // Y_j = H_ux in the factor record (k_cond_fast) and carry P_{j-1} = H_xx on as the cost-to-go
+      double v = H[KS];
+      if (own0) v += Du_c;
+      const int nc = Nc * UD;
+      if (L.cu && gu) a.Hc_part[(size_t)i * nc * nc + (size_t)(j * UD + g) + (size_t)nc * (j * UD + L.cb)] = v;
+      st_rec(j, (L.cxv && gu) ? H[KS] : 0.0);
+#pragma unroll
+      for (int r = 0; r < KS; r++) S[r] = H[r];
+      if (lane < UD) a.gc_part[(size_t)i * (Nc * UD) + j * UD + lane] = pick<UD>(hu, lane);
+      if (j == 0) return;
+      const double p2 = grp_allsum(p2q);
+      s_col = L.cxv ? h_col + p2 + gx_c : 0.0;
+      col_to_row<KS>(s_col, g, s_row);
+      return;
+    }
+
+    // ---- Cholesky of Huu on lane-uniform values (readlane broadcast of the lower triangle) --------
+    double Lc[UD][UD], Ld[UD], col[UD];
+#pragma unroll
+    for (int q = 0; q < UD; q++) {
+#pragma unroll
+      for (int pp = q; pp < UD; pp++) {
+        double v = readlane_d(H[KS], (XP + q) + 16 * pp);  // Huu[pp][q]
+#pragma unroll
+        for (int k = 0; k < q; k++) v -= Lc[pp][k] * Lc[q][k];
+        // (the factor is lane-uniform: parked in scalar registers when SCHOL is set, which frees 2 * (u + u (u-1) / 2) vector
+        // registers during the substitution phase — the difference between 3 and 4 waves per SIMD for the lean variant)
+        if (pp == q) {
+          bad |= !(v > 0.0);  // (reported once, behind the sweep: no branch inside the stage)
+          Ld[q] = SCHOL ? rfl_d(rsqrt_d(v)) : rsqrt_d(v);
+        } else {
+          Lc[pp][q] = SCHOL ? rfl_d(v * Ld[q]) : v * Ld[q];
+        }
+      }
+    }
+    // ---- gather the control rows column-wise and substitute in-lane: state columns give K[:, c], the control columns
+    //      get unit right-hand sides and give Huu^-1[:, c - XP] -------------------------------------------------
+    double rows4[4];
+    grp_gather(H[KS], rows4);
+#pragma unroll
+    for (int k = 0; k < UD; k++) col[k] = L.cu ? (L.cb == k ? 1.0 : 0.0) : rows4[k];
+    chol_solve<UD>(Lc, Ld, col);
+    const double Kg = pick<UD>(col, g);
+    const double rec = frec ? Kg : 0.0;
+    v4d Sn = mfma(H[KS], (L.cxv && gu) ? -Kg : 0.0, H);  // S' = Hxx - Hxu K
+#pragma unroll
+    for (int r = 0; r < KS; r++) S[r] = Sn[r];
+    st_rec(j, rec);
+    if (!DEEP && MAIN) {
+      __builtin_amdgcn_sched_barrier(0);  // (keep the loads HERE: hoisted above the Cholesky phase they cost the 4th wave per SIMD)
+      late_pf();
+    }
+    const double Kreg = L.cxv ? rec : 0.0;
+    // ---- feed-forward k = Huu^-1 hu: the control quad of k-group g holds row g of Huu^-1 ---------------
+    const double hug = pick<UD>(hu, g);
+    double kq = L.cu ? rec * pick<UD>(hu, L.cb) : 0.0;
+    kq += dpp_d<0xB1>(kq);
+    kq += dpp_d<0x4E>(kq);
+    if (c == XP && gu) *(double *)((char *)ubase(kff_, uoff(j)) + lug) = kq;
+    if (!MAIN && j == 0) return;
+    // ---- s_{j-1} = h_x - K' hu + g_x,j-1 -------------------------------------------------------------
+    const double red2 = grp_allsum(fma(-Kreg, hug, p2q));
+    s_col = L.cxv ? h_col + red2 + gx_c : 0.0;
+    col_to_row<KS>(s_col, g, s_row);
+  };
+
+  const int jmin = Nc > 1 ? Nc : 1;  // the MAIN body covers the free stages N-1 .. jmin
+  int j = N - 1;
+  if (MODE == 2) {
+    // three register sets in a ring, three stages per trip (static roles: no moves)
+    Pipe P0, P1, P2;
+    auto fetch = [&](int jj, Pipe &q) {  // everything stage jj needs (jj clamped at 0: the last stages re-read stage 0, no branch)
+      const int k = jj > 0 ? jj : 0;
+      fetch_early(k, q);
+      fetch_late(k, k >= 1 ? k - 1 : 0, q);
+    };
+    fetch(N - 1, P0);
+    fetch(N - 2, P1);
+    for (; j - 2 >= jmin; j -= 3) {
+      fetch(j - 2, P2);
+      stage(std::true_type{}, j, P0, P0);
+      __builtin_amdgcn_sched_barrier(0);  // (no instruction motion across stages: overlapped stages do not fit the register file)
+      fetch(j - 3, P0);
+      stage(std::true_type{}, j - 1, P1, P1);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(j - 4, P1);
+      stage(std::true_type{}, j - 2, P2, P2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; j >= 0; j--) {  // the last free stages, the consensus stages, stage 0: ring rotated by moves
+      fetch(j - 2, P2);
+      if (j >= jmin) stage(std::true_type{}, j, P0, P0);
+      else stage(std::false_type{}, j, P0, P0);
+      P0 = P1;
+      P1 = P2;
+    }
+  } else {
+    Pipe A, B;
+    fetch_early(N - 1, A);
+    fetch_late(N - 1, N >= 2 ? N - 2 : 0, A);
+#if PMPC_AS_PINGPONG
+    for (; j - 1 >= jmin; j -= 2) {
+      stage(std::true_type{}, j, A, B);
+      __builtin_amdgcn_sched_barrier(0);  // (no instruction motion across stages: the scheduler would overlap them and spill)
+      stage(std::true_type{}, j - 1, B, A);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    for (; j >= jmin; j--) {
+      stage(std::true_type{}, j, A, B);
+      A = B;
+    }
+#endif
+    if (j >= jmin) {
+      stage(std::true_type{}, j, A, B);
+      A = B;
+      j--;
+    }
+    for (; j >= 0; j--) {
+      stage(std::false_type{}, j, A, B);
+      A = B;
+    }
+  }
+  if (bad && lane == 0) *a.fail = 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward sweep of an active-set round: feedback law on the (clamped) state, KKT sign tests, clamping / release, new
+// base point = base + clamped step (absolute), statuses, feed-forward of a settled particle's next round, counters
+// ------------------------------------------------------------------------------------------------
+// Loop structure as in k_bwd_as: the consensus stages and stage 0 go through the general body, the free stages j >= 1 through
+// a branch-free MAIN body, two per loop trip with the prefetch register sets swapping roles.
+template <int XD, int UD, bool DEFECT>
+__global__ void __launch_bounds__(64) k_fwd_as(LQArgs a) {
+  typedef Lane<XD, UD> LT;
+  constexpr int KS = LT::KS;
+  constexpr bool PADX = (XD != LT::XP);
+  constexpr long long D8 = sizeof(double);
+  if (a.done && *a.done) return;
+  const int lane = threadIdx.x;
+  const LT L(lane);
+  const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
+  const size_t pbase = (size_t)i * N;
+  const bool gu = g < UD;
+  const double *Z = a.zeros;
+  const bool fF = L.cxv || L.cu;
+  const double *pF = L.cxv ? a.fx + pbase * (XD * XD) + XD * L.oc + L.row0
+                           : (L.cu ? a.fu + pbase * (XD * UD) + XD * L.cb + L.row0 : Z);
+  const int sF = fF ? (int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
+  const double *Xb = DEFECT ? a.X_prev : a.Xb, *Ub = DEFECT ? a.U_prev : a.Ub;
+  const double tol_l = a.as_ctl ? a.as_ctl->tol_l : a.as_tol_l;
+  // uniform stage bases + per-lane constant byte offsets (see k_bwd_as)
+  const unsigned lxr = (unsigned)(L.row0 * D8), lug = (unsigned)((gu ? g : 0) * D8), lrec = (unsigned)(lane * D8);
+  const bool fK = L.cxv && gu;
+  const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
+  const double *Xb_ = ubase(Xb, px), *f_ = ubase(a.f, px), *Xo_ = ubase(a.Xo, px);
+  const double *Ub_ = ubase(Ub, pu), *Uo_ = ubase(a.Uo, pu), *kff_ = ubase(a.kff, pu), *lo_ = ubase(a.as_lo, pu), *hi_ = ubase(a.as_hi, pu);
+  const double *act_ = ubase((const double *)a.as_act, pu >> 1), *K_ = ubase(a.K, (long long)(pbase * 64) * D8);
+  auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
+  auto uoff = [&](int jj) { return (long long)(jj * (int)(UD * D8)); };
+  const bool store_x = (c == 0), store_u = (c == 0) && gu;
+  const int src_grp = 16 * (c & 3);
+  auto ld_xrow = [&](const double *arr, int jj, double *dst) {
+    const double *b = ubase(arr, xoff(jj));
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const bool rv = !PADX || (L.row0 + r < XD);
+      const double v = ldo(b, rv ? lxr + r * 8u : 0u);
+      dst[r] = rv ? v : 0.0;
+    }
+  };
+  // what a stage needs when it starts: F, this lane's gain slot, feed-forward, status / box / base value of control g, base state
+  struct Pipe { double F[KS], K, k, lo, hi, ub, xb[KS], df[KS]; int act; };
+  int jF = 0;  // stage pF points at
+  auto fetch = [&](int jj, Pipe &q) {  // called in ascending stage order (a clamped repeat of the last stage leaves pF alone)
+    if (jj > jF) { pF = badd(pF, sF); jF = jj; }
+#pragma unroll
+    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? pF[r] : 0.0;
+    const double kv = ldo(ubase(K_, (long long)(jj * (int)(64 * D8))), lrec);
+    q.K = fK ? kv : 0.0;
+    q.k = ldo(ubase(kff_, uoff(jj)), lug);  // (k-groups >= udim read control 0 and ignore it, here and below)
+    q.act = *(const int *)((const char *)ubase(act_, uoff(jj) >> 1) + (lug >> 1));
+    q.lo = ldo(ubase(lo_, uoff(jj)), lug);
+    q.hi = ldo(ubase(hi_, uoff(jj)), lug);
+    q.ub = ldo(ubase(Ub_, uoff(jj)), lug);
+    ld_xrow(Xb_, jj, q.xb);
+    if (DEFECT) {  // r = f - x_prev
+      double fr[KS];
+      ld_xrow(f_, jj, fr);
+#pragma unroll
+      for (int r = 0; r < KS; r++) q.df[r] = fr[r] - q.xb[r];
+    }
+  };
+
+  double xcol = 0.0;  // dx[oc] on valid state columns
+  int nrel = 0, nadd = 0, nbad = 0;
+  auto stage = [&](auto main_tag, const int j, const Pipe &cur) {
+    constexpr bool MAIN = decltype(main_tag)::value;
+    double Fr[KS];
+#pragma unroll
+    for (int r = 0; r < KS; r++) Fr[r] = (!MAIN && j == 0 && L.cxv) ? 0.0 : cur.F[r];  // A~_0 = 0
+    const int actc = cur.act;
+    const double loc = cur.lo, hic = cur.hi, ubc = cur.ub;
+    // base control of this stage: in the first round of a warm start the caller's U_prev, which must already BE the base point
+    // of the stored set (inside its box, exactly on the bound where held) — else the caller's promise does not hold
+    if (DEFECT) {
+      const double snapped = actc == 1 ? loc : (actc == 2 ? hic : fmin(fmax(ubc, loc), hic));
+      nbad |= (gu && !(snapped == ubc)) ? 1 : 0;  // (also catches an empty box and a NaN)
+    } else {
+      nbad |= (gu && !(loc <= hic)) ? 1 : 0;  // an empty box ends the solve as the reference's does (NaN outputs)
+    }
+    // du[g] in every lane of k-group g: the shared consensus step (identical in every particle, so are the decisions)
+    // resp. the feedback law on the (clamped) state
+    double draw;
+    if (!MAIN && j < Nc) draw = gu ? a.duc[j * UD + g] : 0.0;
+    else draw = -row_allsum(cur.K * xcol) - cur.k;
+    const bool cnt_here = store_u && (MAIN || j >= Nc || i == 0);
+    const bool held = gu && actc != 0;
+    const double lam = actc == 1 ? -a.as_big * draw : a.as_big * draw;  // multiplier of the held side
+    const bool release = held && lam < -tol_l;
+    const double zt = ubc + draw;
+    const bool vlo = gu && !held && zt < loc - a.as_tol_p * fmax(1.0, fabs(loc));
+    const bool vhi = gu && !held && !vlo && zt > hic + a.as_tol_p * fmax(1.0, fabs(hic));
+    const int anew = release ? 0 : (vlo ? 1 : (vhi ? 2 : actc));
+    // held: no step (a released control starts the next round from its bound); a control that would leave its box is clamped
+    // onto the bound and held from now on.  The new base control is exactly the bound on every held control.
+    const double unew = held ? ubc : (vlo ? loc : (vhi ? hic : zt));
+    const double dug = unew - ubc;
+    nbad |= (gu && !(draw == draw)) ? 1 : 0;
+    nrel += (cnt_here && release) ? 1 : 0;
+    nadd += (cnt_here && (vlo || vhi)) ? 1 : 0;
+    const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
+    const double du_c = L.cu ? t : 0.0;
+    if (store_u) {
+      *(double *)((char *)ubase(Uo_, uoff(j)) + lug) = unew;
+      *(int *)((char *)ubase(act_, uoff(j) >> 1) + (lug >> 1)) = anew;
+      // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
+      // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
+      if (MAIN || j >= Nc) *(double *)((char *)ubase(kff_, uoff(j)) + lug) = actc ? -draw : 0.0;
+      else if (i == 0) a.as_delta[j * UD + g] = dug;  // the consensus step as applied (settled particles: g_i += H_i delta)
+    }
+    const double ycol = L.cxv ? xcol : du_c;
+    double xr[KS];
+#pragma unroll
+    for (int r = 0; r < KS; r++) xr[r] = row_allsum(Fr[r] * ycol) + (DEFECT ? cur.df[r] : 0.0);
+    if (store_x) {
+#pragma unroll
+      for (int r = 0; r < KS; r++)
+        if (!PADX || L.row0 + r < XD) *(double *)((char *)ubase(Xo_, xoff(j)) + lxr + r * 8u) = cur.xb[r] + xr[r];
+    }
+    // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2
+    double nx = 0.0;
+#pragma unroll
+    for (int r = 0; r < KS; r++) {
+      const double tt = __shfl(xr[r], src_grp, 64);
+      nx = ((c >> 2) == r) ? tt : nx;
+    }
+    xcol = L.cxv ? nx : 0.0;
+  };
+
+  // Prefetch distance: TWO stages.  With one wave per SIMD (small shards, the later rounds' few unsettled particles) a stage of
+  // this sweep is shorter than the HBM latency, so data requested one stage ahead would still pin every stage to that latency.
+  // Three register sets in a ring; the main loop runs three stages per trip so that their roles are static (no moves).
+  Pipe P0, P1, P2;
+  auto clampN = [&](int jj) { return jj < N ? jj : N - 1; };  // (the last stages re-read the last one: no branch)
+  fetch(0, P0);
+  fetch(clampN(1), P1);
+  const int jmin = Nc > 1 ? Nc : 1;  // MAIN covers the free stages jmin .. N-1
+  int j = 0;
+  for (; j < jmin && j < N; j++) {  // consensus stages / stage 0: general body, ring rotated by moves
+    fetch(clampN(j + 2), P2);
+    stage(std::false_type{}, j, P0);
+    P0 = P1;
+    P1 = P2;
+  }
+  for (; j + 2 < N; j += 3) {
+    fetch(clampN(j + 2), P2);
+    stage(std::true_type{}, j, P0);
+    fetch(clampN(j + 3), P0);
+    stage(std::true_type{}, j + 1, P1);
+    fetch(clampN(j + 4), P1);
+    stage(std::true_type{}, j + 2, P2);
+  }
+  if (j < N) { stage(std::true_type{}, j, P0); j++; }      // (0 .. 2 stages left; their data is already in flight / landed:
+  if (j < N) { stage(std::true_type{}, j, P1); j++; }      //  after a full trip the ring holds stage j in P0 and j + 1 in P1)
+  // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
+  const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
+  if (lane == 0) {
+    a.as_cnt[3 * i + 0] = (int)r;
+    a.as_cnt[3 * i + 1] = (int)d;
+    a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
+    if (a.as_settled_out) a.as_settled_out[i] = (r == 0.0 && d == 0.0 && !(b > 0.0)) ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// round control (one block): particle sums of {released, activated, bad} + the solve's failure flag -> the device-side decision
+// the host used to take after reading them back.  Single rank: called right behind the forward sweep with reduce = 1,
+// decide = 1.  Sharded: reduce = 1 (local counters -> ctl->cnt), all-reduce of ctl->cnt, then decide = 1.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch,
+                                                AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq) {
+  __shared__ int sh[3][256];
+  if (ctl->done) {  // nothing ran in this round: republish (the host may be waiting on this sequence number)
+    if (threadIdx.x == 0 && decide && last_of_batch && mirror) {
+      *mirror = *ctl;
+      __threadfence_system();
+      *(volatile unsigned long long *)mirror_seq = seq;
+    }
+    return;
+  }
+  if (reduce) {
+    int r = 0, d = 0, b = 0;
+    for (int i = threadIdx.x; i < M; i += 256) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
+    sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) {
+        sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+        sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        sh[2][threadIdx.x] |= sh[2][threadIdx.x + o];
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { ctl->cnt[0] = sh[0][0]; ctl->cnt[1] = sh[1][0]; ctl->cnt[2] = sh[2][0]; ctl->cnt[3] = *fail; }
+  }
+  if (threadIdx.x == 0 && decide) {
+    const int rel = ctl->cnt[0], add = ctl->cnt[1], bad = ctl->cnt[2], fl = ctl->cnt[3];
+    const int round = ctl->round;  // rounds completed before this one
+    if (round < 16) { ctl->hist[round][0] = rel; ctl->hist[round][1] = add; }
+    const int changes = rel + add;
+    int done = 0, status = 1;
+    if (bad || fl) { done = 1; status = 2; }
+    else if (changes == 0) { done = 1; status = 0; }
+    else {
+      if (changes * 2 > ctl->last_changes && ++ctl->stalls >= 2) done = 1;  // not contracting: leave it to the interior-point iteration
+      ctl->last_changes = changes;
+      if (round + 1 >= ctl->max_rounds) done = 1;
+    }
+    ctl->round = round + 1;
+    ctl->status = status;
+    // anti-cycling on (nearly) degenerate boxes: the sign tolerance of the multipliers widens tenfold per round after the
+    // fourth, up to 1e-8 of the dual scale
+    const int e = ctl->round - 3 > 0 ? ctl->round - 3 : 0;
+    double tl = 1e-11;
+    for (int k = 0; k < e && tl < 1e-8; k++) tl *= 10.0;
+    ctl->tol_l = ctl->dual_scale * (tl < 1e-8 ? tl : 1e-8);
+    __threadfence();
+    ctl->done = done;
+    if ((done || last_of_batch) && mirror) {
+      *mirror = *ctl;
+      __threadfence_system();
+      *(volatile unsigned long long *)mirror_seq = seq;
+    }
+  }
+}
+
+template <int XD, int UD>
+void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
+  // waves per SIMD this launch brings (1024 SIMDs): <= 2 deep2, <= 3 deep, else lean (see k_bwd_as)
+  static const int m2 = getenv("PMPC_AS_DEEP2_MAXM") ? atoi(getenv("PMPC_AS_DEEP2_MAXM")) : PMPC_AS_DEEP2_MAXM;
+  static const int m1 = getenv("PMPC_AS_DEEP_MAXM") ? atoi(getenv("PMPC_AS_DEEP_MAXM")) : PMPC_AS_DEEP_WAVES * 1024;
+  const int mode = a.M <= m2 ? 2 : (a.M <= m1 ? 1 : 0);
+  const dim3 grd(a.M), blk(64);
+#define PMPC_BWD_AS(SK, DF)                                                                      \
+  do {                                                                                           \
+    if (mode == 2) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, SK, DF>), grd, blk, 0, s, a);         \
+    else if (mode == 1) hipLaunchKernelGGL((k_bwd_as<XD, UD, 1, SK, DF>), grd, blk, 0, s, a);    \
+    else hipLaunchKernelGGL((k_bwd_as<XD, UD, 0, SK, DF>), grd, blk, 0, s, a);                   \
+  } while (0)
+  if (a.defect) PMPC_BWD_AS(false, true);
+  else if (a.as_settled_in) {  // few particles left: the latency regime at every M
+    if (m2 > 0) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, true, false>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_bwd_as<XD, UD, 1, true, false>), grd, blk, 0, s, a);
+  }
+  else PMPC_BWD_AS(false, false);
+#undef PMPC_BWD_AS
+}
+template <int XD, int UD>
+void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
+  if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true>), dim3(a.M), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((k_fwd_as<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a);
+}
+
+}  // namespace
+
+void launch_bwd_as(const LQArgs &a, hipStream_t s) {
+#define X(xd, ud) if (a.x == xd && a.u == ud) { launch_bwd_as_t<xd, ud>(a, s); return; }
+  PMPC_FAST_DIMS(X)
+#undef X
+  abort();
+}
+void launch_fwd_as(const LQArgs &a, hipStream_t s) {
+#define X(xd, ud) if (a.x == xd && a.u == ud) { launch_fwd_as_t<xd, ud>(a, s); return; }
+  PMPC_FAST_DIMS(X)
+#undef X
+  abort();
+}
+void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
+                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(256), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq);
+}

@@ -32,139 +32,9 @@
 // 8/16-byte stores of K, chol(Huu), k cost 25 % of the factor sweep before).  a.kff = feed-forward k.
 //
 // Reference semantics: same Newton system as kernels_generic.hip (PMPC.jl/src/lqp_utils.jl:2-393).
-#include "pmpc_dev.h"
+#include "fast_common.h"
 
 namespace {
-
-typedef double v4d __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ v4d mfma(double a, double b, v4d c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ double readlane_d(double v, int l) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-  // every lane has a valid source for these permutations: no "old" value needed (saves the init moves)
-  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-// sum over the 16 lanes of a DPP row (all lanes get the total): xor1, xor2, half-mirror, mirror
-__device__ __forceinline__ double row_allsum(double v) {
-  v += dpp_d<0xB1>(v);
-  v += dpp_d<0x4E>(v);
-  v += dpp_d<0x141>(v);
-  v += dpp_d<0x140>(v);
-  return v;
-}
-// Cross-row exchanges on the VALU (gfx950 v_permlane32_swap / v_permlane16_swap; semantics checked on
-// hardware, tools/micro/swap_test): with both operands equal to v,
-//   permlane32_swap -> [0] = v of the lane in rows {0,1} at the same position, [1] = same for rows {2,3}
-//   permlane16_swap -> [0] = v of the even row of this row pair,               [1] = v of the odd row
-// Same-box A/B vs ds_bpermute shuffles: factor sweep -4.5 %, vector sweep -6 % at 256 particles (latency-bound).
-__device__ __forceinline__ void swap32_d(double v, double &a, double &b) {
-  auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-  auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-  a = __hiloint2double(hi[0], lo[0]);
-  b = __hiloint2double(hi[1], lo[1]);
-}
-__device__ __forceinline__ void swap16_d(double v, double &a, double &b) {
-  auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-  auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-  a = __hiloint2double(hi[0], lo[0]);
-  b = __hiloint2double(hi[1], lo[1]);
-}
-// sum over the 4 k-groups (lanes c, c+16, c+32, c+48), all lanes get the total
-__device__ __forceinline__ double grp_allsum(double v) {
-  double a, b;
-  swap32_d(v, a, b);
-  v = a + b;
-  swap16_d(v, a, b);
-  return a + b;
-}
-// out[k] = v of lane (c, k): every lane gets the values its column holds in all four k-groups
-__device__ __forceinline__ void grp_gather(double v, double (&out)[4]) {
-  double p01, p23;
-  swap32_d(v, p01, p23);
-  swap16_d(p01, out[0], out[1]);
-  swap16_d(p23, out[2], out[3]);
-}
-// 1/sqrt(d): v_rsq_f64 seed (measured max rel. error 5.1e-8 on gfx950, tools/micro/rsq_test.hip) + ONE Newton
-// step -> 3.8e-15; a second step (3.4e-16) buys nothing for a Cholesky pivot and sits on the critical path
-__device__ __forceinline__ double rsqrt_d(double d) {
-  const double r = __builtin_amdgcn_rsq(d);
-  const double e = fma(-0.5 * d * r, r, 0.5);  // 0.5 (1 - d r^2)
-  return fma(r, e, r);
-}
-__device__ __forceinline__ const double *badd(const double *p, long long bytes) {
-  return (const double *)((const char *)p + bytes);
-}
-__device__ __forceinline__ double ldo(const double *base, unsigned boff) {  // uniform base + 32-bit byte offset
-  return *(const double *)((const char *)base + boff);
-}
-
-// unconditional load from a per-lane VALID address, zeroed by a select (no exec-mask branch);
-// `rv` guards padding rows (only when xdim is not a multiple of 4, where p[r] could leave the block)
-template <bool PADX>
-__device__ __forceinline__ double ldsel(const double *p, bool keep, bool rv) {
-  if (PADX) return (keep && rv) ? *p : 0.0;
-  const double t = *p;
-  return keep ? t : 0.0;
-}
-
-template <int XD, int UD>
-struct Lane {
-  static constexpr int KS = (XD + 3) / 4, XP = 4 * KS;
-  int c, g, oc, cb, row0;
-  bool cxv, cu;
-  __device__ explicit Lane(int lane) {
-    c = lane & 15;
-    g = lane >> 4;
-    oc = (c & 3) * KS + (c >> 2);  // original state index of kernel column c
-    cxv = c < XP && oc < XD;
-    cb = c - XP;
-    cu = cb >= 0 && cb < UD;
-    row0 = KS * g;  // original index of kernel row g + 4r is row0 + r
-  }
-};
-
-// s_row[r] = s_col of the lane that owns kernel column g + 4r (same k-group)
-template <int KS>
-__device__ __forceinline__ void col_to_row(double s_col, int g, double *s_row) {
-#pragma unroll
-  for (int r = 0; r < KS; r++) s_row[r] = __shfl(s_col, (g + 4 * r) + 16 * g, 64);
-}
-
-template <int UD>
-__device__ __forceinline__ double pick(const double (&v)[UD], int k) {
-  double o = v[0];
-#pragma unroll
-  for (int b = 1; b < UD; b++) o = (k == b) ? v[b] : o;
-  return o;
-}
-
-// y = (L L')^-1 y with L given as strict lower part + reciprocal diagonal
-template <int UD>
-__device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const double (&Ld)[UD], double (&y)[UD]) {
-#pragma unroll
-  for (int p = 0; p < UD; p++) {
-    double v = y[p];
-#pragma unroll
-    for (int k = 0; k < p; k++) v -= Lc[p][k] * y[k];
-    y[p] = v * Ld[p];
-  }
-#pragma unroll
-  for (int p = UD - 1; p >= 0; p--) {
-    double v = y[p];
-#pragma unroll
-    for (int k = p + 1; k < UD; k++) v -= Lc[k][p] * y[k];
-    y[p] = v * Ld[p];
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // backward sweep (see kernels_generic.hip for the FACTOR / vector-only protocol)
@@ -178,16 +48,14 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const dou
 // DEEP: also the stage's mid/late data (Q_{j-1}, xm, gx, D) is loaded a full stage ahead — lowest per-stage
 // latency (few particles per GPU) at 144 VGPRs / 3 waves per SIMD; !DEEP issues those at the top of their own stage
 // and fits 4 waves per SIMD (128 VGPRs), which wins once there are > 3 waves per SIMD to run.
-// SKIP (active-set rounds after the first): particles flagged in a.as_settled_in leave at once — a kernel of its own name, so
-// that profiles of the full sweep (the roofline figure) never mix with launches that process a subset of the particles
-// DEFECT: the base point has the dynamics defect a.defect (see LQArgs): s_j += S_j r_j before h = F' s
-template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP, bool SKIP = false, bool DEFECT = false>
+// (the sweeps of the active-set rounds — no gradient pre-pass, settled particles skipped, dynamics defect of a no-rollout warm
+// start — are kernels of their own: kernels_as.hip)
+template <int XD, int UD, bool FACTOR, bool HXB, bool HUB, bool DEEP>
 __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
   constexpr bool PADX = (XD != XP);
   constexpr long long D8 = sizeof(double);
-  if (SKIP && a.as_settled_in[blockIdx.x]) return;  // active-set rounds: nothing of this particle changed
   const int lane = threadIdx.x;
   const LT L(lane);
   const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
@@ -236,11 +104,6 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
   unsigned ou_g = (unsigned)(((pbase + N - 1) * UD + (gu ? g : 0)) * D8);
   unsigned ou_0 = (unsigned)(((pbase + N - 1) * UD) * D8);
   constexpr unsigned SX = XD * D8, SU = UD * D8;
-  // dynamics defect of the base point on the state columns (DEFECT), stage by stage
-  const bool fdf = DEFECT && L.cxv;
-  const double *pdf = fdf ? a.defect + (pbase + N - 1) * XD + L.oc : Z;
-  const int sdf = fdf ? -(int)D8 * XD : 0;
-  double dfn = DEFECT ? *pdf : 0.0;
   double *pRec = a.K + (pbase + N - 1) * 64 + lane;  // factor record of stage N-1, this lane's slot
   const bool frec = (L.cxv || L.cu) && gu;           // lanes whose slot carries a value
 
@@ -304,7 +167,7 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
     double Fr[KS], Qc[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) Fr[r] = Fn[r];
-    const double Rc = Rn, um_g = umn, df_c = dfn;
+    const double Rc = Rn, um_g = umn;
     double gu_c = gun, rec = recn;  // rec: this lane's slot of the stage's factor record
     if (!FACTOR && HUB && cons && !own0) gu_c = 0.0;  // consensus shift counted once, on the owner's particle 0
     if (j == 0) {  // stage 0 has no incoming state: A~_0 = 0
@@ -359,7 +222,6 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       pgu = badd(pgu, sgu);
       gun = *pgu;
       ou_g -= SU;
-      if (DEFECT) { pdf = badd(pdf, sdf); dfn = *pdf; }
       if (FACTOR) {
         pR = badd(pR, sR);
         Rn = *pR;
@@ -370,10 +232,6 @@ __global__ void __launch_bounds__(64) k_bwd_fast(LQArgs a) {
       }
     }
 
-    if (DEFECT) {  // x_j = F [x_{j-1}; u_j] + r_j: the cost-to-go gradient seen through the stage is s + S r
-#pragma unroll
-      for (int r = 0; r < KS; r++) s_row[r] += row_allsum(S[r] * df_c);
-    }
     // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
     double hp = Rc * um_g;
 #pragma unroll
@@ -559,14 +417,7 @@ __global__ void __launch_bounds__(256) k_particle_cost(LQArgs a, const double *X
 // Stage data (F_j, K_j, k_j resp. U_j - U_prev_j, f_j, X_prev_j) is loaded one stage ahead; lanes
 // without an entry read the zero buffer through a zero-stride pointer.
 // ------------------------------------------------------------------------------------------------
-// AS (active-set mode, !ROLLOUT): the sweep also carries out the primal-dual active-set update of the control boxes as it
-// goes — a held control whose multiplier (-/+ big du) is negative is released, a free control that would leave its box is
-// clamped onto the bound and held from now on — and propagates the CLAMPED step, so that base + step is the next
-// dynamics-consistent base point with every held control exactly on its bound (later stages react to the clamped state
-// through their feedback gains, as in a control-limited DDP forward pass).  With no change anywhere the step is the exact
-// optimum on the current set.  Writes the new statuses and per-particle change counters.
-// DEFECT (with AS): the base point's dynamics defect enters the state recursion, dx_j = F [dx_{j-1}; du_j] + r_j
-template <int XD, int UD, bool ROLLOUT, bool AS = false, bool DEFECT = false>
+template <int XD, int UD, bool ROLLOUT>
 __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, double *Xout) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
@@ -611,21 +462,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
   load_row(pF, Fn);
   Kn = *pK;
   kn = *pk;
-  // active-set mode: status, box and base value of control g, per k-group (prefetched like k_j)
-  int actn = 0, nrel = 0, nadd = 0, nbad = 0;
-  double lon = 0.0, hin = 0.0, ubn = 0.0;
-  if (AS) {  // every lane loads (lanes of the k-groups g >= udim read control 0's entries and ignore them): no branch
-    actn = *(const int *)((const char *)a.as_act + (ou_g >> 1));
-    lon = ldo(a.as_lo, ou_g); hin = ldo(a.as_hi, ou_g); ubn = ldo(a.U, ou_g);
-  }
   un = ROLLOUT ? *pu - *pup : 0.0;
-  if (DEFECT) {
-#pragma unroll
-    for (int r = 0; r < KS; r++) {
-      const bool rv = !PADX || (L.row0 + r < XD);
-      fn[r] = rv ? ldo(a.defect, ox_row + (rv ? r * 8u : 0u)) : 0.0;
-    }
-  }
   if (ROLLOUT) {
 #pragma unroll
     for (int r = 0; r < KS; r++) {
@@ -639,8 +476,6 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
 #pragma unroll
     for (int r = 0; r < KS; r++) { Fr[r] = Fn[r]; fr[r] = fn[r]; xpr[r] = xpn[r]; }
     const double Kreg = Kn, kreg = kn, ureg = un;
-    const int actc = actn;
-    const double loc = lon, hic = hin, ubc = ubn;
     if (j == 0) {  // A~_0 = 0
 #pragma unroll
       for (int r = 0; r < KS; r++) Fr[r] = L.cxv ? 0.0 : Fr[r];
@@ -663,17 +498,6 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
         Kn = *pK;
         pk = badd(pk, sk);
         kn = *pk;
-        if (AS) {
-          actn = *(const int *)((const char *)a.as_act + ((ou_g + SU) >> 1));
-          lon = ldo(a.as_lo, ou_g + SU); hin = ldo(a.as_hi, ou_g + SU); ubn = ldo(a.U, ou_g + SU);
-        }
-        if (DEFECT) {
-#pragma unroll
-          for (int r = 0; r < KS; r++) {
-            const bool rv = !PADX || (L.row0 + r < XD);
-            fn[r] = rv ? ldo(a.defect, ox_row + SX + (rv ? r * 8u : 0u)) : 0.0;
-          }
-        }
       }
     }
     double ycol;
@@ -681,38 +505,7 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
       ycol = L.cxv ? xcol : ureg;  // ureg is zero off the control columns
     } else {
       double du_c;
-      if (AS) {
-        // du[g] in every lane of k-group g: the shared consensus step (identical in every particle, so are the decisions)
-        // resp. the feedback law on the (clamped) state
-        double dug;
-        if (j < Nc) dug = gu ? a.duc[j * UD + g] : 0.0;
-        else dug = -row_allsum(Kreg * xcol) - kreg;
-        const bool cnt_here = store_u && (j >= Nc || i == 0);
-        // (selects only: the divergent form of this block cost 35 exec-mask branches per stage)
-        const double draw = dug;
-        const bool held = gu && actc != 0;
-        const double lam = actc == 1 ? -a.as_big * draw : a.as_big * draw;  // multiplier of the held side
-        const bool release = held && lam < -a.as_tol_l;
-        const double zt = ubc + draw;
-        const bool vlo = gu && !held && zt < loc - a.as_tol_p * fmax(1.0, fabs(loc));
-        const bool vhi = gu && !held && !vlo && zt > hic + a.as_tol_p * fmax(1.0, fabs(hic));
-        const int anew = release ? 0 : (vlo ? 1 : (vhi ? 2 : actc));
-        // held: no step (a released control starts the next round from its bound); a control that would leave its box is
-        // clamped onto the bound and held from now on
-        dug = held ? 0.0 : (vlo ? loc - ubc : (vhi ? hic - ubc : draw));
-        nbad |= (gu && !(draw == draw)) ? 1 : 0;
-        nrel += (cnt_here && release) ? 1 : 0;
-        nadd += (cnt_here && (vlo || vhi)) ? 1 : 0;
-        const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
-        du_c = L.cu ? t : 0.0;
-        if (store_u) {
-          *(double *)((char *)a.dU + ou_g) = dug;
-          *(int *)((char *)a.as_act + (ou_g >> 1)) = anew;
-          // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
-          // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
-          if (j >= Nc) *(double *)((char *)a.kff + ou_g) = actc ? -draw : 0.0;
-        }
-      } else if (j < Nc) {
+      if (j < Nc) {
         du_c = *pdc;  // shared consensus step (zero off the control columns)
         pdc = badd(pdc, sdc);
         if (store_u) {
@@ -735,10 +528,6 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
     double xr[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) xr[r] = row_allsum(Fr[r] * ycol);
-    if (DEFECT) {
-#pragma unroll
-      for (int r = 0; r < KS; r++) xr[r] += fr[r];
-    }
     if (ROLLOUT) {
       // X_j = f_j + fx (X_{j-1} - Xp_{j-1}) + fu (U_j - Up_j); the next column state is X_j - X_prev_j
 #pragma unroll
@@ -767,90 +556,8 @@ __global__ void __launch_bounds__(64) k_fwd_fast(LQArgs a, const double *Uin, do
     ox_row += SX;
     ou_g += SU;
   }
-  if (AS) {  // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
-    const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
-    if (lane == 0) {
-      a.as_cnt[3 * i + 0] = (int)r;
-      a.as_cnt[3 * i + 1] = (int)d;
-      a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
-      if (a.as_settled_out) a.as_settled_out[i] = (r == 0.0 && d == 0.0 && !(b > 0.0)) ? 1 : 0;
-    }
-  }
 }
 
-// base point of an active-set round and everything the factor sweep needs at it (see launch_as_prep in pmpc_dev.h)
-__global__ void __launch_bounds__(256) k_as_prep(LQArgs a, int add_step, double *Du, int defect_mode, const double *ubase) {
-  const long long nx = (long long)a.M * a.N * a.x, nu = (long long)a.M * a.N * a.u;
-  const long long stride = (long long)gridDim.x * 256;
-  const long long perx = (long long)a.N * a.x, peru = (long long)a.N * a.u;
-  double *Xb = const_cast<double *>(a.X), *Ub = const_cast<double *>(a.U);
-  for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nx; k += stride) {
-    double X = Xb[k];
-    if (add_step) { X += a.dX[k]; Xb[k] = X; }
-    if (defect_mode) {  // base states = the linearisation point itself; its defect is f - X_prev, no matrix product needed
-      X = a.X_prev[k];
-      Xb[k] = X;
-      const_cast<double *>(a.defect)[k] = a.f[k] - X;
-    }
-    const double pw = a.pw ? a.pw[k / perx] : 1.0;
-    a.xm[k] = pw * (X - a.X_ref[k]);
-    a.xd[k] = pw * a.reg_x * (X - a.X_prev[k]);
-  }
-  for (long long k = blockIdx.x * 256LL + threadIdx.x; k < nu; k += stride) {
-    const int act = a.as_act[k];
-    double U = Ub[k];
-    if (add_step) U += a.dU[k];
-    if (ubase) {  // defect mode: this pass also takes the first base point from the previous solution (k_as_setup's job)
-      const double lo = a.as_lo[k], hi = a.as_hi[k];
-      U = lo > hi ? NAN : fmin(fmax(ubase[k], lo), hi);  // (an empty box ends the solve through the NaN counter)
-    }
-    if (act) U = act == 1 ? a.as_lo[k] : a.as_hi[k];  // exactly on the bound
-    if (defect_mode && U != a.U_prev[k]) *a.fail = 2;  // the base controls are not the linearisation point's: promise broken
-    if (add_step || act || ubase) Ub[k] = U;
-    const double pw = a.pw ? a.pw[k / peru] : 1.0;
-    a.um[k] = pw * (U - a.U_ref[k]);
-    a.ud[k] = pw * a.reg_u * (U - a.U_prev[k]);
-    Du[k] = act ? a.as_big : 0.0;
-  }
-}
-__global__ void __launch_bounds__(256) k_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta,
-                                                      int M, int nc) {
-  const long long idx = blockIdx.x * 256LL + threadIdx.x;
-  if (idx >= (long long)M * nc) return;
-  const int i = (int)(idx / nc), r = (int)(idx % nc);
-  if (!settled[i]) return;
-  const double *H = Hc_part + (size_t)i * nc * nc;  // symmetric; diagonal blocks full, off-diagonal blocks in the upper triangle
-  double acc = 0.0;
-  for (int c = 0; c < nc; c++) acc = fma(H[(r < c ? r : c) + nc * (r < c ? c : r)], delta[c], acc);
-  gc_part[(size_t)i * nc + r] += acc;
-}
-// counters[0..2] = particle sums of {released, activated, NaN seen}, counters[3] = the solve's failure flag; single rank:
-// published straight into host-coherent memory (the host polls `seq`, as for the interior-point scalars)
-__global__ void __launch_bounds__(256) k_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt,
-                                                   unsigned long long *mirror_seq, unsigned long long seq) {
-  __shared__ int sh[3][256];
-  int r = 0, d = 0, b = 0;
-  for (int i = threadIdx.x; i < M; i += 256) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
-  sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) {
-      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
-      sh[2][threadIdx.x] |= sh[2][threadIdx.x + o];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int f = *fail;
-    counters[0] = sh[0][0]; counters[1] = sh[1][0]; counters[2] = sh[2][0]; counters[3] = f;
-    if (mirror_cnt) {
-      mirror_cnt[0] = sh[0][0]; mirror_cnt[1] = sh[1][0]; mirror_cnt[2] = sh[2][0]; mirror_cnt[3] = f;
-      __threadfence_system();
-      *(volatile unsigned long long *)mirror_seq = seq;
-    }
-  }
-}
 // counters[3] <- failure flag (fail != null), and / or publication of counters[0..3] (mirror_cnt != null)
 __global__ void k_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq) {
   if (threadIdx.x == 0) {
@@ -883,6 +590,7 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
   const int lane = threadIdx.x;
   const LT L(lane);
   const int N = a.N, Nc = a.Nc, nc = Nc * UD, i = blockIdx.x, g = L.g, c = L.c;
+  if (a.done && *a.done) return;  // (active-set rounds enqueued ahead: the set has settled)
   if (a.as_settled_in && a.as_settled_in[i]) return;
   const size_t pbase = (size_t)i * N;
   const int t0 = blockIdx.y * COND_TPW;
@@ -939,14 +647,7 @@ void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
   const dim3 grd(a.M), blk(64);
 #define PMPC_BWD(F, XB, UB, DP) hipLaunchKernelGGL((k_bwd_fast<XD, UD, F, XB, UB, DP>), grd, blk, 0, s, a)
 #define PMPC_BWD2(F, XB, UB) do { if (deep) PMPC_BWD(F, XB, UB, true); else PMPC_BWD(F, XB, UB, false); } while (0)
-  if (factor && a.defect && !xb && ub) {  // first round of a warm start with a defective base point (no rollout)
-    if (deep) hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, false, true>), grd, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, false, false, true>), grd, blk, 0, s, a);
-  } else if (factor && a.as_settled_in && !xb && ub) {  // (the active-set rounds run on control boxes only)
-    // few particles are left in these launches (the settled ones leave at once): occupancy is irrelevant, the deeper pipeline
-    // with its lower per-stage latency wins at every M
-    hipLaunchKernelGGL((k_bwd_fast<XD, UD, true, false, true, true, true>), grd, blk, 0, s, a);
-  } else if (factor) {
+  if (factor) {
     if (xb && ub) PMPC_BWD2(true, true, true);
     else if (xb) PMPC_BWD2(true, true, false);
     else if (ub) PMPC_BWD2(true, false, true);
@@ -967,9 +668,7 @@ void launch_cond_t(const LQArgs &a, hipStream_t s) {
 }
 template <int XD, int UD>
 void launch_fwd_t(const LQArgs &a, hipStream_t s) {
-  if (a.as_act && a.defect) hipLaunchKernelGGL((k_fwd_fast<XD, UD, false, true, true>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
-  else if (a.as_act) hipLaunchKernelGGL((k_fwd_fast<XD, UD, false, true>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
-  else hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
+  hipLaunchKernelGGL((k_fwd_fast<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a, (const double *)nullptr, (double *)nullptr);
 }
 template <int XD, int UD>
 void launch_rollout_t(const LQArgs &a, const double *U, double *X, hipStream_t s) {
@@ -977,11 +676,6 @@ void launch_rollout_t(const LQArgs &a, const double *U, double *X, hipStream_t s
 }
 
 }  // namespace
-
-// (xdim, udim) pairs with compiled instances
-#define PMPC_FAST_DIMS(X)                                                                                          \
-  X(12, 4) X(12, 3) X(12, 2) X(10, 4) X(10, 2) X(9, 4) X(9, 3) X(8, 4) X(8, 2) X(7, 3) X(6, 4) X(6, 3) X(6, 2) X(5, 3) \
-  X(5, 2) X(4, 4) X(4, 3) X(4, 2) X(4, 1) X(3, 3) X(3, 2) X(3, 1) X(2, 2) X(2, 1) X(1, 1)
 
 bool lq_fast_supported(const LQArgs &a) {
   if (a.w != 0 || a.any_slew || !a.sym_cost) return false;
@@ -1022,21 +716,6 @@ void launch_grad_prep(const LQArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_grad_prep, dim3((unsigned)b), dim3(256), 0, s, a);
 }
 
-void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode, const double *ubase) {
-  long long n = (long long)a.M * a.N * a.x;
-  long long b = (n + 255) / 256;
-  if (b > 2048) b = 2048;
-  hipLaunchKernelGGL(k_as_prep, dim3((unsigned)b), dim3(256), 0, s, a, add_step, Du, defect_mode, ubase);
-}
-void launch_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta, int M, int nc, hipStream_t s) {
-  if (nc <= 0) return;
-  const long long n = (long long)M * nc;
-  hipLaunchKernelGGL(k_as_gc_update, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gc_part, Hc_part, settled, delta, M, nc);
-}
-void launch_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq,
-                      unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(k_as_reduce, dim3(1), dim3(256), 0, s, cnt_part, M, counters, fail, mirror_cnt, mirror_seq, seq);
-}
 void launch_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s) {
   hipLaunchKernelGGL(k_as_publish, dim3(1), dim3(64), 0, s, counters, fail, mirror_cnt, mirror_seq, seq);
 }

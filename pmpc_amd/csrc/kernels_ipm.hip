@@ -456,8 +456,8 @@ __global__ void __launch_bounds__(TB) k_as_setup(Slab s, int from_ipm, int keep_
     if (!keep_base) ztry[k] = a == 1 ? lo : (a == 2 ? hi : fmin(fmax(z, lo), hi));  // (keep_base: only D changes)
     if (lo > hi) ztry[k] = NAN;  // an empty box: the NaN reaches the counters, the rounds stop and the solve fails as the
                                  // reference's does (NaN outputs, osqp_solver.jl:65-71)
-    s.D[k] = a ? big : 0.0;
-    s.w[k] = 0.0;
+    if (s.D) s.D[k] = a ? big : 0.0;  // (the fast-path rounds read the statuses themselves: no penalty / shift arrays)
+    if (s.w) s.w[k] = 0.0;
   }
 }
 

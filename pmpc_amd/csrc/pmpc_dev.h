@@ -35,6 +35,19 @@ struct PmpcHipError {
       fprintf(stderr, "pmpc_hip: HIP error %s at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
   } while (0)
 
+// Device-resident control block of the active-set rounds (kernels_as.hip, k_as_ctl): the decisions the host used to take
+// after reading the change counters back are taken on the device, so that several rounds can be enqueued ahead.
+struct AsCtl {
+  int done;          // no further round has work: every kernel of a later round returns at once
+  int status;        // 0 accepted (set unchanged: the optimum), 1 not settled (stalled / round limit), 2 numerical failure
+  int round;         // rounds completed
+  int max_rounds, last_changes, stalls;
+  int cnt[4];        // {released, activated, bad (NaN / empty box / broken promise), failure flag} of the last round (all ranks)
+  int hist[16][2];   // per round: released, activated
+  double tol_l;      // sign tolerance of the multipliers for the NEXT round
+  double dual_scale;
+};
+
 // Arguments of the structured LQ kernels (Riccati factor / vector sweeps / forward sweep).
 struct LQArgs {
   int x, u, N, M, Nc;
@@ -80,6 +93,14 @@ struct LQArgs {
   const int *as_settled_in;
   int *as_settled_out;
   double as_big, as_tol_p, as_tol_l;
+  // active-set sweeps of kernels_as.hip: base point in (Xb, Ub) — ignored in the first round of a no-rollout warm start, whose
+  // base is (X_prev, U_prev) —, new base point out (Xo, Uo: may alias Xb, Ub), the consensus step as applied (as_delta, nc
+  // doubles, written by particle 0), the control block (tolerance of the round; null = as_tol_l) and the early-exit flag
+  const double *Xb, *Ub;
+  double *Xo, *Uo;
+  double *as_delta;
+  const AsCtl *as_ctl;
+  const int *done;
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
@@ -147,21 +168,20 @@ void launch_fwd_fast(const LQArgs &a, hipStream_t s);
 void launch_cond_fast(const LQArgs &a, hipStream_t s);  // off-diagonal blocks of the condensed consensus Hessian (Nc > 1)
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_grad_prep(const LQArgs &a, hipStream_t s);
-// active-set rounds on the fast path: base point <- base + last (clamped) step (add_step), held controls exactly on their
-// bounds, Du = big on them, and the gradient pre-pass arrays of the factor sweep at that point (replaces launch_grad_prep)
-// defect_mode (with a.defect set, add_step 0): base states <- X_prev, a.defect <- f - X_prev, and the check that the base
-// controls ARE U_prev (else *a.fail = 2: the caller's promise was wrong, the solve falls back)
-// ubase (defect mode): the previous solution's controls — the pass also snaps them into the boxes (first base point)
-void launch_as_prep(const LQArgs &a, int add_step, double *Du, hipStream_t s, int defect_mode = 0, const double *ubase = nullptr);
-// counters[0..2] = {released, activated, NaN seen} over the particles, counters[3] = *fail; mirror_cnt != null: also published
-// to host-coherent memory with sequence number `seq`
-// settled particles: gc_part[i] += Hc_part[i] * delta (delta = the consensus step applied in the previous round, nc doubles)
-void launch_as_gc_update(double *gc_part, const double *Hc_part, const int *settled, const double *delta, int M, int nc, hipStream_t s);
-void launch_as_reduce(const int *cnt_part, int M, int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq,
-                      unsigned long long seq, hipStream_t s);
+// generic-path active-set rounds: counters[3] <- *fail (fail != null) and / or publication of counters[0..3] (mirror_cnt != null)
 void launch_as_publish(int *counters, const int *fail, int *mirror_cnt, unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s);
 // J[i] = 1/2 z_i' P_i z_i + q_i' z_i + r_i of PMPC.jl/src/qp_utils.jl:60-162 at (X, U) (unweighted), any dims / slew
 void launch_particle_cost(const LQArgs &a, const double *X, const double *U, double *J, hipStream_t s);
+
+// ---- kernels_as.hip -----------------------------------------------------------------------------
+// sweeps of one active-set round on the control boxes (a.as_act etc. set; a.defect != null: first round of a no-rollout warm start;
+// a.as_settled_in != null: skip the settled particles, which only refresh g_i += H_i as_delta)
+void launch_bwd_as(const LQArgs &a, hipStream_t s);
+void launch_fwd_as(const LQArgs &a, hipStream_t s);
+// round control: reduce the per-particle counters into ctl->cnt (+ failure flag) and / or decide (done, status, next tolerance);
+// publishes ctl to the host-coherent mirror with sequence number `seq` when the rounds are over or the batch ends
+void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
+                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_block_transpose(const double *in, double *out, int rows, int cols, long long n, hipStream_t s);

@@ -150,7 +150,9 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
-  DevBuf as_act, as_cnt, as_cntp, as_settled, defect;  // active-set iteration: status per bounded control (int), counters, per-particle counters
+  DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta;  // active-set iteration: status per bounded control (int), counters,
+                                                                 // per-particle counters, settled flags, control block, applied consensus step
+  int as_pred_rounds = 3;  // rounds the last accepted solve took: how many the next one enqueues before it reads anything back
   DevBuf cons_lo, cons_hi;  // sharded runs: the consensus controls' bounds as last broadcast (PMPC_STATIC_CONS_BOUNDS)
   long long cons_key = -1;
   long long xb_block_key = -1;  // shape whose state boxes were found active: no active-set attempts for it
@@ -172,15 +174,18 @@ struct pmpc_ctx {
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
   double partial_ms = 0.0;  // class 4 of the last pmpc_profile_read
   long long partial_n = 0;
-  ProfCat cat[5];  // 0 backward+factor (all particles), 1 backward vector-only, 2 forward, 3 consensus reduce+solve,
-                   // 4 backward+factor of an active-set round that skips the settled particles (never part of the roofline figure)
+  double last_ms[8] = {0};  // every class of the last pmpc_profile_read (pmpc_profile_read_all)
+  long long last_n[8] = {0};
+  ProfCat cat[8];  // 0 backward+factor (all particles), 1 backward vector-only, 2 forward, 3 consensus reduce+solve,
+                   // 4 backward+factor of an active-set round that skips the settled particles (never part of the roofline figure),
+                   // 5 active-set bookkeeping (first base point, round control), 6 on-device linearisation, 7 SCP residual
   int device = 0;
   hipStream_t stream = nullptr;
   Workspace ws;
   IpmScal *sc_host = nullptr;  // host snapshot of the device scalars
   int *fail_host = nullptr;
   // host-coherent mapped mirror the exchange kernel publishes into (zero-copy; the host polls `seq`)
-  struct ScMirror { IpmScal sc; unsigned long long seq; int as_cnt[4]; unsigned long long as_seq; };
+  struct ScMirror { IpmScal sc; unsigned long long seq; int as_cnt[4]; unsigned long long as_seq; AsCtl ctl; };
   ScMirror *mirror = nullptr, *mirror_dev = nullptr;
   unsigned long long seq = 0, as_seq = 0;
   // RCCL
@@ -221,7 +226,7 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
   int k;
   std::pair<hipEvent_t, hipEvent_t> ev;
   bool on;
-  ProfScope(pmpc_ctx *c_, int k_) : c(c_), k(k_), on(c_->prof >= 2 || (c_->prof == 1 && k_ == 0)) {
+  ProfScope(pmpc_ctx *c_, int k_) : c(c_), k(k_), on(c_->prof >= 2 || (c_->prof == 1 && k_ == 0)) {  // (level 1: dominant kernel only)
     if (!on) return;
     ProfCat &pc = c->cat[k];
     if (pc.pool.empty()) {
@@ -289,7 +294,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
   if (fast && factor && !prep_done) launch_grad_prep(a, s);
   {
     ProfScope ps(c, factor ? ((fast && a.as_settled_in) ? 4 : 0) : 1);
-    if (fast) launch_bwd_fast(a, factor, s);
+    if (fast && a.as_act) launch_bwd_as(a, s);  // a round of the active-set iteration (kernels_as.hip)
+    else if (fast) launch_bwd_fast(a, factor, s);
     else launch_bwd_generic(a, factor, s);
   }
   if (nc > 0) {
@@ -313,7 +319,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
     }
   }
   ProfScope ps(c, 2);
-  if (fast) launch_fwd_fast(a, s);
+  if (fast && a.as_act) launch_fwd_as(a, s);
+  else if (fast) launch_fwd_fast(a, s);
   else launch_fwd_generic(a, s);
 }
 
@@ -391,7 +398,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.defect};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -414,7 +421,7 @@ void pmpc_profile_enable(pmpc_ctx *c, int level) { c->prof = level < 0 ? 0 : lev
 // 0 backward+factor, 1 backward vector-only, 2 forward sweep, 3 consensus reduce + dense solve.
 void pmpc_profile_read(pmpc_ctx *c, double *ms4, long long *n4) {
   HIP_WARN(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 5; k++) {
+  for (int k = 0; k < 8; k++) {
     ProfCat &pc = c->cat[k];
     for (auto &ev : pc.pending) {
       float t = 0.f;
@@ -425,10 +432,17 @@ void pmpc_profile_read(pmpc_ctx *c, double *ms4, long long *n4) {
     }
     pc.pending.clear();
     if (k < 4) { ms4[k] = pc.ms; n4[k] = pc.n; }
-    else { c->partial_ms = pc.ms; c->partial_n = pc.n; }
+    else if (k == 4) { c->partial_ms = pc.ms; c->partial_n = pc.n; }
+    c->last_ms[k] = pc.ms;
+    c->last_n[k] = pc.n;
     pc.ms = 0.0;
     pc.n = 0;
   }
+}
+
+// every class as of the last pmpc_profile_read (see pmpc_ctx::cat): ms[count], n[count], count <= 8
+void pmpc_profile_read_all(pmpc_ctx *c, double *ms, long long *n, int count) {
+  for (int k = 0; k < count && k < 8; k++) { ms[k] = c->last_ms[k]; n[k] = c->last_n[k]; }
 }
 
 // class 4 (factor sweeps of active-set rounds that skipped the settled particles) as of the last pmpc_profile_read
@@ -492,6 +506,7 @@ int pmpc_scp_residual_device(pmpc_ctx *c, size_t xdim, size_t udim, size_t N, si
                              const double *U, const double *U_prev, double *out) {
   try {
     HIP_CHECK(hipSetDevice(c->device));
+    ProfScope ps(c, 7);
     launch_scp_residual(X, X_prev, U, U_prev, (long long)M * (long long)N, (int)xdim, (int)udim, out, c->stream);
     HIP_CHECK(hipGetLastError());
   } catch (const PmpcHipError &) {
@@ -504,6 +519,7 @@ int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const doub
                           const double *U_prev, const double *params, double *f, double *fx, double *fu) {
   try {
     HIP_CHECK(hipSetDevice(c->device));
+    ProfScope ps(c, 6);
     launch_linearize(model, (int)N, (int)M, x0, X_prev, U_prev, params, f, fx, fu, c->stream);
     HIP_CHECK(hipGetLastError());
   } catch (const PmpcHipError &) {
@@ -916,8 +932,121 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   const long long as_key = as_key_pre;
   // mode 1: guess from the interior-point iterate in (w.U, slacks, multipliers); mode 0: the stored set, base point = w.U
   // (the previous solution).  Returns 0 accepted (w.X, w.U hold the optimum), 1 not settled, 2 numerical failure.
+  // Fast path: the rounds run on the device's own decisions (k_as_ctl); the host enqueues as many rounds as the previous
+  // solve of this shape took before it reads anything back, every kernel of a round that is no longer needed returns at once.
+  // The base point lives in the caller's output buffers (the forward sweep writes base + step there), so an accepted round
+  // leaves nothing to copy.  Returns 0 accepted, 1 not settled, 2 numerical failure.
+  auto active_set_fast = [&](double dual_scale, int mode, int max_rounds) -> int {
+    const double big = 1e30, tol_p = 1e-13;
+    w.as_act.ensure(nu * sizeof(int)); w.as_cntp.ensure((size_t)M * 3 * sizeof(int)); w.as_settled.ensure((size_t)M * sizeof(int));
+    w.as_ctl.ensure(sizeof(AsCtl)); w.as_delta.ensure((size_t)std::max(nc, 1) * D8);
+    int *act = (int *)w.as_act.p;
+    AsCtl *ctl = (AsCtl *)w.as_ctl.p;
+    LQArgs b = a;
+    b.Dx = b.wx = b.Du = b.wu = nullptr; b.du_full = 0;
+    b.as_act = act; b.as_lo = su.lo; b.as_hi = su.hi; b.as_cnt = (int *)w.as_cntp.p; b.as_big = big; b.as_tol_p = tol_p;
+    b.as_settled_out = (int *)w.as_settled.p; b.as_delta = w.as_delta.d(); b.as_ctl = ctl; b.done = &ctl->done;
+    b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
+    w.as_key = -1;
+    {  // control block of this attempt
+      AsCtl h0;
+      memset(&h0, 0, sizeof(h0));
+      h0.max_rounds = max_rounds; h0.last_changes = 0x7fffffff; h0.dual_scale = dual_scale; h0.tol_l = dual_scale * 1e-11;
+      memcpy((void *)&c->mirror->ctl, &h0, sizeof(h0));  // staged through the host-coherent mirror (no pageable-memory copy)
+      HIP_CHECK(hipMemcpyAsync(ctl, &c->mirror_dev->ctl, sizeof(AsCtl), hipMemcpyDeviceToDevice, s));
+    }
+    // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
+    // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout, nothing
+    // written before the sweep.  The forward sweep verifies that U_prev IS the base point of the stored set.
+    // (consensus horizons Nc <= 1 only: with several consensus stages the condensed gradient of stage j would also need
+    // Y_j d_{j-1}, d = the defect propagated FORWARD through the earlier consensus stages — a term no backward sweep can
+    // form; found by the config-B full-consensus test, which a single accepted round got wrong by 8 %)
+    const bool use_defect = mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && Nc <= 1;
+    if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
+      ProfScope ps(c, 5);
+      Slab st = su;
+      st.z = w.U.d(); st.D = nullptr; st.w = nullptr;
+      launch_as_setup(st, mode, 0, act, p->U_out, big, s);
+      launch_rollout_fast(b, p->U_out, p->X_out, s);
+    }
+    int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
+    AsCtl h;
+    memset(&h, 0, sizeof(h));
+    while (true) {
+      const int batch = std::min(depth, max_rounds - round);
+      for (int k = 0; k < batch; k++) {
+        const int r = round + k;
+        b.defect = (use_defect && r == 0) ? p->f : nullptr;
+        // particles without a status change in the previous round keep their factors, their condensed Hessian H_i and their
+        // conditional optimum: no factor sweep for them — g_i follows the applied consensus step, g_i += H_i delta
+        const bool skip = as_skip_on && r > 0 && nc <= 32;
+        b.as_settled_in = skip ? (const int *)w.as_settled.p : nullptr;
+        structured_solve(c, b, true, true, /*prep_done=*/true);
+        const bool last = k == batch - 1;
+        c->as_seq++;
+        ProfScope ps(c, 5);
+        if (c->multi()) {  // {released, activated, bad, failure}: one sum for all four, then every rank takes the same decision
+          launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s);
+          allreduce(c, ctl->cnt, 4, ncclInt32, ncclSum);
+          launch_as_ctl(ctl, nullptr, M, (const int *)w.fail.p, 0, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
+        } else {
+          launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
+        }
+      }
+      // the control block is published when the rounds are over (done) or at the end of the batch, whichever comes first,
+      // with the sequence number of the round that published it: wait for any of this batch's numbers
+      {
+        const unsigned long long lo_seq = c->as_seq - (unsigned long long)batch + 1, hi_seq = c->as_seq;
+        bool seen = false;
+        for (long long spin = 0; spin < (1LL << 31) && !seen; spin++) {
+          const unsigned long long v = *(volatile unsigned long long *)&c->mirror->as_seq;
+          if (v >= lo_seq && v <= hi_seq) seen = true;
+          else __builtin_ia32_pause();
+        }
+        if (!seen) {
+          HIP_CHECK(hipStreamSynchronize(s));
+          const unsigned long long v = *(volatile unsigned long long *)&c->mirror->as_seq;
+          if (!(v >= lo_seq && v <= hi_seq)) throw PmpcHipError{-1, "active-set control block never published", __FILE__, __LINE__};
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        memcpy(&h, (const void *)&c->mirror->ctl, sizeof(h));
+      }
+      if (verbose)
+        for (int r = round; r < h.round && r < 16; r++)
+          printf("pmpc_hip: active set (%s) round %d: %d released, %d activated\n", mode == 2 ? "cold" : (mode ? "finish" : "warm"), r + 1,
+                 h.hist[r][0], h.hist[r][1]);
+      inf.structured_solves += h.round - round;
+      inf.active_set_rounds += h.round - round;
+      round = h.round;
+      if (h.done || round >= max_rounds) break;
+      depth = 1;
+    }
+    if (verbose && (h.cnt[2] || h.cnt[3])) printf("pmpc_hip: active set: numerical failure / broken promise (bad %d, fail %d)\n", h.cnt[2], h.cnt[3]);
+    if (!h.done) return 1;
+    if (h.status != 0) return h.status;
+    if (has_xb) {  // the candidate's states against their boxes
+      HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
+      Slab sc2 = sx;
+      sc2.z = p->X_out;
+      launch_violation(sc2, w.part_max.d(), s);
+      exchange(c, 1);
+      read_scalars(c);
+      if (*c->fail_host || !(c->sc_host->viol_max <= 1e-13)) {
+        if (verbose) printf("pmpc_hip: active set settled but a state box is violated by %.3e: interior-point path\n", c->sc_host->viol_max);
+        w.xb_block_key = as_key;
+        return 1;
+      }
+    }
+    HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_out, nu * D8, hipMemcpyDeviceToDevice, s));  // the next solve's warm start (non-SCP callers)
+    outputs_written = true;
+    w.as_key = as_key;  // the stored set (+ w.U) start the next solve of this shape
+    w.as_scale = dual_scale;
+    if (mode == 0) w.as_pred_rounds = round;
+    return 0;
+  };
   auto active_set_solve = [&](double dual_scale, int mode, int max_rounds) -> int {
-    // `big` never meets a normal-sized term in a sum (the penalty's target is a ZERO step), so it only has to dwarf every
+    if (fast) return active_set_fast(dual_scale, mode, max_rounds);
+    // generic kernels: a check pass + rollout per round, decisions on the host.  `big` never meets a normal-sized term in a sum (the penalty's target is a ZERO step), so it only has to dwarf every
     // H_uu entry: gains, H_uu^-1 and the step of a held control come out ~1e-30 relative and -big du_b is its multiplier
     const double big = 1e30, tol_p = 1e-13;
     w.as_act.ensure(nu * sizeof(int)); w.as_cnt.ensure(4 * sizeof(int) + 8);
@@ -928,47 +1057,13 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     b.X = Xtry; b.U = Utry; b.Dx = b.wx = nullptr; b.Du = su.D; b.wu = su.w; b.dX = w.dX.d(); b.dU = w.dU.d();
     Slab st = su;
     st.z = w.U.d(); st.dz = w.dU.d(); st.dz2 = nullptr;
-    if (fast) {
-      w.as_cntp.ensure((size_t)M * 3 * sizeof(int));
-      HIP_CHECK(hipMemsetAsync(cnt, 0, 4 * sizeof(int) + 8, s));
-      b.as_act = act; b.as_lo = su.lo; b.as_hi = su.hi; b.as_cnt = (int *)w.as_cntp.p; b.as_big = big; b.as_tol_p = tol_p;
-      w.as_settled.ensure((size_t)M * sizeof(int));
-      b.as_settled_out = (int *)w.as_settled.p;
-    }
     int last_add = 1, last_changes = 0x7fffffff, stalls = 0;
     w.as_key = -1;
     for (int round = 0; round < max_rounds; round++) {
       // anti-cycling on (nearly) degenerate boxes — a control at its bound with a multiplier of a few ulps flips for ever —:
       // the sign tolerance of the multipliers widens tenfold per round after the fourth, up to 1e-8 of the dual scale
       const double tol_l = dual_scale * std::min(1e-8, 1e-11 * std::pow(10.0, std::max(0, round - 3)));
-      if (fast) {
-        // fast path: the forward sweep itself clamps, tests the held controls' multipliers and propagates the clamped step
-        // (k_fwd_fast<AS>), so base + step is the next round's base point: no rollout and no check pass after round 1
-        b.as_tol_l = tol_l;
-        // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
-        // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout
-        const bool use_defect = round == 0 && mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
-        if (round == 0 && !use_defect) {
-          launch_as_setup(st, mode, 0, act, Utry, big, s);
-          launch_rollout_fast(b, Utry, Xtry, s);
-        }
-        if (use_defect) {  // one pass: base point from the previous solution (stored set, boxes), defect, gradient arrays, D
-          w.defect.ensure(nx * D8);
-          b.defect = w.defect.d();
-          launch_as_prep(b, 0, su.D, s, /*defect_mode=*/1, /*ubase=*/w.U.d());
-        } else {
-          b.defect = nullptr;
-          launch_as_prep(b, round > 0, su.D, s);
-        }
-        // particles without a status change in the previous round keep their factors, their condensed Hessian H_i and their
-        // conditional optimum: no factor sweep for them — g_i follows the applied consensus step, g_i += H_i delta
-        const bool skip = as_skip_on && round > 0 && nc <= 32;
-        b.as_settled_in = skip ? (const int *)w.as_settled.p : nullptr;
-        if (skip) launch_as_gc_update(w.gc_part.d(), w.Hc_part.d(), (const int *)w.as_settled.p, w.dU.d(), M, nc, s);
-        structured_solve(c, b, true, true, /*prep_done=*/true);
-        launch_as_reduce((const int *)w.as_cntp.p, M, cnt, (const int *)w.fail.p, c->multi() ? nullptr : c->mirror_dev->as_cnt,
-                         &c->mirror_dev->as_seq, ++c->as_seq, s);
-      } else {
+      {
         // a round that only RELEASED controls keeps its base point (a released control may start from its bound): no new
         // rollout; only D changes
         const bool same_base = round > 0 && last_add == 0;
@@ -989,7 +1084,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       struct { int rel, add, bad, fail; unsigned long long worst; } hc;
       memcpy(&hc, (const void *)c->mirror->as_cnt, 4 * sizeof(int));
       hc.worst = 0;
-      if (verbose && !fast) {  // (diagnostic of the check pass only)
+      if (verbose) {  // (diagnostic of the check pass only)
         HIP_CHECK(hipMemcpyAsync(&hc.worst, worst_dev, 8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
       }
@@ -1286,8 +1381,12 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
   memset(&last, 0, sizeof(last));
   int outer = 0, solves_total = 0, ipm_total = 0;
   // threshold rank of the piecewise-linear epigraph cost in t: the m*-th cheapest particle, m* = ceil(2 eps M / (1+eps))
-  const long long mstar = std::max<long long>(1, (long long)std::ceil(2.0 * eps * (double)M / (1.0 + eps) - 1e-12));
-  const double w_hi = 1.0 + eps, w_thr = (1.0 + eps) * (double)mstar - 2.0 * eps * (double)M, w_floor = 1e-4;
+  // (general k, main.jl:204-227: multipliers lambda_i in [0, 1+eps] of the cone rows sum to (1-eps) k, so the
+  // n_hi = floor((1-eps) k / (1+eps)) costliest particles carry 1+eps, the next one the remainder, the rest nothing)
+  const double kk = (p->cone_k > 0 && p->cone_k < (long long)M) ? (double)p->cone_k : (double)M;
+  const long long n_hi = (long long)std::floor((1.0 - eps) * kk / (1.0 + eps) + 1e-12);
+  const long long mstar = std::max<long long>(1, (long long)M - n_hi);
+  const double w_hi = 1.0 + eps, w_thr = (1.0 - eps) * kk - (1.0 + eps) * (double)n_hi, w_floor = 1e-4;
 
   auto solve_with = [&](const std::vector<double> &rankw) -> int {
     for (size_t i = 0; i < Ml; i++) pw[i] = user[off + i] * rankw[off + i];
@@ -1327,7 +1426,7 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
   };
 
   std::vector<double> rw(M, w_hi);
-  if (M == 1) {  // one particle: weight 1 - eps, same minimiser as the QP
+  if (M == 1) {  // one particle: weight 1 - eps, same minimiser as the QP (k = 1)
     rw[0] = 1.0 - eps;
     return finish(solve_with(rw));
   }
@@ -1467,7 +1566,7 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
                        double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R,
                        double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x,
                        double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, bool cone = false,
-                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN(), unsigned rowmajor = 0) {
+                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN(), unsigned rowmajor = 0, long long cone_k = 0) {
   const size_t nx = xdim * N * M, nu = udim * N * M;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   auto fail_out = [&]() {  // osqp_solver.jl:65-71 convention
@@ -1546,6 +1645,7 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
   pmpc_info info;
   p.weights = nullptr;
   p.barrier_mu = 0.0;
+  p.cone_k = cone_k;
   if (cone) pmpc_lcone_solve_device(c, &p, smooth_alpha, &info, (int)verbose);
   else pmpc_lqp_solve_device(c, &p, &info, (int)verbose);
   HIP_CHECK(hipMemcpyAsync(X_out, p.X_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1597,9 +1697,9 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                            double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q,
                            double *R, double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu,
                            double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
-                           long long verbose, double smooth_alpha, unsigned rowmajor) {
+                           long long verbose, double smooth_alpha, unsigned rowmajor, long long cone_k) {
   host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
-             reg_u, slew_reg, slew_reg0, slew_um1, verbose, true, smooth_alpha, rowmajor);
+             reg_u, slew_reg, slew_reg0, slew_um1, verbose, true, smooth_alpha, rowmajor, cone_k);
 }
 
 }  // extern "C"

@@ -90,7 +90,7 @@ class DeviceSolver:
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
                  barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, static_cons_bounds=False, prev_is_last_solution=False, soc_W=None, soc_w0=None,
-                 soc_v=None, soc_v0=0.0, soc_u_interior=None):
+                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
@@ -124,7 +124,7 @@ class DeviceSolver:
             X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
             slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu),
             soc_q=0 if soc_W is None else int(soc_W.shape[0]), soc_W=_p(soc_W), soc_w0=_p(soc_w0), soc_v=_p(soc_v), soc_v0=float(soc_v0),
-            soc_u_interior=_p(soc_u_interior))
+            soc_u_interior=_p(soc_u_interior), cone_k=int(cone_k))
         return prob, X_out, U_out
 
     def lqp_solve(self, *, verbose=False, wait_current_stream=True, **kw):
@@ -141,7 +141,8 @@ class DeviceSolver:
 
     def lcone_solve(self, *, smooth_alpha=float("nan"), verbose=False, wait_current_stream=True, **kw):
         """The cone-path objective of `c_lcone_solve` (epsilon-anchored epigraph, PMPC.jl/src/main.jl:194-354) with
-        every buffer in HBM; same tensor conventions as `lqp_solve`."""
+        every buffer in HBM; same tensor conventions as `lqp_solve`.  `cone_k` = the reference's `k` setting (worst-k
+        objective for k < M; not reachable through its C ABI)."""
         prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
         self._before(wait_current_stream)
@@ -213,6 +214,10 @@ class DeviceSolver:
         pms, pn = ctypes.c_double(), ctypes.c_longlong()
         self.lib.pmpc_profile_read_partial(self.h, ctypes.byref(pms), ctypes.byref(pn))
         out["bwd_factor_partial"] = (pms.value, pn.value)  # active-set rounds that skip the settled particles (level 2 only)
+        ms8, n8 = (ctypes.c_double * 8)(), (ctypes.c_longlong * 8)()
+        self.lib.pmpc_profile_read_all(self.h, ms8, n8, 8)
+        for k, name in ((5, "as_bookkeeping"), (6, "linearize"), (7, "scp_residual")):
+            out[name] = (ms8[k], n8[k])
         return out
 
 

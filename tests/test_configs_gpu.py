@@ -53,28 +53,39 @@ def _scp_loop_vs_cpu(solver, prob, model, Nc, steps, cpu_solve, tol=1e-7):
         rounds.append(solver.last_info["active_set_rounds"])
         Xc, Uc = cpu_solve(f.cpu().numpy(), fx.cpu().numpy().swapaxes(-1, -2), fu.cpu().numpy().swapaxes(-1, -2), Xa.cpu().numpy(), Ua.cpu().numpy())
         ex, eu = _rel(Xb.cpu().numpy(), Xc), _rel(Ub.cpu().numpy(), Uc)
+        print(f"  SCP iteration {it + 1}: rel err X {ex:.1e} U {eu:.1e}, rounds {rounds[-1]}", flush=True)
         worst = max(worst, ex, eu)
         assert ex < tol and eu < tol, (it, ex, eu, solver.last_info)
         Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
     return worst, rounds
 
 
-@pytest.mark.parametrize("Nc", [1, -1])
-def test_config_B_unicycle_256_scp_loop_matches_exact_oracle(solver, oracle, Nc):
+@pytest.mark.parametrize("M,Nc,cpu_kind", [(256, 1, "exact"), (256, -1, "structured"), (24, -1, "exact")])
+def test_config_B_unicycle_scp_loop_matches_cpu(solver, oracle, M, Nc, cpu_kind):
     """BASELINE configs[1] as SURVEY.md section 8(d) specifies it: unicycle M=256, N=30, p_i = [1+0.1 xi, 1+0.1 xi, 0.3],
-    x0_i = 1 + 0.05 N(0, I), |u| <= 1, Nc = 1 (primary) and Nc = N (the reference's default), 5 SCP iterations."""
+    x0_i = 1 + 0.05 N(0, I), |u| <= 1, 5 SCP iterations.  Nc = 1 (primary) against the exact sparse oracle; Nc = N (the
+    reference's default) at full size against the structured C solver (the exact oracle needs 4 minutes per solve there: its
+    KKT matrix has a dense 60-column border) and at M = 24 against the exact oracle."""
+    import os
+
     from pmpc_amd import dynamics as dyn
     from pmpc_amd.device import MODEL_UNICYCLE
 
-    prob = dyn.make_unicycle_problem(M=256, N=30, Nc=Nc)
+    prob = dyn.make_unicycle_problem(M=M, N=30, Nc=Nc)
+    threads = min(16, len(os.sched_getaffinity(0)))
 
     def cpu(f, fx, fu, Xp, Up):
-        return oracle.lqp_solve_py(prob["x0"], f, fx, fu, Xp, Up, prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], reg_x=prob["reg_x"],
-                                   reg_u=prob["reg_u"], Nc=Nc, u_l=prob["u_l"], u_u=prob["u_u"])
+        if cpu_kind == "exact":
+            return oracle.lqp_solve_py(prob["x0"], f, fx, fu, Xp, Up, prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], reg_x=prob["reg_x"],
+                                       reg_u=prob["reg_u"], Nc=Nc, u_l=prob["u_l"], u_u=prob["u_u"])
+        X, U, info = oracle.structured_cpu_solve_py(prob["x0"], f, fx, fu, Xp, Up, prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"],
+                                                    prob["reg_x"], prob["reg_u"], Nc=Nc, u_l=prob["u_l"], u_u=prob["u_u"], threads=threads)
+        assert info["status"] == 0, info
+        return X, U
 
     worst, rounds = _scp_loop_vs_cpu(solver, prob, MODEL_UNICYCLE, Nc, 5, cpu)
     assert rounds[-1] >= 1  # the later sub-problems went through the warm-started active-set rounds
-    print(f"config B Nc={Nc}: worst rel err {worst:.2e}, active-set rounds {rounds}")
+    print(f"config B M={M} Nc={Nc}: worst rel err {worst:.2e}, active-set rounds {rounds}")
 
 
 @pytest.mark.parametrize("M", [1024, 4096])

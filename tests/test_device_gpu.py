@@ -360,5 +360,8 @@ def test_bench_line_keeps_the_driver_contract():
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["per_solve"]["frac"] > 0 and set(rf["kernel_ms_per_step"]) >= {"bwd_factor", "fwd", "linearize", "scp_residual"}
+    rp = d["repeats"]
+    assert rp["windows"] == 5 and len(rp["values"]) == 5 and rp["min"] <= rp["median"] <= rp["max"] and abs(rp["values"][0] - d["value"]) < 1e-9 * d["value"]
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and "julia" in cb

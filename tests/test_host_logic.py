@@ -49,8 +49,9 @@ def test_aff_solve_marshalling(monkeypatch):
         xdim, N, M = f.shape
         return np.zeros((M, N, xdim)), np.zeros((M, N, args[6].shape[0]))
 
-    def fake_cone(*args, verbose=False, solver="ecos"):
+    def fake_cone(*args, verbose=False, solver="ecos", k=None):
         seen["cone"] = (args, solver)
+        seen["k"] = k
         f = args[2]
         xdim, N, M = f.shape
         return np.zeros((M, N, xdim)), np.zeros((M, N, args[6].shape[0]))
