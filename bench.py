@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--soc", action="store_true", help="quadrotor only: add the thrust cone ||(tau_x,tau_y)|| <= 0.3 T per stage "
                     "(config E's constraint set, fp64; pmpc_lsoc_solve_device)")
     ap.add_argument("--repeats", type=int, default=4, help="extra repeats of the timed window from a fresh SCP start (spread; outside `value`)")
+    ap.add_argument("--python-loop", action="store_true", help="drive the SCP loop from Python (one linearise / solve / residual call per "
+                    "iteration) instead of pmpc_scp_loop_device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -234,11 +236,27 @@ def main():
                 dist.all_reduce(res, op=dist.ReduceOp.MAX)
         return res
 
+    f2, fx2, fu2 = torch.empty_like(f), torch.empty_like(fx), torch.empty_like(fu)
+
     def run(k, time_solve=False):
         nonlocal Xa, Ua, Xb, Ub
-        for _ in range(k):
-            res = step(Xa, Ua, Xb, Ub, first=len(hist) == 0, time_solve=time_solve)
-            hist.append((res, dict(solver.last_info)))
+        if args.python_loop or time_solve or k == 0:
+            for _ in range(k):
+                res = step(Xa, Ua, Xb, Ub, first=len(hist) == 0, time_solve=time_solve)
+                hist.append((res, dict(solver.last_info)))
+                Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+            return
+        # the SCP loop inside the library (pmpc_scp_loop_device): same kernels, same sequence, no host work between iterations
+        res, infos, last_in_out, done = solver.scp_loop(
+            model, d["params"], k, f2=f2, fx2=fx2, fu2=fu2, first_cold=len(hist) == 0, **soc_kw, f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua,
+            Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
+            lu=d.get("lu"), uu=d.get("uu"), X_out=Xb, U_out=Ub, force_generic=args.force_generic, symmetric_cost=True,
+            wait_current_stream=False)
+        if done != k and not args.ignore_status:
+            raise SystemExit(f"solver failed with status {infos[-1]['status']} in SCP iteration {len(hist) + done + 1}")
+        for i in range(done):
+            hist.append((res[i:i + 1], infos[i]))
+        if last_in_out:
             Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
 
     def window(profile_level, time_solve=False):
@@ -343,6 +361,7 @@ def main():
                                    + f"; timed window = SCP iterations {w0}..{w1} from the cold start X_prev = x0, U_prev = U_ref "
                                      "(the active-set round count falls as the SCP loop converges, so the rate depends on the window)",
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",
+                       "scp_loop": "python (one call per linearise / solve / residual)" if args.python_loop else "library (pmpc_scp_loop_device)",
                        "ipm_iters_per_step": float(np.mean(ipm_its)), "riccati_factorisations_per_step": float(np.mean(solves)),
                        "active_set_rounds_per_step": float(np.mean(as_rounds)),
                        "fast_path": bool(timed[-1][1]["fast_path"]), "final_scp_residual": float(timed[-1][0][0].item()),

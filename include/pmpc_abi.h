@@ -207,6 +207,22 @@ int pmpc_linearize_device(pmpc_ctx *ctx, int model, size_t N, size_t M, const do
 int pmpc_scp_residual_device(pmpc_ctx *ctx, size_t xdim, size_t udim, size_t N, size_t M, const double *X, const double *X_prev,
                              const double *U, const double *U_prev, double *out);
 
+/* `steps` iterations of the SCP loop (pmpc/scp_mpc.py:337-430) for a built-in dynamics model with the host out of the loop
+ * body: per iteration  linearise about (X_prev, U_prev) -> convex sub-problem (pmpc_lqp_solve_device semantics, or
+ * pmpc_lsoc_solve_device if p->soc_u_interior is set) -> SCP residual -> (X_prev, U_prev) <- (X, U).
+ *   p          the sub-problem; p->X_prev / p->U_prev hold the start iterate (and are OVERWRITTEN: the two trajectory buffer
+ *              pairs (X_prev, U_prev) and (X_out, U_out) swap roles every iteration), p->f / fx / fu are scratch the
+ *              linearisation writes (device, caller-allocated), f2 / fx2 / fu2 a second set of the same sizes: the next
+ *              linearisation is enqueued behind the sub-problem's rounds BEFORE the host knows they sufficed (if they did
+ *              not, it is redone), and must not touch what a continued solve still reads
+ *   first_cold non-zero: X_prev / U_prev of the first iteration are not the previous solve's outputs (no warm-start promise)
+ *   res        device, `steps` doubles: the residual of each iteration (max over ranks when sharded)
+ *   infos      host, `steps` entries (may be NULL)
+ * The final iterate is in (X_out, U_out) if `steps` is odd, else in (X_prev, U_prev); *last_in_out says which.  Returns the
+ * number of iterations completed (== steps unless a sub-problem failed: its status is in infos[returned]). */
+int pmpc_scp_loop_device(pmpc_ctx *ctx, int model, const double *params, const pmpc_problem *p, double *f2, double *fx2, double *fu2,
+                         int steps, int first_cold, double *res, pmpc_info *infos, int *last_in_out);
+
 /* Live kernel timing for bench.py: HIP events on pmpc_stream() around the launches of a class
  * (0 backward+factor, 1 backward vector-only, 2 forward, 3 consensus reduce+solve).
  * level 0 = off, 1 = class 0 only (the dominant kernel; what bench.py's roofline needs), 2 = every class

@@ -563,40 +563,53 @@ int structured_cpu_solve(int xdim, int udim, int N, int M, long long Nc_in, cons
     int *act = (int *)malloc(sizeof(int) * nU);
     memcpy(Xs, X, sizeof(double) * nX);
     memcpy(Us, U, sizeof(double) * nU);
-    for (long long k = 0; k < nU; k++) {
+    for (long long k = 0; k < nU; k++) { /* first guess: multiplier above slack */
       const int consj = ((k / u) % N) < Nc;
       const long long ks = consj ? (k % ((long long)N * u)) : k; /* consensus controls: particle 0 decides for everyone */
       const int lo_a = isfinite(G[1].lo[ks]) && G[1].ll[ks] > G[1].tl[ks], hi_a = isfinite(G[1].hi[ks]) && G[1].lu[ks] > G[1].tu[ks];
       act[k] = lo_a ? 1 : (hi_a ? 2 : 0);
-      if (act[k]) U[k] = act[k] == 1 ? G[1].lo[ks] : G[1].hi[ks];
-      else U[k] = fmin(fmax(U[consj ? ks : k], G[1].lo[ks]), G[1].hi[ks]);
-      Du[k] = consj ? 0.0 : (act[k] ? big : 0.0);
-      if (consj && k < (long long)N * u) Dc[k] = act[k] ? big : 0.0;
+      U[k] = U[consj ? ks : k];
     }
-    rollout(&q, U, X);
-    int ok = lq_factor(&q, NULL, Du, nc ? Dc : NULL) == 0;
-    if (ok) {
+    int ok = 0;
+    for (int pass = 0; pass < 12 && !ok; pass++) { /* primal-dual active-set iteration: exact solve on the set, KKT sign check */
+      for (long long k = 0; k < nU; k++) {
+        const int consj = ((k / u) % N) < Nc;
+        const long long ks = consj ? (k % ((long long)N * u)) : k;
+        U[k] = act[k] ? (act[k] == 1 ? G[1].lo[ks] : G[1].hi[ks]) : fmin(fmax(U[k], G[1].lo[ks]), G[1].hi[ks]);
+        Du[k] = consj ? 0.0 : (act[k] ? big : 0.0);
+        if (consj && k < (long long)N * u) Dc[k] = act[k] ? big : 0.0;
+      }
+      rollout(&q, U, X);
+      if (lq_factor(&q, NULL, Du, nc ? Dc : NULL)) break;
       gradient(&q, X, U, gx, gu);
       if (nc) memset(gce, 0, sizeof(double) * nc);
       lq_solve(&q, gx, gu, nc ? gce : NULL, dX, dU, NULL);
-      for (long long k = 0; k < nU && ok; k++) {
+      long long changes = 0;
+      int nan_seen = 0;
+      for (long long k = 0; k < nU; k++) {
         const int consj = ((k / u) % N) < Nc;
         const long long ks = consj ? (k % ((long long)N * u)) : k;
-        if (!(dU[k] == dU[k])) ok = 0;
-        else if (act[k]) {
+        if (!(dU[k] == dU[k])) { nan_seen = 1; break; }
+        if (act[k]) {
           const double lam = act[k] == 1 ? -big * dU[k] : big * dU[k];
-          if (lam < -1e-9) ok = 0; /* wrong set: a held control wants to leave its bound */
+          if (lam < -1e-11) { act[k] = 0; changes++; } /* a held control wants to leave its bound: release */
         } else {
           const double z = U[k] + dU[k];
-          if (z < G[1].lo[ks] - 1e-11 * fmax(1.0, fabs(G[1].lo[ks])) || z > G[1].hi[ks] + 1e-11 * fmax(1.0, fabs(G[1].hi[ks]))) ok = 0;
+          if (z < G[1].lo[ks] - 1e-13 * fmax(1.0, fabs(G[1].lo[ks]))) { act[k] = 1; changes++; }
+          else if (z > G[1].hi[ks] + 1e-13 * fmax(1.0, fabs(G[1].hi[ks]))) { act[k] = 2; changes++; }
         }
       }
+      if (nan_seen) break;
+      if (changes == 0) ok = 1;
+      else
+        for (long long k = 0; k < nU; k++) /* next base point: this pass's step, clipped (held / newly held ones are snapped above) */
+          if (!act[k]) U[k] += dU[k];
     }
     if (ok) {
       for (long long k = 0; k < nX; k++) X[k] += dX[k];
       for (long long k = 0; k < nU; k++)
         if (!act[k]) U[k] += dU[k];
-    } else { /* the set was not the optimal one: keep the interior-point solution */
+    } else { /* did not settle: keep the interior-point solution */
       memcpy(X, Xs, sizeof(double) * nX);
       memcpy(U, Us, sizeof(double) * nU);
     }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_lqp_solve_host", "pmpc_lcone_solve_host", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
-    "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all",
+    "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device",
 ]
 
 
@@ -102,6 +102,9 @@ def load():
     lib.pmpc_profile_read_partial.restype = None
     lib.pmpc_profile_read_all.argtypes = [vp, c_dp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
     lib.pmpc_profile_read_all.restype = None
+    lib.pmpc_scp_loop_device.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(PmpcProblem), vp, vp, vp, ctypes.c_int, ctypes.c_int, vp,
+                                         ctypes.POINTER(PmpcInfo), ctypes.POINTER(ctypes.c_int)]
+    lib.pmpc_scp_loop_device.restype = ctypes.c_int
     lib.pmpc_version.argtypes = []
     lib.pmpc_version.restype = ctypes.c_char_p
     _lib = lib

@@ -116,6 +116,43 @@ def lcone_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, l
                  slew_reg, slew_reg0, slew_um1, verbose, extra, cone_k=k)
 
 
+_SOC_SOLVER = None
+
+
+def _aff_solve_stage_cone(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l, u_u,
+                          solver_settings, soc):
+    """Sub-problem with one second-order cone ||W u + w0|| <= v'u + v0 on the controls of every (particle, stage) next to the
+    control boxes — the structured case of the reference's `extra_cstrs` (README.md:219-239) — through the device solver's
+    path-following method (`pmpc_lsoc_solve_device`).  py-layout host arrays in, py-layout out.  The objective is the plain
+    sum of the particle costs (the QP's), as for solver = "osqp"."""
+    import torch
+
+    from .device import DeviceSolver
+
+    global _SOC_SOLVER
+    if slew_rate or u_slew is not None or (x_l is not None and np.size(x_l)):
+        raise ValueError("extra_cstrs (stage-wise second-order cone): slew penalties and state boxes are not supported on this path")
+    if u_l is None or np.size(u_l) == 0:
+        raise ValueError("extra_cstrs (stage-wise second-order cone): control boxes are required (the method starts strictly inside them)")
+    if _SOC_SOLVER is None:
+        _SOC_SOLVER = DeviceSolver(0)
+    s = _SOC_SOLVER
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    tm = lambda a: torch.as_tensor(np.ascontiguousarray(np.swapaxes(a, -1, -2)), dtype=torch.float64, device="cuda")
+    u_int = solver_settings.get("soc_u_interior")
+    if u_int is None:  # box centre, pulled inside the cone along v if necessary is the caller's business: ask for it
+        u_int = 0.5 * (np.asarray(u_l)[0, 0] + np.asarray(u_u)[0, 0])
+    Nc = solver_settings.get("Nc", -1)
+    X, U, status = s.lsoc_solve(f=t(f), fx=tm(fx), fu=tm(fu), X_prev=t(X_prev), U_prev=t(U_prev), Q=tm(Q), R=tm(R), X_ref=t(X_ref),
+                                U_ref=t(U_ref), reg_x=float(reg_x), reg_u=float(reg_u), Nc=Nc, x0=t(x0), lu=t(u_l), uu=t(u_u),
+                                soc_W=t(soc["W"]), soc_w0=t(soc["w0"]), soc_v=t(soc["v"]), soc_v0=float(soc["v0"]), soc_u_interior=t(u_int))
+    s.sync()
+    X, U = X.cpu().numpy(), U.cpu().numpy()
+    if status != 0:
+        X[:], U[:] = np.nan, np.nan
+    return np.concatenate([np.asarray(x0)[:, None, :], X], -2), U, dict()
+
+
 def aff_solve(
     f: np.ndarray, fx: np.ndarray, fu: np.ndarray, x0: np.ndarray, X_prev: np.ndarray, U_prev: np.ndarray,
     Q: np.ndarray, R: np.ndarray, X_ref: np.ndarray, U_ref: np.ndarray, reg_x: float, reg_u: float,
@@ -131,6 +168,45 @@ def aff_solve(
     Q, R = atleast_nd(to_numpy_f64(Q), 4), atleast_nd(to_numpy_f64(R), 4)
     X_ref, U_ref = atleast_nd(to_numpy_f64(X_ref), 3), atleast_nd(to_numpy_f64(U_ref), 3)
     x_l, x_u, u_l, u_u = [None if z is None else atleast_nd(to_numpy_f64(z), 3) for z in (x_l, x_u, u_l, u_u)]
+
+    # user constraints in the reference's tuple format (pyjulia only upstream, PMPC.jl/src/main.jl:293-316): the cases this
+    # back end implements are folded in here; anything else is REFUSED, never dropped silently
+    soc = None
+    if solver_settings.get("extra_cstrs"):
+        from .extra_cstrs import linear_rows_to_boxes, stage_soc_from_extra_cstrs
+
+        Mb, Nb, xd, ud = f.shape[0], f.shape[1], f.shape[2], fu.shape[-1]
+        Ncb = solver_settings.get("Nc", -1)
+        for cstr in solver_settings["extra_cstrs"]:
+            try:  # single-variable linear rows: boxes
+                bx = linear_rows_to_boxes(cstr, Mb, Nb, xd, ud, Ncb)
+            except ValueError as e_lin:
+                try:  # one second-order cone on the controls of every stage
+                    if soc is not None:
+                        raise ValueError("more than one stage-wise second-order cone")
+                    soc = stage_soc_from_extra_cstrs(cstr, Mb, Nb, xd, ud, Ncb)
+                    continue
+                except ValueError as e_soc:
+                    raise ValueError("extra_cstrs: supported are linear rows on single variables (boxes) and one second-order cone "
+                                     f"on the controls of every stage; this tuple is neither ({e_lin}; {e_soc})") from None
+            merged = []
+            for cur, new, is_lo, like in ((x_l, bx[0], True, X_prev), (x_u, bx[1], False, X_prev), (u_l, bx[2], True, U_prev), (u_u, bx[3], False, U_prev)):
+                if np.all(np.isinf(new)):
+                    merged.append(cur)
+                    continue
+                base = np.full(like.shape, -np.inf if is_lo else np.inf) if cur is None or cur.size == 0 else cur
+                merged.append(np.maximum(base, new) if is_lo else np.minimum(base, new))
+            x_l, x_u, u_l, u_u = merged
+            # a one-sided box needs its other side too (the ABI takes lower and upper together)
+            if (x_l is None or x_l.size == 0) != (x_u is None or x_u.size == 0):
+                x_l = np.full(X_prev.shape, -np.inf) if x_l is None or x_l.size == 0 else x_l
+                x_u = np.full(X_prev.shape, np.inf) if x_u is None or x_u.size == 0 else x_u
+            if (u_l is None or u_l.size == 0) != (u_u is None or u_u.size == 0):
+                u_l = np.full(U_prev.shape, -np.inf) if u_l is None or u_l.size == 0 else u_l
+                u_u = np.full(U_prev.shape, np.inf) if u_u is None or u_u.size == 0 else u_u
+    if soc is not None:
+        return _aff_solve_stage_cone(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l, u_u,
+                                     solver_settings, soc)
 
     x_l, x_u, u_l, u_u = [None if z is None else py2jl(z, 1) for z in (x_l, x_u, u_l, u_u)]
     x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = [

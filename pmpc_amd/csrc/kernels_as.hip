@@ -382,8 +382,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // ------------------------------------------------------------------------------------------------
 // Loop structure as in k_bwd_as: the consensus stages and stage 0 go through the general body, the free stages j >= 1 through
 // a branch-free MAIN body, two per loop trip with the prefetch register sets swapping roles.
-template <int XD, int UD, bool DEFECT>
-__global__ void __launch_bounds__(64) k_fwd_as(LQArgs a) {
+// PF2: data requested two stages ahead (ring of three register sets) — the latency regime, up to 3 waves per SIMD; else one
+// stage ahead (two sets, 4 waves per SIMD: with more than 3072 particles per GPU the waves hide each other's latency)
+template <int XD, int UD, bool DEFECT, bool PF2>
+__global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
   constexpr bool PADX = (XD != LT::XP);
@@ -510,31 +512,46 @@ __global__ void __launch_bounds__(64) k_fwd_as(LQArgs a) {
     xcol = L.cxv ? nx : 0.0;
   };
 
-  // Prefetch distance: TWO stages.  With one wave per SIMD (small shards, the later rounds' few unsettled particles) a stage of
-  // this sweep is shorter than the HBM latency, so data requested one stage ahead would still pin every stage to that latency.
-  // Three register sets in a ring; the main loop runs three stages per trip so that their roles are static (no moves).
-  Pipe P0, P1, P2;
-  auto clampN = [&](int jj) { return jj < N ? jj : N - 1; };  // (the last stages re-read the last one: no branch)
-  fetch(0, P0);
-  fetch(clampN(1), P1);
   const int jmin = Nc > 1 ? Nc : 1;  // MAIN covers the free stages jmin .. N-1
+  auto clampN = [&](int jj) { return jj < N ? jj : N - 1; };  // (the last stages re-read the last one: no branch)
   int j = 0;
-  for (; j < jmin && j < N; j++) {  // consensus stages / stage 0: general body, ring rotated by moves
-    fetch(clampN(j + 2), P2);
-    stage(std::false_type{}, j, P0);
-    P0 = P1;
-    P1 = P2;
+  if (PF2) {
+    // Prefetch distance: TWO stages.  With one wave per SIMD (small shards, the later rounds' few unsettled particles) a stage
+    // of this sweep is shorter than the HBM latency, so data requested one stage ahead would still pin every stage to that
+    // latency.  Three register sets in a ring; the main loop runs three stages per trip so that their roles are static (no moves).
+    Pipe P0, P1, P2;
+    fetch(0, P0);
+    fetch(clampN(1), P1);
+    for (; j < jmin && j < N; j++) {  // consensus stages / stage 0: general body, ring rotated by moves
+      fetch(clampN(j + 2), P2);
+      stage(std::false_type{}, j, P0);
+      P0 = P1;
+      P1 = P2;
+    }
+    for (; j + 2 < N; j += 3) {
+      fetch(clampN(j + 2), P2);
+      stage(std::true_type{}, j, P0);
+      fetch(clampN(j + 3), P0);
+      stage(std::true_type{}, j + 1, P1);
+      fetch(clampN(j + 4), P1);
+      stage(std::true_type{}, j + 2, P2);
+    }
+    if (j < N) { stage(std::true_type{}, j, P0); j++; }  // (0 .. 2 stages left; their data is already in flight / landed:
+    if (j < N) { stage(std::true_type{}, j, P1); j++; }  //  after a full trip the ring holds stage j in P0 and j + 1 in P1)
+  } else {
+    Pipe A, B;
+    fetch(0, A);
+    for (; j < jmin && j < N; j++) {
+      fetch(clampN(j + 1), B);
+      stage(std::false_type{}, j, A);
+      A = B;
+    }
+    for (; j < N; j++) {
+      fetch(clampN(j + 1), B);
+      stage(std::true_type{}, j, A);
+      A = B;
+    }
   }
-  for (; j + 2 < N; j += 3) {
-    fetch(clampN(j + 2), P2);
-    stage(std::true_type{}, j, P0);
-    fetch(clampN(j + 3), P0);
-    stage(std::true_type{}, j + 1, P1);
-    fetch(clampN(j + 4), P1);
-    stage(std::true_type{}, j + 2, P2);
-  }
-  if (j < N) { stage(std::true_type{}, j, P0); j++; }      // (0 .. 2 stages left; their data is already in flight / landed:
-  if (j < N) { stage(std::true_type{}, j, P1); j++; }      //  after a full trip the ring holds stage j in P0 and j + 1 in P1)
   // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
   const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
   if (lane == 0) {
@@ -550,9 +567,22 @@ __global__ void __launch_bounds__(64) k_fwd_as(LQArgs a) {
 // the host used to take after reading them back.  Single rank: called right behind the forward sweep with reduce = 1,
 // decide = 1.  Sharded: reduce = 1 (local counters -> ctl->cnt), all-reduce of ctl->cnt, then decide = 1.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch,
-                                                AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq) {
-  __shared__ int sh[3][256];
+// control block of a fresh attempt (one thread): replaces a host -> device copy and a memset per solve
+__global__ void k_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale) {
+  if (threadIdx.x == 0) {
+    *fail = 0;
+    AsCtl h = {};
+    h.max_rounds = max_rounds;
+    h.last_changes = 0x7fffffff;
+    h.dual_scale = dual_scale;
+    h.tol_l = dual_scale * 1e-11;
+    *ctl = h;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch,
+                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq) {
+  __shared__ int sh[3][1024];
   if (ctl->done) {  // nothing ran in this round: republish (the host may be waiting on this sequence number)
     if (threadIdx.x == 0 && decide && last_of_batch && mirror) {
       *mirror = *ctl;
@@ -563,10 +593,10 @@ __global__ void __launch_bounds__(256) k_as_ctl(AsCtl *ctl, const int *cnt_part,
   }
   if (reduce) {
     int r = 0, d = 0, b = 0;
-    for (int i = threadIdx.x; i < M; i += 256) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
+    for (int i = threadIdx.x; i < M; i += 1024) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
     sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
       if (threadIdx.x < o) {
         sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
         sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
@@ -630,8 +660,15 @@ void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
 }
 template <int XD, int UD>
 void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
-  if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true>), dim3(a.M), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((k_fwd_as<XD, UD, false>), dim3(a.M), dim3(64), 0, s, a);
+  static const int m2 = getenv("PMPC_AS_FWD_PF2_MAXM") ? atoi(getenv("PMPC_AS_FWD_PF2_MAXM")) : 3072;
+  const dim3 grd(a.M), blk(64);
+  if (a.M <= m2) {
+    if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true>), grd, blk, 0, s, a);
+  } else {
+    if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, false>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, false>), grd, blk, 0, s, a);
+  }
 }
 
 }  // namespace
@@ -650,5 +687,8 @@ void launch_fwd_as(const LQArgs &a, hipStream_t s) {
 }
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
                    unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(256), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq);
+  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(1024), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq);
+}
+void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_begin, dim3(1), dim3(64), 0, s, ctl, fail, max_rounds, dual_scale);
 }

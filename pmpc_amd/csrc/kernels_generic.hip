@@ -695,7 +695,7 @@ void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int 
   const int nH = nc * nc;
   int G = (M + 127) / 128;  // ~4 particles per lane and slice
   if (G > 64) G = 64;
-  if (M <= 1024) G = 1;  // small shards are launch-bound: one block sums <= 32 particles per lane and solves, one launch instead of two
+  if (M <= 512) G = 1;  // small shards are launch-bound: one block sums <= 32 particles per lane and solves, one launch instead of two
   double *Hc = Hg, *gc = Hg + nH;
   if (G <= 1) {
     hipLaunchKernelGGL(k_cons_small, dim3(1), dim3(1024), 0, s, Hc_part, gc_part, M, nc, with_H ? 1 : 0, Hc, gc, solve_now ? 1 : 0,

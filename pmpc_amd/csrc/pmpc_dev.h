@@ -180,6 +180,7 @@ void launch_bwd_as(const LQArgs &a, hipStream_t s);
 void launch_fwd_as(const LQArgs &a, hipStream_t s);
 // round control: reduce the per-particle counters into ctl->cnt (+ failure flag) and / or decide (done, status, next tolerance);
 // publishes ctl to the host-coherent mirror with sequence number `seq` when the rounds are over or the batch ends
+void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s);  // fresh control block of an attempt, *fail = 0
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
                    unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s);
 

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <atomic>
 #include <mutex>
@@ -152,6 +153,9 @@ struct Workspace {
   long long warm_key = -1;
   DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta;  // active-set iteration: status per bounded control (int), counters,
                                                                  // per-particle counters, settled flags, control block, applied consensus step
+  long long su_key = -1;  // shape / source arrays the working copy of the control boxes (w.su.lo, w.su.hi) was made for
+  const double *su_src_lo = nullptr, *su_src_hi = nullptr;
+  bool as_U_valid = false;  // w.U holds the solution that goes with the stored active set
   int as_pred_rounds = 3;  // rounds the last accepted solve took: how many the next one enqueues before it reads anything back
   DevBuf cons_lo, cons_hi;  // sharded runs: the consensus controls' bounds as last broadcast (PMPC_STATIC_CONS_BOUNDS)
   long long cons_key = -1;
@@ -201,6 +205,10 @@ struct pmpc_ctx {
   struct StagedChunk { void *dst; size_t bytes, off; };
   std::vector<StagedChunk> staged;  // what the bounce buffer (and the device staging buffers) hold from the previous call
   DevBuf host_flags;
+  // pmpc_scp_loop_device: work to enqueue right behind the first batch of active-set rounds, BEFORE the host waits for their
+  // outcome (the residual of this iteration and the linearisation of the next); spec_ok: that batch was the whole solve
+  std::function<void()> post_batch;
+  bool spec_fired = false, spec_ok = false;
 };
 
 namespace {
@@ -602,7 +610,6 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     HIP_CHECK(hipMemsetAsync(w.part_cnt.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
     HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
   }
-  HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
   const long long as_prev = w.as_key;  // accepted active set + solution of the previous solve (valid only if nothing ran since)
   w.as_key = -1;
   if (!has_slew || !has_slew0) {
@@ -639,8 +646,16 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     w.part_dev.ensure(2 * PMPC_RED_BLOCKS * D8);
     HIP_CHECK(hipMemsetAsync(w.part_dev.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
   }
-  launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
-                      mu_target, w.part_dev.d());
+  // failure flag and interior-point scalars: reset lazily — the warm-started active-set rounds (the path an SCP loop takes)
+  // clear the flag in their own first kernel and never touch the scalars
+  bool scalars_reset = false;
+  auto reset_scalars = [&]() {
+    if (scalars_reset) return;
+    scalars_reset = true;
+    HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+    launch_ipm_exchange(0, false, false, sc, (const int *)w.fail.p, w.xch.d(), c->rank, c->world, nullptr, nullptr, nullptr, 0, s,
+                        mu_target, w.part_dev.d());
+  };
   auto equality_solve = [&]() {
     launch_init_base(w.U.d(), p->U_prev, M, N, u, Nc, s);
     if (fast) launch_rollout_fast(a, w.U.d(), w.X.d(), s);
@@ -682,8 +697,15 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   if (has_xb) setup_slab(sx, w.sx, nx, x, false, p->lx, p->ux, w.X.d(), w.dX.d());
   if (has_ub) {
     const double *lo = p->lu, *hi = p->uu;
-    if (Nc > 0 && (M > 1 || c->multi())) {  // consensus bounds = global particle 0's (lqp_utils.jl:329-330)
+    const long long sukey = ((((long long)u * 131 + N) * 1000003 + M) * 131 + Nc);
+    if (Nc > 0 && (M > 1 || c->multi()) && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && (p->flags & PMPC_STATIC_CONS_BOUNDS || !c->multi()) &&
+        w.su_key == sukey && w.su_src_lo == p->lu && w.su_src_hi == p->uu && w.su.lo.bytes >= nu * D8) {
+      // inside an SCP loop (the caller vouches: boxes unchanged) the working copy of the previous solve — the caller's boxes with
+      // particle 0's on the consensus stages — still stands: two 6.5 MB copies and a kernel per solve saved
+      lo = w.su.lo.d(); hi = w.su.hi.d();
+    } else if (Nc > 0 && (M > 1 || c->multi())) {  // consensus bounds = global particle 0's (lqp_utils.jl:329-330)
       w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
+      w.su_key = sukey; w.su_src_lo = p->lu; w.su_src_hi = p->uu;
       HIP_CHECK(hipMemcpyAsync(w.su.lo.p, p->lu, nu * D8, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipMemcpyAsync(w.su.hi.p, p->uu, nu * D8, hipMemcpyDeviceToDevice, s));
       if (c->multi()) {
@@ -711,6 +733,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   const int B = PMPC_RED_BLOCKS;
 
   if (soc) {
+    reset_scalars();
     // ---- stage-wise control cones: primal-dual path following on the same Riccati kernels (kernels_soc.hip) ----------
     if (has_xb || p->weights || a.any_slew || p->soc_u_interior == nullptr || (p->soc_q > 0 && (!p->soc_W || !p->soc_w0 || !p->soc_v)) ||
         u > 8 || p->soc_q > 4) {
@@ -896,6 +919,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
 
   // returns 0: the equality-only optimum satisfies every box (done), 1: boxes violated (interior-point phase), 2: failure
   auto equality_phase = [&]() -> int {
+    reset_scalars();
     equality_solve();
     if (has_xb) launch_violation(sx, w.part_max.d(), s);
     if (has_ub) launch_violation(su, w.part_max.d() + B, s);
@@ -948,13 +972,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     b.as_settled_out = (int *)w.as_settled.p; b.as_delta = w.as_delta.d(); b.as_ctl = ctl; b.done = &ctl->done;
     b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
     w.as_key = -1;
-    {  // control block of this attempt
-      AsCtl h0;
-      memset(&h0, 0, sizeof(h0));
-      h0.max_rounds = max_rounds; h0.last_changes = 0x7fffffff; h0.dual_scale = dual_scale; h0.tol_l = dual_scale * 1e-11;
-      memcpy((void *)&c->mirror->ctl, &h0, sizeof(h0));  // staged through the host-coherent mirror (no pageable-memory copy)
-      HIP_CHECK(hipMemcpyAsync(ctl, &c->mirror_dev->ctl, sizeof(AsCtl), hipMemcpyDeviceToDevice, s));
-    }
+    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s);  // control block of this attempt (+ cleared failure flag)
     // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
     // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout, nothing
     // written before the sweep.  The forward sweep verifies that U_prev IS the base point of the stored set.
@@ -970,6 +988,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     }
     int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
+    int n_batches_at_hook = -1000;  // batches waited for since the speculation hook fired (in THIS attempt)
     AsCtl h;
     memset(&h, 0, sizeof(h));
     while (true) {
@@ -993,6 +1012,14 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
         }
       }
+      if (round == 0 && c->post_batch) {  // the caller's follow-up work goes in behind the rounds before anything is read back
+        std::function<void()> hook;
+        hook.swap(c->post_batch);
+        c->spec_fired = true;
+        n_batches_at_hook = 0;
+        hook();
+      }
+      n_batches_at_hook++;
       // the control block is published when the rounds are over (done) or at the end of the batch, whichever comes first,
       // with the sequence number of the round that published it: wait for any of this batch's numbers
       {
@@ -1025,6 +1052,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     if (!h.done) return 1;
     if (h.status != 0) return h.status;
     if (has_xb) {  // the candidate's states against their boxes
+      reset_scalars();
       HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
       Slab sc2 = sx;
       sc2.z = p->X_out;
@@ -1037,15 +1065,20 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         return 1;
       }
     }
-    HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_out, nu * D8, hipMemcpyDeviceToDevice, s));  // the next solve's warm start (non-SCP callers)
+    // the next solve's warm start: a caller inside an SCP loop (promise flag) hands the solution back as U_prev, which is then
+    // the base point itself — no copy; any other caller's next warm start snaps THIS copy into its boxes
+    w.as_U_valid = !(p->flags & PMPC_PREV_IS_LAST_SOLUTION);
+    if (w.as_U_valid) HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_out, nu * D8, hipMemcpyDeviceToDevice, s));
     outputs_written = true;
     w.as_key = as_key;  // the stored set (+ w.U) start the next solve of this shape
     w.as_scale = dual_scale;
     if (mode == 0) w.as_pred_rounds = round;
+    c->spec_ok = n_batches_at_hook == 1 && !has_xb;  // what was enqueued behind the first batch saw the final outputs
     return 0;
   };
   auto active_set_solve = [&](double dual_scale, int mode, int max_rounds) -> int {
     if (fast) return active_set_fast(dual_scale, mode, max_rounds);
+    reset_scalars();
     // generic kernels: a check pass + rollout per round, decisions on the host.  `big` never meets a normal-sized term in a sum (the penalty's target is a ZERO step), so it only has to dwarf every
     // H_uu entry: gains, H_uu^-1 and the step of a held control come out ~1e-30 relative and -big du_b is its multiplier
     const double big = 1e30, tol_p = 1e-13;
@@ -1119,7 +1152,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     }
     return 1;
   };
-  if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key) {
+  const bool as_can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && Nc <= 1 && fast;
+  if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || as_can_defect)) {
     a.Dx = a.wx = nullptr;
     const int r = active_set_solve(w.as_scale, 0, 8);
     if (r == 0) return finish(0);
@@ -1284,6 +1318,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     return status;
   };
 
+  reset_scalars();
   int status = try_warm ? interior_point(true) : interior_point(false);
   if (try_warm && status != 0) {  // rejected or failed: fresh scalars, the equality-only optimum after all, cold start
     if (verbose && status > 0) printf("pmpc_hip: warm-started iteration failed (status %d): repeating from a cold start\n", status);
@@ -1298,6 +1333,67 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   }
   if (verbose && status != 0) printf("pmpc_hip: interior-point iteration did not converge (status %d)\n", status);
   return finish(status);
+}
+
+// -------------------------------------------------------------------------------------------------
+// SCP loop with the host out of the loop body (built-in dynamics)
+// -------------------------------------------------------------------------------------------------
+int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmpc_problem *p0, double *f2, double *fx2, double *fu2,
+                         int steps, int first_cold, double *res, pmpc_info *infos, int *last_in_out) {
+  pmpc_problem p = *p0;
+  // trajectory buffers A = (X_prev, U_prev), B = (X_out, U_out); linearisation buffers 0 = (f, fx, fu), 1 = (f2, fx2, fu2)
+  double *XA = const_cast<double *>(p0->X_prev), *UA = const_cast<double *>(p0->U_prev), *XB = p0->X_out, *UB = p0->U_out;
+  double *F[2][3] = {{const_cast<double *>(p0->f), const_cast<double *>(p0->fx), const_cast<double *>(p0->fu)}, {f2, fx2, fu2}};
+  const bool soc = p0->soc_u_interior != nullptr;
+  int done = 0, cur = 0;
+  bool lin_ready = false;  // the linearisation of iteration `done` is already enqueued (valid speculation of the previous one)
+  try {
+    HIP_CHECK(hipSetDevice(c->device));
+    for (; done < steps; done++) {
+      double *Xp = (done & 1) ? XB : XA, *Up = (done & 1) ? UB : UA, *Xo = (done & 1) ? XA : XB, *Uo = (done & 1) ? UA : UB;
+      if (!lin_ready) {
+        ProfScope ps(c, 6);
+        launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xp, Up, params, F[cur][0], F[cur][1], F[cur][2], c->stream);
+      }
+      p.f = F[cur][0]; p.fx = F[cur][1]; p.fu = F[cur][2];
+      p.X_prev = Xp; p.U_prev = Up; p.X_out = Xo; p.U_out = Uo;
+      p.flags = p0->flags | PMPC_STATIC_CONS_BOUNDS;
+      if (done > 0 || !first_cold) p.flags |= PMPC_PREV_IS_LAST_SOLUTION;
+      else p.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;
+      auto follow_up = [&, Xp, Up, Xo, Uo](bool with_next_lin) {  // residual of this iteration (+ the next linearisation)
+        {
+          ProfScope ps(c, 7);
+          launch_scp_residual(Xo, Xp, Uo, Up, (long long)p.M * (long long)p.N, (int)p.xdim, (int)p.udim, res + done, c->stream);
+        }
+        if (c->multi()) allreduce(c, res + done, 1, ncclFloat64, ncclMax);
+        if (with_next_lin && done + 1 < steps) {
+          ProfScope ps(c, 6);
+          launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xo, Uo, params, F[cur ^ 1][0], F[cur ^ 1][1], F[cur ^ 1][2], c->stream);
+        }
+      };
+      c->spec_fired = c->spec_ok = false;
+      c->post_batch = [&]() { follow_up(true); };
+      pmpc_info inf;
+      const int st = solve_impl(c, &p, &inf, 0, soc);
+      c->post_batch = nullptr;
+      if (infos) infos[done] = inf;
+      if (st != 0) break;
+      if (c->spec_fired && c->spec_ok) {
+        lin_ready = true;  // residual and next linearisation are in flight behind the accepted rounds
+      } else {
+        follow_up(false);  // (a speculative copy, if any, was computed from unfinished outputs: redone; the next linearisation
+        lin_ready = false;  //  is enqueued at the top of the next iteration, into the other buffer set)
+      }
+      cur ^= 1;
+    }
+    HIP_CHECK(hipGetLastError());
+  } catch (const PmpcHipError &) {
+    c->post_batch = nullptr;
+    if (infos && done < steps) { memset(&infos[done], 0, sizeof(pmpc_info)); infos[done].status = 2; }
+    fail_after_error(c, nullptr, nullptr);
+  }
+  if (last_in_out) *last_in_out = done & 1;
+  return done;
 }
 
 // -------------------------------------------------------------------------------------------------

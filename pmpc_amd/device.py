@@ -197,6 +197,27 @@ class DeviceSolver:
         self._after(wait_current_stream)
         return out
 
+    def scp_loop(self, model: int, params, steps: int, *, f2, fx2, fu2, first_cold=True, res=None, wait_current_stream=True, **kw):
+        """`steps` SCP iterations (linearise -> sub-problem -> residual -> swap) for a built-in dynamics model in ONE library
+        call: the host is out of the loop body (no Python / ctypes work between iterations, the residual and the next
+        linearisation are enqueued behind the sub-problem's rounds before their outcome is read back).  `kw` as for
+        `lqp_solve` / `lsoc_solve` with `f, fx, fu` (scratch the linearisation writes), `X_prev, U_prev` (start iterate,
+        OVERWRITTEN) and `X_out, U_out`; `f2, fx2, fu2`: a second scratch set.  Returns (res, infos, last_in_out, done):
+        per-iteration residuals (device tensor), per-iteration info dicts, whether the final iterate is in (X_out, U_out)
+        (else in (X_prev, U_prev)), iterations completed."""
+        prob, X_out, U_out = self._problem(**kw)
+        res = torch.empty((steps,), dtype=torch.float64, device=f2.device) if res is None else res
+        infos = (_lib.PmpcInfo * steps)()
+        last = ctypes.c_int(0)
+        self._before(wait_current_stream)
+        done = self.lib.pmpc_scp_loop_device(self.h, int(model), _p(params), ctypes.byref(prob), _p(f2), _p(fx2), _p(fu2), int(steps),
+                                             int(bool(first_cold)), _p(res), infos, ctypes.byref(last))
+        self._after(wait_current_stream)
+        out = [{k: getattr(infos[i], k) for k, _ in _lib.PmpcInfo._fields_} for i in range(min(done + 1, steps))]
+        if out:
+            self.last_info = out[min(done, steps) - 1] if done > 0 else out[0]
+        return res, out, bool(last.value), done
+
     def sync(self):
         self.lib.pmpc_sync(self.h)
 

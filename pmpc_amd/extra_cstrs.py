@@ -81,3 +81,50 @@ def stage_soc_to_extra_cstrs(W, w0, v, v0, M: int, N: int, xdim: int, udim: int,
     G = sp.hstack([G, sp.csr_matrix((nblocks * qq, n - ncu))], format="csr")
     h = np.tile(np.concatenate([[-float(v0)], -w0]), nblocks)
     return (0, [qq] * nblocks, 0, G, sp.csr_matrix((nblocks * qq, 0)), h, np.zeros(n), np.zeros(0))
+
+
+def linear_rows_to_boxes(cstr: Sequence[Any], M: int, N: int, xdim: int, udim: int, Nc: int):
+    """Linear rows `G z <= h` (the `l` part of a tuple, PMPC.jl/src/cone_solver.jl:163-166) with ONE nonzero per row are box
+    constraints on single variables.  Returns `(x_l, x_u, u_l, u_u)` as (M, N, d) arrays with -inf / +inf where nothing is
+    imposed — to be intersected with the caller's boxes — or raises `ValueError` if the tuple is anything else (cones, new
+    variables, cost terms, rows that couple variables).  A row on a consensus control (shared column) bounds that control for
+    every particle; the joint QP takes particle 0's bound there (lqp_utils.jl:329-330)."""
+    l, q, e, G_left, G_right, h, c_left, c_right = cstr
+    Nc = N if Nc < 0 else min(int(Nc), N)
+    Nf = N - Nc
+    ncu = Nc * udim + M * Nf * udim
+    n = ncu + M * N * xdim
+    if (np.size(q) and sum(int(v) for v in np.atleast_1d(q)) > 0) or int(e) != 0:
+        raise ValueError("not a purely linear tuple (q / e non-empty)")
+    if G_right is not None and np.size(G_right) > 0 and sp.csr_matrix(G_right).shape[1] > 0:
+        raise ValueError("rows that introduce new variables (G_right) are not supported")
+    for c in (c_left, c_right):
+        if c is not None and np.size(c) > 0 and np.any(np.asarray(c, dtype=np.float64) != 0.0):
+            raise ValueError("cost augmentation (c_left / c_right) is not supported")
+    G = sp.csr_matrix(G_left, dtype=np.float64)
+    G.eliminate_zeros()
+    h = np.asarray(h, dtype=np.float64).reshape(-1)
+    if G.shape != (int(l), n) or h.size != int(l):
+        raise ValueError(f"G_left must be ({int(l)}, {n}) over z = [U_cons; U_free; X], h ({int(l)},)")
+    if np.any(np.diff(G.indptr) != 1):
+        raise ValueError("rows that couple several variables are not supported (one nonzero per row: a box on one variable)")
+    x_l, x_u = np.full((M, N, xdim), -np.inf), np.full((M, N, xdim), np.inf)
+    u_l, u_u = np.full((M, N, udim), -np.inf), np.full((M, N, udim), np.inf)
+    for col, coef, rhs in zip(G.indices, G.data, h):
+        bound = rhs / coef
+        if col < Nc * udim:  # shared control: stage j, component r, every particle
+            j, r = divmod(int(col), udim)
+            lo, hi, idx = u_l, u_u, (slice(None), j, r)
+        elif col < ncu:
+            i, rest = divmod(int(col) - Nc * udim, Nf * udim)
+            j, r = divmod(rest, udim)
+            lo, hi, idx = u_l, u_u, (i, Nc + j, r)
+        else:
+            i, rest = divmod(int(col) - ncu, N * xdim)
+            j, r = divmod(rest, xdim)
+            lo, hi, idx = x_l, x_u, (i, j, r)
+        if coef > 0:
+            hi[idx] = np.minimum(hi[idx], bound)
+        else:
+            lo[idx] = np.maximum(lo[idx], bound)
+    return x_l, x_u, u_l, u_u

@@ -206,7 +206,7 @@ def test_stage_cones_match_cone_oracle(case, oracle):
     s.close()
 
 
-@pytest.mark.parametrize("M,k", [(40, 10), (40, 39), (24, 1), (600, 300)])
+@pytest.mark.parametrize("M,k", [(40, 20), (40, 30), (40, 39), (24, 1), (600, 300)])
 def test_worst_k_objective_matches_cone_oracle(oracle, M, k):
     """The reference's `k` setting (PMPC.jl/src/main.jl:204-227, pyjulia only): weight (1 - eps) k on the epigraph offset, i.e.
     only the ~k (1 - eps) / (1 + eps) costliest particles carry weight.  Zero-weight particles: stated semantics of the oracle
@@ -223,3 +223,25 @@ def test_worst_k_objective_matches_cone_oracle(oracle, M, k):
     X, U = backend.lcone_solve(*abi_args(args, kw, 1), smooth_alpha=float("nan"), solver="ecos", k=k)
     assert np.all(np.isfinite(X)) and np.all(np.isfinite(U))
     assert _rel(X, Xo) < TOL and _rel(U, Uo) < TOL, (_rel(X, Xo), _rel(U, Uo))
+
+
+def test_host_loop_takes_the_stage_cone_as_an_extra_cstrs_tuple(oracle):
+    """`pmpc_amd.solve(..., solver_settings=dict(extra_cstrs=[tuple]))` with the reference-format tuple of the stage-wise thrust
+    cone (README.md:219-239): the host back end routes the sub-problem to the device cone solver; one sub-problem against
+    the cone oracle."""
+    from pmpc_amd import backend
+    from pmpc_amd.extra_cstrs import stage_soc_to_extra_cstrs
+
+    M, N, x, u, Nc = 6, 8, 4, 3, 1
+    rng = np.random.default_rng(11)
+    args, kw = rand_problem(rng, M, N, x, u, 0.6)
+    W = np.zeros((2, 3)); W[0, 1] = W[1, 2] = 1.0
+    w0, v, v0 = np.zeros(2), np.array([0.5, 0.0, 0.0]), 0.1
+    cstr = stage_soc_to_extra_cstrs(W, w0, v, v0, M, N, x, u, Nc)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    Xo, Uo = oracle.lsoc_solve_py(*args, Nc=Nc, reg_x=kw["reg_x"], reg_u=kw["reg_u"], u_l=kw["u_l"], u_u=kw["u_u"], soc_W=W, soc_w0=w0, soc_v=v,
+                                  soc_v0=v0, u_interior=np.zeros(3))
+    X, U, _ = backend.aff_solve(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, kw["reg_x"], kw["reg_u"], 0.0, None, np.zeros((0, 0, 0)),
+                                np.zeros((0, 0, 0)), kw["u_l"], kw["u_u"], solver_settings=dict(solver="osqp", Nc=Nc, extra_cstrs=[cstr],
+                                                                                              soc_u_interior=np.zeros(3)))
+    assert _rel(X[:, 1:], Xo) < TOL and _rel(U, Uo) < TOL, (_rel(X[:, 1:], Xo), _rel(U, Uo))

@@ -337,6 +337,52 @@ def test_scp_like_sequence_without_rollout(case, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("model,M,N,Nc", [("quadrotor", 96, 20, 1), ("unicycle", 40, 12, 3)])
+def test_library_scp_loop_equals_the_python_driven_loop(solver, model, M, N, Nc):
+    """pmpc_scp_loop_device (linearise -> sub-problem -> residual -> swap inside the library, follow-up work enqueued behind the
+    rounds before their outcome is known) walks exactly the sequence a Python-driven loop of the same calls walks: identical
+    iterates and residuals after 1..5 iterations, cold first iteration included."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, to_device_problem
+
+    prob = dyn.make_quadrotor_problem(M=M, N=N, Nc=Nc) if model == "quadrotor" else dyn.make_unicycle_problem(M=M, N=N, Nc=Nc)
+    mid = MODEL_QUADROTOR if model == "quadrotor" else MODEL_UNICYCLE
+    d = to_device_problem(prob)
+    common = dict(Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"], lu=d["lu"],
+                  uu=d["uu"], symmetric_cost=True)
+    for steps in (1, 2, 5):
+        # Python-driven
+        Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+        Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+        res_py = []
+        for it in range(steps):
+            f, fx, fu = solver.linearize(mid, d["x0"], Xa, Ua, d["params"])
+            _, _, st = solver.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, static_cons_bounds=True,
+                                        prev_is_last_solution=it > 0, cold_start=it == 0, **common)
+            assert st == 0
+            res_py.append(float(solver.scp_residual(Xb, Xa, Ub, Ua)[0].item()))
+            Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+        X_py, U_py = Xa.clone(), Ua.clone()
+        # inside the library (a fresh shape memory: cold like the loop above)
+        Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+        Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+        x, u = Xa.shape[-1], Ua.shape[-1]
+        mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device="cuda")
+        bufs = [mk(M, N, x), mk(M, N, x, x), mk(M, N, u, x), mk(M, N, x), mk(M, N, x, x), mk(M, N, u, x)]
+        solver.lqp_solve(f=bufs[0].zero_(), fx=bufs[1].zero_(), fu=bufs[2].zero_(), X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, cold_start=True,
+                         **dict(common, lu=None, uu=None))  # (forget the warm-start memory of this shape)
+        res, infos, last_in_out, done = solver.scp_loop(mid, d["params"], steps, f=bufs[0], fx=bufs[1], fu=bufs[2], f2=bufs[3], fx2=bufs[4],
+                                                        fu2=bufs[5], X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, first_cold=True, **common)
+        solver.sync()
+        assert done == steps and all(i["status"] == 0 for i in infos)
+        X_lib, U_lib = (Xb, Ub) if last_in_out else (Xa, Ua)
+        assert last_in_out == bool(steps & 1)
+        np.testing.assert_array_equal(res.cpu().numpy(), np.array(res_py))
+        assert torch.equal(X_lib, X_py) and torch.equal(U_lib, U_py)
+
+
 def test_bench_line_keeps_the_driver_contract():
     """`python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with the keys the driver reads, the metric / unit of
     BASELINE.json, and the `roofline` and `cpu_baseline` objects (small sizes here: the contract, not the numbers)."""

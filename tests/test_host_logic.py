@@ -297,6 +297,56 @@ def test_oracle_reaches_the_fixed_points_of_the_remaining_reference_tables(oracl
     nbp.check_fixed_point(name, data["hist"], table)
 
 
+def test_extra_cstrs_linear_rows_become_boxes_and_the_rest_is_refused(monkeypatch):
+    """`extra_cstrs` tuples (README.md:219-239) on the host path: single-variable linear rows G z <= h are folded into the boxes
+    handed to the ABI (intersected with the caller's), consensus columns bound the shared control; a tuple outside the
+    supported cases raises — it is never dropped silently."""
+    import scipy.sparse as sp
+
+    from pmpc_amd import backend
+    from pmpc_amd.extra_cstrs import linear_rows_to_boxes
+
+    M, N, x, u, Nc = 3, 5, 4, 2, 2
+    ncu = Nc * u + M * (N - Nc) * u
+    n = ncu + M * N * x
+    G = sp.lil_matrix((4, n))
+    G[0, 1] = 2.0                                   # shared control, stage 0, component 1:  2 u <= 1
+    G[1, Nc * u + 1 * (N - Nc) * u + 2 * u] = -1.0  # particle 1, stage Nc + 2, component 0:  -u <= 0.3
+    G[2, ncu + 2 * N * x + 3 * x + 1] = 1.0         # particle 2, stage 3, state 1 <= 7
+    G[3, ncu] = -4.0                                # particle 0, stage 0, state 0:  -4 x <= 8
+    cstr = (4, [], 0, G.tocsr(), sp.csr_matrix((4, 0)), np.array([1.0, 0.3, 7.0, 8.0]), np.zeros(n), np.zeros(0))
+    xl, xu, ul, uu = linear_rows_to_boxes(cstr, M, N, x, u, Nc)
+    assert np.all(uu[:, 0, 1] == 0.5) and ul[1, Nc + 2, 0] == -0.3 and xu[2, 3, 1] == 7.0 and xl[0, 0, 0] == -2.0
+    assert np.isinf(uu).sum() == uu.size - 3 and np.isinf(ul).sum() == ul.size - 1 and np.isinf(xl).sum() == xl.size - 1
+
+    seen = {}
+
+    def fake_lqp(*args, verbose=False):
+        seen["args"] = args
+        f = args[2]
+        xdim, Nn, Mm = f.shape
+        return np.zeros((Mm, Nn, xdim)), np.zeros((Mm, Nn, args[6].shape[0]))
+
+    monkeypatch.setattr(backend, "lqp_solve", fake_lqp)
+    rng = np.random.default_rng(0)
+    f, fx, fu = rng.standard_normal((M, N, x)), rng.standard_normal((M, N, x, x)), rng.standard_normal((M, N, x, u))
+    z3 = lambda d: np.zeros((M, N, d))
+    Q, R = np.tile(np.eye(x), (M, N, 1, 1)), np.tile(np.eye(u), (M, N, 1, 1))
+    empty = np.zeros((0, 0, 0))
+    backend.aff_solve(f, fx, fu, np.zeros((M, x)), z3(x), z3(u), Q, R, z3(x), z3(u), 1.0, 0.1, 0.0, None, empty, empty, -0.4 * np.ones((M, N, u)),
+                      0.4 * np.ones((M, N, u)), solver_settings=dict(solver="osqp", Nc=Nc, extra_cstrs=[cstr]))
+    a = seen["args"]
+    lx, ux, lu, uub = (backend.jl2py(a[k], 1) for k in (11, 12, 13, 14))
+    assert lu[1, Nc + 2, 0] == -0.3 and np.all(uub[:, 0, 1] == 0.4) and np.all(lu[0] == -0.4)  # intersected with the caller's +-0.4
+    assert ux[2, 3, 1] == 7.0 and lx[0, 0, 0] == -2.0 and np.isinf(ux).sum() == ux.size - 1
+    G2 = G.copy()
+    G2[0, 3] = 1.0  # a row coupling two variables
+    bad = (4, [], 0, G2.tocsr(), sp.csr_matrix((4, 0)), np.ones(4), np.zeros(n), np.zeros(0))
+    with pytest.raises(ValueError, match="neither"):
+        backend.aff_solve(f, fx, fu, np.zeros((M, x)), z3(x), z3(u), Q, R, z3(x), z3(u), 1.0, 0.1, 0.0, None, empty, empty, empty, empty,
+                          solver_settings=dict(solver="osqp", Nc=Nc, extra_cstrs=[bad]))
+
+
 def test_extra_cstrs_tuple_to_stage_cones():
     """The reference's `extra_cstrs` tuple format (README.md:219-239) for the stage-wise thrust cone is recognised and
     mapped to the device solver's `(W, w0, v, v0)`; anything outside that structure is refused with a reason."""

@@ -5,14 +5,15 @@ tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --repeats 0 --no-cpu-baseline > $out/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --repeats 0 --no-cpu-baseline > $out/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --repeats 0 --no-cpu-baseline > $out/bench_write.log 2>&1
 python3 bench.py --steps 20 --warmup 3 > $out/bench_full.log 2>&1
 grep '^{' $out/bench_full.log | cut -c1-400
 find $out -name '*.csv' | head -20
 # other BASELINE configs (no CPU baseline): C = quadrotor M=1024, B = unicycle M=256 N=30
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M 1024 > $out/bench_C.log 2>&1
+for m in 512 2048; do python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M $m > $out/bench_shard_$m.log 2>&1; done
 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --M 256 --N 30 --model unicycle > $out/bench_B.log 2>&1
 grep -h '^{' $out/bench_C.log $out/bench_B.log | cut -c1-200
 # secondary: the reference's default consensus horizon Nc = N (full consensus) on B and on the quadrotor

@@ -36,12 +36,12 @@ read_factor = ax_read_true / ax_fetch
 ax_write = sum(write[key(write, "k_axpy(")]) / len(write[key(write, "k_axpy(")]) * 1024
 out = {"calibration": {"kernel": "k_axpy", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
                        "read_factor": read_factor, "true_write_bytes": 8 * (nx + nu) / 2, "WRITE_SIZE_bytes": ax_write}}
-# full factor sweep only: the SKIP instantiation (last template argument true) processes a subset of the particles
-# template arguments: <x, u, FACTOR, HXB, HUB, DEEP, SKIP, DEFECT>
-for name, label in (("k_bwd_fast<12, 4, true, false, true, false, false, false>", "bwd_factor"),
-                    ("k_bwd_fast<12, 4, true, false, true, false, false, true>", "bwd_factor_defect"), ("k_bwd_fast<12, 4, false", "bwd_vec"),
-                    ("k_fwd_fast<12, 4, false, false, false>", "fwd"), ("k_fwd_fast<12, 4, false, true, false>", "fwd_active_set"),
-                    ("k_fwd_fast<12, 4, false, true, true>", "fwd_active_set_defect")):
+# kernels_as.hip: k_bwd_as<x, u, MODE, SKIP, DEFECT> (MODE 0 lean / 1 deep / 2 deep2; SKIP launches process a subset of the particles:
+# never part of the roofline figure), k_fwd_as<x, u, DEFECT, PF2>; kernels_fast.hip: k_bwd_fast<x, u, FACTOR, HXB, HUB, DEEP>
+for name, label in (("k_bwd_fast<12, 4, true, false, true, false>", "bwd_factor"),
+                    ("k_bwd_as<12, 4, 0, false, true>", "bwd_factor_defect"), ("k_bwd_as<12, 4, 0, false, false>", "bwd_factor_as_plain"),
+                    ("k_bwd_fast<12, 4, false", "bwd_vec"), ("k_fwd_fast<12, 4, false>", "fwd"),
+                    ("k_fwd_as<12, 4, false, false>", "fwd_active_set"), ("k_fwd_as<12, 4, true, false>", "fwd_active_set_defect")):
     try:
         kf, kw = key(fetch, name), key(write, name)
     except StopIteration:
@@ -58,7 +58,8 @@ stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))[0]
 (dst / f"{tag}_kernel_stats.csv").write_text(open(stats).read())
 for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f"{tag}_bench_under_rocprof.json"),
                   ("bench_C.log", f"{tag}_bench_C.json"), ("bench_B.log", f"{tag}_bench_B.json"),
-                  ("bench_B_NcN.log", f"{tag}_bench_B_NcN.json"), ("bench_D_NcN.log", f"{tag}_bench_D_NcN.json")):
+                  ("bench_B_NcN.log", f"{tag}_bench_B_NcN.json"), ("bench_D_NcN.log", f"{tag}_bench_D_NcN.json"),
+                  ("bench_shard_512.log", f"{tag}_bench_shard_512.json"), ("bench_shard_2048.log", f"{tag}_bench_shard_2048.json")):
     if not (src / log).exists():
         continue
     lines = [l for l in open(src / log) if l.startswith("{")]
