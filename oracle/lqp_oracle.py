@@ -600,6 +600,26 @@ def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, 
         return dict(sum_lambda=float(abs(np.sum(lam) - (1 - eps) * k)), full_below=float(max(0.0, np.max(t - J[w >= hi], initial=0.0)) / max(1.0, abs(t))),
                     ok=bool(abs(np.sum(lam) - (1 - eps) * k) <= 1e-9 * M and np.all(J[w >= hi] >= t - tol)))
 
+    Ncc = np.shape(f)[1] if Nc < 0 else min(int(Nc), np.shape(f)[1])
+
+    def polish_weightless(X, U, w):
+        """The joint solve carries the weightless particles at `w_floor`: its KKT certificate (absolute tolerances) says nothing
+        about THEIR accuracy.  Each of them is re-solved on its own, weight 1, with the shared controls pinned (box lo = hi)."""
+        X, U = X.copy(), U.copy()
+        for i in np.where(w <= w_floor)[0]:
+            sl = slice(i, i + 1)
+            bx = {k: (None if kw.get(k) is None else np.array(np.broadcast_to(_f64(kw[k]), U.shape if k[0] == "u" else X.shape)[sl]))
+                  for k in ("x_l", "x_u", "u_l", "u_u")}
+            if Ncc > 0:
+                if bx["u_l"] is None:
+                    bx["u_l"], bx["u_u"] = np.full(U[sl].shape, -np.inf), np.full(U[sl].shape, np.inf)
+                bx["u_l"][:, :Ncc], bx["u_u"][:, :Ncc] = U[sl, :Ncc], U[sl, :Ncc]
+            sub = {k: (None if kw.get(k) is None else np.broadcast_to(_f64(kw[k]), (M,) + np.shape(kw[k])[1:] if np.ndim(kw[k]) else (M,))[sl])
+                   for k in ("slew_reg", "slew_reg0", "slew_um1")}
+            Xi, Ui = lqp_solve_py(*[np.asarray(a_)[sl] for a_ in args], reg_x=reg_x, reg_u=reg_u, Nc=Nc, **bx, **sub)
+            X[sl], U[sl, Ncc:] = Xi, Ui[:, Ncc:]
+        return X, U
+
     X, U, J, _ = solve(np.full(M, hi))
     w1, w_prev = weights_of(J), None
     for _ in range(12):
@@ -608,6 +628,7 @@ def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, 
         if np.array_equal(w2, w1):
             cert = certificate(w1, J)
             assert cert["ok"], cert
+            X, U = polish_weightless(X, U, w1)
             return (X, U, dict(weights=w1, J=J, qp=info, kink=False, cone_cert=cert)) if return_info else (X, U)
         if w_prev is not None and np.array_equal(w2, w_prev):
             d = w1 - w2
@@ -627,6 +648,7 @@ def _lcone_many_particles(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, 
             tol = 1e-9 * max(1.0, abs(jk))
             ok = abs(np.sum(lam) - (1 - eps) * k) <= 1e-9 * M and np.all(J[others & (w >= hi)] >= jk - tol) and np.all(J[others & (w < hi)] <= jk + tol)
             assert ok, "cone oracle: the kink between two rankings is not a KKT point"
+            X, U = polish_weightless(X, U, w)
             return (X, U, dict(weights=w, J=J, qp=info, kink=True, theta=th)) if return_info else (X, U)
         w_prev, w1 = w1, w2
     raise RuntimeError("cone oracle: the threshold set did not settle")

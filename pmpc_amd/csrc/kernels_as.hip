@@ -402,7 +402,9 @@ __global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
                            : (L.cu ? a.fu + pbase * (XD * UD) + XD * L.cb + L.row0 : Z);
   const int sF = fF ? (int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
   const double *Xb = DEFECT ? a.X_prev : a.Xb, *Ub = DEFECT ? a.U_prev : a.Ub;
-  const double tol_l = a.as_ctl ? a.as_ctl->tol_l : a.as_tol_l;
+  // sign tolerance of the multipliers, in units of THIS particle's cost weight (a down-weighted particle of the cone path has
+  // proportionally small multipliers: an absolute tolerance would freeze its weakly active bounds)
+  const double tol_l = (a.as_ctl ? a.as_ctl->tol_l : a.as_tol_l) * (a.pw ? a.pw[i] : 1.0);
   // uniform stage bases + per-lane constant byte offsets (see k_bwd_as)
   const unsigned lxr = (unsigned)(L.row0 * D8), lug = (unsigned)((gu ? g : 0) * D8), lrec = (unsigned)(lane * D8);
   const bool fK = L.cxv && gu;
@@ -448,6 +450,8 @@ __global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
 
   double xcol = 0.0;  // dx[oc] on valid state columns
   int nrel = 0, nadd = 0, nbad = 0;
+  double vworst = 0.0;
+  const double inv_dual = 1.0 / (a.as_ctl ? a.as_ctl->dual_scale : 1.0);
   auto stage = [&](auto main_tag, const int j, const Pipe &cur) {
     constexpr bool MAIN = decltype(main_tag)::value;
     double Fr[KS];
@@ -483,6 +487,11 @@ __global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
     nbad |= (gu && !(draw == draw)) ? 1 : 0;
     nrel += (cnt_here && release) ? 1 : 0;
     nadd += (cnt_here && (vlo || vhi)) ? 1 : 0;
+    {  // size of the violation behind a change (diagnostic / acceptance of changes at round-off level)
+      const double pv = vlo ? (loc - zt) / fmax(1.0, fabs(loc)) : (vhi ? (zt - hic) / fmax(1.0, fabs(hic)) : 0.0);
+      const double dv = release ? -lam * inv_dual / (a.pw ? a.pw[i] : 1.0) : 0.0;
+      vworst = fmax(vworst, cnt_here ? fmax(pv, dv) : 0.0);
+    }
     const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
     const double du_c = L.cu ? t : 0.0;
     if (store_u) {
@@ -554,6 +563,13 @@ __global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
   }
   // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
   const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
+  if (a.as_viol) {  // max over the k-groups (the counting lanes are c == 0)
+    double p01, p23, q0, q1;
+    swap32_d(vworst, p01, p23);
+    const double m = fmax(p01, p23);
+    swap16_d(m, q0, q1);
+    if (lane == 0) a.as_viol[i] = fmax(q0, q1);
+  }
   if (lane == 0) {
     a.as_cnt[3 * i + 0] = (int)r;
     a.as_cnt[3 * i + 1] = (int)d;
@@ -580,9 +596,13 @@ __global__ void k_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_sc
   }
 }
 
+// `tail` (sharded runs, consensus horizon > 0): the four counters travel as doubles behind [Hc | gc] in the NEXT round's
+// consensus all-reduce instead of in a collective of their own — reduce = 1 packs the local sums into tail[0..3], decide = 1
+// reads the all-reduced values from there.
 __global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch,
-                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq) {
+                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq, double *tail, const double *viol) {
   __shared__ int sh[3][1024];
+  __shared__ double shv[1024];
   if (ctl->done) {  // nothing ran in this round: republish (the host may be waiting on this sequence number)
     if (threadIdx.x == 0 && decide && last_of_batch && mirror) {
       *mirror = *ctl;
@@ -593,20 +613,32 @@ __global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part
   }
   if (reduce) {
     int r = 0, d = 0, b = 0;
-    for (int i = threadIdx.x; i < M; i += 1024) { r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2]; }
-    sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b;
+    double vw = 0.0;
+    for (int i = threadIdx.x; i < M; i += 1024) {
+      r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2];
+      if (viol) vw = fmax(vw, viol[i]);
+    }
+    sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b; shv[threadIdx.x] = vw;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
       if (threadIdx.x < o) {
         sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
         sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
         sh[2][threadIdx.x] |= sh[2][threadIdx.x + o];
+        shv[threadIdx.x] = fmax(shv[threadIdx.x], shv[threadIdx.x + o]);
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) { ctl->cnt[0] = sh[0][0]; ctl->cnt[1] = sh[1][0]; ctl->cnt[2] = sh[2][0]; ctl->cnt[3] = *fail; }
+    if (threadIdx.x == 0 && viol && ctl->round < 16) ctl->worst[ctl->round] = shv[0];  // (local to this rank when sharded: a diagnostic)
+    if (threadIdx.x == 0) {
+      if (tail) { tail[0] = sh[0][0]; tail[1] = sh[1][0]; tail[2] = sh[2][0]; tail[3] = *fail; }
+      else { ctl->cnt[0] = sh[0][0]; ctl->cnt[1] = sh[1][0]; ctl->cnt[2] = sh[2][0]; ctl->cnt[3] = *fail; }
+    }
   }
   if (threadIdx.x == 0 && decide) {
+    if (tail) {  // all-reduced sums (exact in fp64: small integers)
+      for (int k = 0; k < 4; k++) ctl->cnt[k] = (int)(tail[k] < 2e9 ? tail[k] : 2e9);
+    }
     const int rel = ctl->cnt[0], add = ctl->cnt[1], bad = ctl->cnt[2], fl = ctl->cnt[3];
     const int round = ctl->round;  // rounds completed before this one
     if (round < 16) { ctl->hist[round][0] = rel; ctl->hist[round][1] = add; }
@@ -686,8 +718,8 @@ void launch_fwd_as(const LQArgs &a, hipStream_t s) {
   abort();
 }
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
-                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s) {
-  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(1024), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq);
+                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail, const double *viol) {
+  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(1024), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol);
 }
 void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s) {
   hipLaunchKernelGGL(k_as_begin, dim3(1), dim3(64), 0, s, ctl, fail, max_rounds, dual_scale);

@@ -647,7 +647,18 @@ __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, cons
   if (e < E) {
     const double *src = isH ? Hc_part + e : gc_part + (with_H ? e - nH : e);
     const int stride = isH ? nH : nc;
-    for (int i = i0 + pl; i < i1; i += 32) acc += src[(size_t)i * stride];
+    // independent accumulators: the loads of a lane are all in flight together (a single dependent chain of 16 loads of
+    // ~1 us each was most of this kernel's 15 us at 512 particles); summation order is fixed, so the result stays deterministic
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = i0 + pl;
+    for (; i + 96 < i1; i += 128) {
+      a0 += src[(size_t)i * stride];
+      a1 += src[(size_t)(i + 32) * stride];
+      a2 += src[(size_t)(i + 64) * stride];
+      a3 += src[(size_t)(i + 96) * stride];
+    }
+    for (; i < i1; i += 32) a0 += src[(size_t)i * stride];
+    acc = (a0 + a1) + (a2 + a3);
   }
   red[pl][e] = acc;
   __syncthreads();

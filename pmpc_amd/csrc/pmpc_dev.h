@@ -46,6 +46,8 @@ struct AsCtl {
   int hist[16][2];   // per round: released, activated
   double tol_l;      // sign tolerance of the multipliers for the NEXT round
   double dual_scale;
+  double worst[16];  // per round: largest KKT violation among the changed controls — how far outside its box a control that got
+                     // clamped stood (relative to max(1, |bound|)), how negative a released multiplier was (relative to dual_scale)
 };
 
 // Arguments of the structured LQ kernels (Riccati factor / vector sweeps / forward sweep).
@@ -84,6 +86,7 @@ struct LQArgs {
   int *as_act;
   const double *as_lo, *as_hi;
   int *as_cnt;
+  double *as_viol;  // per particle: largest KKT violation among its changed controls (see AsCtl::worst); null = not recorded
   // first round of a warm start inside an SCP loop: the base point (X_prev, snapped U_prev) is NOT rolled out — its dynamics
   // defect r_j = f_j - X_prev_j (elementwise, since base == linearisation point) rides through the sweeps instead:
   // backward s_j += S_j r_j, forward dx_j += r_j.  Non-null selects the DEFECT kernel variants.
@@ -101,6 +104,9 @@ struct LQArgs {
   double *as_delta;
   const AsCtl *as_ctl;
   const int *done;
+  // sharded active-set rounds with a consensus horizon: the previous round's change counters ride behind [Hc | gc] in this
+  // round's consensus all-reduce (0 off, 1 first round of an attempt: nothing to carry yet, 2 later rounds)
+  int as_merge;
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
@@ -182,7 +188,7 @@ void launch_fwd_as(const LQArgs &a, hipStream_t s);
 // publishes ctl to the host-coherent mirror with sequence number `seq` when the rounds are over or the batch ends
 void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s);  // fresh control block of an attempt, *fail = 0
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
-                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s);
+                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail = nullptr, const double *viol = nullptr);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_block_transpose(const double *in, double *out, int rows, int cols, long long n, hipStream_t s);

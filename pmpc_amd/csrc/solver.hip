@@ -151,7 +151,7 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
-  DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta;  // active-set iteration: status per bounded control (int), counters,
+  DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta, as_viol;  // active-set iteration: status per bounded control (int), counters,
                                                                  // per-particle counters, settled flags, control block, applied consensus step
   long long su_key = -1;  // shape / source arrays the working copy of the control boxes (w.su.lo, w.su.hi) was made for
   const double *su_src_lo = nullptr, *su_src_hi = nullptr;
@@ -310,19 +310,29 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
     ProfScope ps(c, 3);
     double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
     if (fast && factor) launch_cond_fast(a, s);
+    // sharded active-set rounds: the previous round's change counters travel behind [Hc | gc] (one collective per round
+    // instead of two); the decision about that round is taken right behind the all-reduce, before this round's forward sweep
+    const size_t tail = (a.as_merge && factor) ? 4 : 0;
+    double *tl = Hc + (size_t)nc * nc + nc;
+    auto merged_exchange = [&]() {
+      if (a.as_merge == 2) launch_as_ctl(const_cast<AsCtl *>(a.as_ctl), a.as_cnt, a.M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, tl);
+      else if (a.as_merge == 1) HIP_CHECK(hipMemsetAsync(tl, 0, 4 * sizeof(double), s));
+      if (factor) allreduce(c, Hc, (size_t)nc * nc + nc + tail, ncclFloat64, ncclSum);
+      else allreduce(c, gc, nc, ncclFloat64, ncclSum);
+      if (a.as_merge == 2)
+        launch_as_ctl(const_cast<AsCtl *>(a.as_ctl), nullptr, a.M, (const int *)w.fail.p, 0, 1, 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s, tl);
+    };
     if (nc * nc + nc <= 32) {
       const bool solve_now = !c->multi();
       launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
       if (!solve_now) {
-        if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
-        else allreduce(c, gc, nc, ncclFloat64, ncclSum);
+        merged_exchange();
         launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
       }
     } else {
       if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
       launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
-      if (factor) allreduce(c, Hc, (size_t)nc * nc + nc, ncclFloat64, ncclSum);
-      else allreduce(c, gc, nc, ncclFloat64, ncclSum);
+      merged_exchange();
       launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
     }
   }
@@ -406,7 +416,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -600,7 +610,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   w.gc_part.ensure((size_t)M * nc * D8); w.Hc_part.ensure((size_t)M * nc * nc * D8);
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
   w.red_tmp.ensure((size_t)64 * ((size_t)nc * nc + nc) * D8);
-  w.Hg.ensure(((size_t)nc * nc + nc) * D8); w.Lc.ensure((size_t)nc * nc * D8); w.duc.ensure((size_t)nc * D8);
+  w.Hg.ensure(((size_t)nc * nc + nc + 4) * D8);  // (+ 4: change counters of the active-set rounds, sharded runs)
+  w.Lc.ensure((size_t)nc * nc * D8); w.duc.ensure((size_t)nc * D8);
   w.sc.ensure(sizeof(IpmScal)); w.fail.ensure(sizeof(int)); w.xch.ensure((size_t)c->world * 8 * D8);
   const bool fresh_parts = w.part_sum.bytes == 0;
   w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_cnt.ensure(2 * PMPC_RED_BLOCKS * D8);
@@ -970,6 +981,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     b.Dx = b.wx = b.Du = b.wu = nullptr; b.du_full = 0;
     b.as_act = act; b.as_lo = su.lo; b.as_hi = su.hi; b.as_cnt = (int *)w.as_cntp.p; b.as_big = big; b.as_tol_p = tol_p;
     b.as_settled_out = (int *)w.as_settled.p; b.as_delta = w.as_delta.d(); b.as_ctl = ctl; b.done = &ctl->done;
+    w.as_viol.ensure((size_t)M * D8);
+    b.as_viol = w.as_viol.d();
     b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
     w.as_key = -1;
     launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s);  // control block of this attempt (+ cleared failure flag)
@@ -1000,16 +1013,29 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         // conditional optimum: no factor sweep for them — g_i follows the applied consensus step, g_i += H_i delta
         const bool skip = as_skip_on && r > 0 && nc <= 32;
         b.as_settled_in = skip ? (const int *)w.as_settled.p : nullptr;
-        structured_solve(c, b, true, true, /*prep_done=*/true);
         const bool last = k == batch - 1;
+        // sharded with a consensus horizon: {released, activated, bad, failure} of round r ride in round r + 1's consensus
+        // all-reduce (structured_solve), the decision about round r follows it there; only the last round of a batch needs a
+        // collective of its own.  Every rank takes the same decisions from the same sums.
+        const bool merge = c->multi() && nc > 0;
+        b.as_merge = merge ? (k == 0 ? 1 : 2) : 0;  // (the first round of a batch carries nothing: the previous batch closed its last round)
         c->as_seq++;
+        structured_solve(c, b, true, true, /*prep_done=*/true);
         ProfScope ps(c, 5);
-        if (c->multi()) {  // {released, activated, bad, failure}: one sum for all four, then every rank takes the same decision
+        if (merge) {
+          if (last) {
+            double *tl = w.Hg.d() + (size_t)nc * nc + nc;
+            launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, tl);
+            allreduce(c, tl, 4, ncclFloat64, ncclSum);
+            launch_as_ctl(ctl, nullptr, M, (const int *)w.fail.p, 0, 1, 1, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s, tl);
+          }
+        } else if (c->multi()) {  // no consensus exchange to ride on: one sum for all four
           launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s);
           allreduce(c, ctl->cnt, 4, ncclInt32, ncclSum);
           launch_as_ctl(ctl, nullptr, M, (const int *)w.fail.p, 0, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
         } else {
-          launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
+          launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s,
+                        nullptr, b.as_viol);
         }
       }
       if (round == 0 && c->post_batch) {  // the caller's follow-up work goes in behind the rounds before anything is read back
@@ -1040,8 +1066,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       }
       if (verbose)
         for (int r = round; r < h.round && r < 16; r++)
-          printf("pmpc_hip: active set (%s) round %d: %d released, %d activated\n", mode == 2 ? "cold" : (mode ? "finish" : "warm"), r + 1,
-                 h.hist[r][0], h.hist[r][1]);
+          printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest violation behind a change %.2e)\n",
+                 mode == 2 ? "cold" : (mode ? "finish" : "warm"), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
       inf.structured_solves += h.round - round;
       inf.active_set_rounds += h.round - round;
       round = h.round;
@@ -1142,6 +1168,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           }
         }
         launch_as_accept_all(st, act, Utry, p->U_out, Xtry, w.dX.d(), (long long)nx, w.X.d(), p->X_out, s);
+        w.as_U_valid = true;  // (the acceptance pass wrote the controls into the warm-start memory)
         outputs_written = true;
         w.as_key = as_key;  // act + w.U start the next solve of this shape
         w.as_scale = dual_scale;
@@ -1482,7 +1509,9 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
   const double kk = (p->cone_k > 0 && p->cone_k < (long long)M) ? (double)p->cone_k : (double)M;
   const long long n_hi = (long long)std::floor((1.0 - eps) * kk / (1.0 + eps) + 1e-12);
   const long long mstar = std::max<long long>(1, (long long)M - n_hi);
-  const double w_hi = 1.0 + eps, w_thr = (1.0 - eps) * kk - (1.0 + eps) * (double)n_hi, w_floor = 1e-4;
+  // floor weight of the weightless particles: they shift the shared controls by O(w_floor (m* - 1) / n_hi) — 1e-4 is harmless for
+  // the one-in-500 of k = M, the worst-k objective (half the particles weightless at k = M / 2) needs it smaller
+  const double w_hi = 1.0 + eps, w_thr = (1.0 - eps) * kk - (1.0 + eps) * (double)n_hi, w_floor = kk < (double)M ? 1e-9 : 1e-4;
 
   auto solve_with = [&](const std::vector<double> &rankw) -> int {
     for (size_t i = 0; i < Ml; i++) pw[i] = user[off + i] * rankw[off + i];

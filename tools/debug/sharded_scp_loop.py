@@ -66,4 +66,55 @@ for world in (2, 4, 8):
     print(f"world {world}: rel diff X {ex:.2e} U {eu:.2e}; per-solve (ipm, rounds) {infos[0]}; ranks agree: {len({tuple(i) for i in infos}) == 1}")
     assert ex < 1e-9 and eu < 1e-9 and len({tuple(i) for i in infos}) == 1
     assert all(i[0] == 0 for i in infos[0][1:]), "a later solve fell back to the interior-point path"
+
+
+# ---- the same through pmpc_scp_loop_device (the loop body inside the library: what bench.py times), built-in quadrotor dynamics ----
+from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem  # noqa: E402
+
+
+def run_world_lib(world):
+    Ml = M // world
+    _group[0] += 1
+    group, out, errs = _group[0], [None] * world, []
+
+    def rank_fn(rank):
+        try:
+            sl = slice(rank * Ml, (rank + 1) * Ml)
+            shard = {k: (v[sl] if isinstance(v, np.ndarray) and v.shape[:1] == (M,) else v) for k, v in prob.items()}
+            d = to_device_problem(shard)
+            s = DeviceSolver(0)
+            if world > 1:
+                assert s.lib.pmpc_comm_init_mock(s.h, rank, world, group) == 0
+                s.rank, s.world = rank, world
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device="cuda")
+            Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+            Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+            res, infos, last_in_out, done = s.scp_loop(
+                MODEL_QUADROTOR, d["params"], ITERS, f=mk(Ml, N, 12), fx=mk(Ml, N, 12, 12), fu=mk(Ml, N, 4, 12), f2=mk(Ml, N, 12),
+                fx2=mk(Ml, N, 12, 12), fu2=mk(Ml, N, 4, 12), X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
+                U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d["lu"], uu=d["uu"], symmetric_cost=True)
+            s.sync()
+            assert done == ITERS and all(i["status"] == 0 for i in infos), infos
+            X, U = (Xb, Ub) if last_in_out else (Xa, Ua)
+            out[rank] = (X.cpu().numpy(), U.cpu().numpy(), res.cpu().numpy(), [(i["ipm_iters"], i["active_set_rounds"]) for i in infos])
+            s.close()
+        except Exception as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    assert all(o is not None for o in out), "a rank did not finish"
+    assert all(np.array_equal(o[2], out[0][2]) for o in out), "ranks disagree on the SCP residuals"
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out]), out[0][2], [o[3] for o in out]
+
+
+X1, U1, r1, j1 = run_world_lib(1)
+print("library loop, single rank: residuals", r1, "(ipm iterations, rounds)", j1[0])
+for world in (2, 4):
+    Xw, Uw, rw, infos = run_world_lib(world)
+    ex, eu = np.linalg.norm(Xw - X1) / np.linalg.norm(X1), np.linalg.norm(Uw - U1) / np.linalg.norm(U1)
+    print(f"library loop, world {world}: rel diff X {ex:.2e} U {eu:.2e}; residual diff {np.max(np.abs(rw / r1 - 1)):.1e}; ranks agree: {len({tuple(i) for i in infos}) == 1}")
+    assert ex < 1e-9 and eu < 1e-9 and np.max(np.abs(rw / r1 - 1)) < 1e-9 and len({tuple(i) for i in infos}) == 1
 print("SHARDED_SCP_OK")
