@@ -242,6 +242,16 @@ void launch_soc_update(const SocArgs &a, double alpha, double *X, const double *
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s);
 
 // ---- dynamics.hip -------------------------------------------------------------------------------
+// slew penalties on the MFMA path: the problem restated in control increments (kernels_slew.hip)
+struct SlewAug {
+  int x, u, N, M, Nc, has_xb, has_ub, has_um1;
+  double dx, du;
+  const double *f, *fx, *fu, *Xp, *Up, *Q, *R, *Xr, *Ur, *lx, *ux, *lu, *uu, *cons_lo, *cons_hi, *slew, *slew0, *um1;
+  double *af, *afx, *afu, *aXp, *aUp, *aQ, *aR, *aXr, *aUr, *alo, *ahi;
+};
+void launch_slew_augment(const SlewAug &g, hipStream_t s);
+void launch_slew_split(const double *Z, const double *W, double *X, double *U, long long rows, int x, int u, int N, int Nc,
+                       const double *cons_lo, const double *cons_hi, hipStream_t s);
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                       const double *params, double *f, double *fx, double *fu, hipStream_t s);
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,

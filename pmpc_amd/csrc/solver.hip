@@ -163,6 +163,7 @@ struct Workspace {
   long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
   double as_scale = 1.0;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
+  DevBuf sa_f, sa_fx, sa_fu, sa_Xp, sa_Up, sa_Q, sa_R, sa_Xr, sa_Ur, sa_lo, sa_hi, sa_Xo, sa_Uo, sa_cl, sa_ch;  // slew: increment form
   SlabBufs sx, su;
 };
 
@@ -416,7 +417,9 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol};
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol,
+                   &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
+                   &w.sa_cl, &w.sa_ch};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -565,7 +568,93 @@ int pmpc_lsoc_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   return solve_impl(c, p, info, verbose, true);
 }
 
+// Slew penalties on the MFMA path: restate the problem in control increments (kernels_slew.hip: state [x; u], control
+// u_j - u_{j-1}, control boxes -> boxes on the state), solve that plain problem, split the state back into (X, U).
+static bool slew_increment_form_applies(const pmpc_problem *p, bool soc) {
+  if (soc || !(p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0)) || (p->flags & PMPC_FORCE_GENERIC) || !(p->flags & PMPC_SYMMETRIC_COST))
+    return false;
+  if (p->N < 2) return false;  // N = 1: the reference's diagonal rule is not the plain penalty (lqp_utils.jl:31-39)
+  // With boxes the control boxes become STATE boxes of the restated problem: interior-point iteration only (no active-set
+  // rounds, no warm start from the previous set).  Measured (tools/debug/slew_paths.py): 1.8x - 2.6x
+  // slower cold and ~10x slower warm than the generic kernels' active-set rounds, and 1e-7 instead of 1e-10 from the oracle —
+  // so boxed slew problems stay on the generic kernels.  PMPC_SLEW_INCREMENT_BOXES=1 forces the restated form (measurements).
+  static const bool with_boxes = [] { const char *e = getenv("PMPC_SLEW_INCREMENT_BOXES"); return e && atoi(e) != 0; }();
+  if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && !with_boxes) return false;
+  LQArgs t;
+  memset(&t, 0, sizeof(t));
+  t.x = (int)(p->xdim + p->udim); t.u = (int)p->udim; t.N = (int)p->N; t.M = (int)p->M; t.sym_cost = 1;
+  return lq_fast_supported(t);
+}
+
+static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
+  HIP_CHECK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  Workspace &w = c->ws;
+  const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M, n = x + u;
+  const int Nc = p->Nc < 0 ? N : (int)p->Nc;
+  const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
+  const bool has_slew = p->flags & PMPC_HAS_SLEW, has_slew0 = p->flags & PMPC_HAS_SLEW0;
+  const size_t rows = (size_t)M * N, D8 = sizeof(double);
+  w.sa_f.ensure(rows * n * D8); w.sa_fx.ensure(rows * n * n * D8); w.sa_fu.ensure(rows * n * u * D8);
+  w.sa_Xp.ensure(rows * n * D8); w.sa_Up.ensure(rows * u * D8); w.sa_Q.ensure(rows * n * n * D8); w.sa_R.ensure(rows * u * u * D8);
+  w.sa_Xr.ensure(rows * n * D8); w.sa_Ur.ensure(rows * u * D8); w.sa_Xo.ensure(rows * n * D8); w.sa_Uo.ensure(rows * u * D8);
+  const bool boxes = has_xb || has_ub;
+  if (boxes) { w.sa_lo.ensure(rows * n * D8); w.sa_hi.ensure(rows * n * D8); }
+  if (w.zslew.bytes < (size_t)M * D8 || w.zum1.bytes < (size_t)M * u * D8) {
+    w.zslew.ensure((size_t)M * D8); w.zslew0.ensure((size_t)M * D8); w.zum1.ensure((size_t)M * u * D8);
+    HIP_CHECK(hipMemsetAsync(w.zslew.p, 0, (size_t)M * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, (size_t)M * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, (size_t)M * u * D8, s));
+  }
+  SlewAug g;
+  memset(&g, 0, sizeof(g));
+  g.x = x; g.u = u; g.N = N; g.M = M; g.Nc = Nc; g.has_xb = has_xb; g.has_ub = has_ub;
+  g.has_um1 = (has_slew0 && Nc >= 1) ? 1 : 0;  // the linear term -s0 u_0'u_{-1} exists only with consensus stages (lqp_utils.jl:165)
+  const double reg = std::min(p->reg_x, p->reg_u);  // the one regulariser of the restated problem; the excess goes into the cost blocks
+  g.dx = p->reg_x - reg; g.du = p->reg_u - reg;
+  g.f = p->f; g.fx = p->fx; g.fu = p->fu; g.Xp = p->X_prev; g.Up = p->U_prev; g.Q = p->Q; g.R = p->R; g.Xr = p->X_ref; g.Ur = p->U_ref;
+  g.lx = p->lx; g.ux = p->ux; g.lu = p->lu; g.uu = p->uu;
+  g.slew = has_slew ? p->slew_reg : w.zslew.d();
+  g.slew0 = has_slew0 ? p->slew_reg0 : w.zslew0.d();
+  g.um1 = has_slew0 ? p->slew_um1 : w.zum1.d();
+  if (has_ub && Nc > 0) {  // consensus controls: (global) particle 0's boxes, lqp_utils.jl:329-330
+    const size_t nc = (size_t)Nc * u;
+    w.sa_cl.ensure(nc * D8); w.sa_ch.ensure(nc * D8);
+    HIP_CHECK(hipMemcpyAsync(w.sa_cl.p, p->lu, nc * D8, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(w.sa_ch.p, p->uu, nc * D8, hipMemcpyDeviceToDevice, s));
+    if (c->multi()) {
+      broadcast(c, w.sa_cl.p, nc, ncclFloat64, 0);
+      broadcast(c, w.sa_ch.p, nc, ncclFloat64, 0);
+    }
+    g.cons_lo = w.sa_cl.d(); g.cons_hi = w.sa_ch.d();
+  }
+  g.af = w.sa_f.d(); g.afx = w.sa_fx.d(); g.afu = w.sa_fu.d(); g.aXp = w.sa_Xp.d(); g.aUp = w.sa_Up.d();
+  g.aQ = w.sa_Q.d(); g.aR = w.sa_R.d(); g.aXr = w.sa_Xr.d(); g.aUr = w.sa_Ur.d();
+  g.alo = boxes ? w.sa_lo.d() : nullptr; g.ahi = boxes ? w.sa_hi.d() : nullptr;
+  launch_slew_augment(g, s);
+
+  pmpc_problem q = *p;
+  q.xdim = (size_t)n;
+  q.flags &= ~(PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_HAS_UBOUNDS | PMPC_HAS_XBOUNDS | PMPC_PREV_IS_LAST_SOLUTION | PMPC_STATIC_CONS_BOUNDS);
+  if (boxes) q.flags |= PMPC_HAS_XBOUNDS;
+  q.reg_x = reg;
+  q.reg_u = 0.0;
+  q.f = g.af; q.fx = g.afx; q.fu = g.afu; q.X_prev = g.aXp; q.U_prev = g.aUp; q.Q = g.aQ; q.R = g.aR; q.X_ref = g.aXr; q.U_ref = g.aUr;
+  q.lx = g.alo; q.ux = g.ahi; q.lu = q.uu = nullptr;
+  q.slew_reg = q.slew_reg0 = q.slew_um1 = nullptr;
+  q.X_out = w.sa_Xo.d(); q.U_out = w.sa_Uo.d();
+  pmpc_info inf;
+  memset(&inf, 0, sizeof(inf));
+  const int st = solve_impl_body(c, &q, &inf, verbose, false);
+  if (st == 0) launch_slew_split(w.sa_Xo.d(), w.sa_Uo.d(), p->X_out, p->U_out, (long long)rows, x, u, N, (M > 1 || c->multi()) ? Nc : 0, g.cons_lo, g.cons_hi, s);
+  else fill_nan_outputs(c, p);
+  if (info) *info = inf;
+  return st;
+}
+
 static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
+  if (p->xdim > 0 && p->udim > 0 && p->N > 0 && p->M > 0 && p->Nc <= (long long)p->N && slew_increment_form_applies(p, soc))
+    return solve_slew_increment_form(c, p, info, verbose);
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
