@@ -382,10 +382,15 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // ------------------------------------------------------------------------------------------------
 // Loop structure as in k_bwd_as: the consensus stages and stage 0 go through the general body, the free stages j >= 1 through
 // a branch-free MAIN body, two per loop trip with the prefetch register sets swapping roles.
-// PF2: data requested two stages ahead (ring of three register sets) — the latency regime, up to 3 waves per SIMD; else one
-// stage ahead (two sets, 4 waves per SIMD: with more than 3072 particles per GPU the waves hide each other's latency)
+// PF2: data requested two stages ahead (ring of three register sets; the default); else one stage ahead (two sets).  Both fit
+// 4 waves per SIMD.
+// Memory instructions per stage (the sweep is bound by their count, not by bytes — DESIGN.md section 6): the per-control
+// inputs {base control, feed-forward, lower, upper, status} come in ONE load — lanes c = 0..3 and 7 of k-group g read one array
+// each through a per-lane pointer, quad / row DPP moves gather them in lane c = 0, the only lane whose decisions count; the
+// base state comes in ONE load (lane c < KS of k-group g owns row row0 + c) and the new state leaves in ONE store; the new
+// base control and the next feed-forward leave in ONE store (lanes c = 0 and 1 through a per-lane pointer).
 template <int XD, int UD, bool DEFECT, bool PF2>
-__global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
+__global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
   constexpr bool PADX = (XD != LT::XP);
@@ -404,118 +409,128 @@ __global__ void __launch_bounds__(64, PF2 ? 3 : 4) k_fwd_as(LQArgs a) {
   const double *Xb = DEFECT ? a.X_prev : a.Xb, *Ub = DEFECT ? a.U_prev : a.Ub;
   // sign tolerance of the multipliers, in units of THIS particle's cost weight (a down-weighted particle of the cone path has
   // proportionally small multipliers: an absolute tolerance would freeze its weakly active bounds)
-  const double tol_l = (a.as_ctl ? a.as_ctl->tol_l : a.as_tol_l) * (a.pw ? a.pw[i] : 1.0);
+  const double pwi = a.pw ? a.pw[i] : 1.0;
+  const double tol_l = (a.as_ctl ? a.as_ctl->tol_l : a.as_tol_l) * pwi;
   // uniform stage bases + per-lane constant byte offsets (see k_bwd_as)
-  const unsigned lxr = (unsigned)(L.row0 * D8), lug = (unsigned)((gu ? g : 0) * D8), lrec = (unsigned)(lane * D8);
+  const unsigned lug = (unsigned)((gu ? g : 0) * D8), lrec = (unsigned)(lane * D8);
+  const bool own_x = c < KS && (!PADX || L.row0 + c < XD);  // this lane owns state row row0 + c
+  const unsigned lx1 = own_x ? (unsigned)((L.row0 + c) * D8) : 0u;
   const bool fK = L.cxv && gu;
   const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
   const double *Xb_ = ubase(Xb, px), *f_ = ubase(a.f, px), *Xo_ = ubase(a.Xo, px);
-  const double *Ub_ = ubase(Ub, pu), *Uo_ = ubase(a.Uo, pu), *kff_ = ubase(a.kff, pu), *lo_ = ubase(a.as_lo, pu), *hi_ = ubase(a.as_hi, pu);
   const double *act_ = ubase((const double *)a.as_act, pu >> 1), *K_ = ubase(a.K, (long long)(pbase * 64) * D8);
   auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
   auto uoff = [&](int jj) { return (long long)(jj * (int)(UD * D8)); };
-  const bool store_x = (c == 0), store_u = (c == 0) && gu;
-  const int src_grp = 16 * (c & 3);
-  auto ld_xrow = [&](const double *arr, int jj, double *dst) {
-    const double *b = ubase(arr, xoff(jj));
-#pragma unroll
-    for (int r = 0; r < KS; r++) {
-      const bool rv = !PADX || (L.row0 + r < XD);
-      const double v = ldo(b, rv ? lxr + r * 8u : 0u);
-      dst[r] = rv ? v : 0.0;
-    }
-  };
-  // what a stage needs when it starts: F, this lane's gain slot, feed-forward, status / box / base value of control g, base state
-  struct Pipe { double F[KS], K, k, lo, hi, ub, xb[KS], df[KS]; int act; };
-  int jF = 0;  // stage pF points at
-  auto fetch = [&](int jj, Pipe &q) {  // called in ascending stage order (a clamped repeat of the last stage leaves pF alone)
-    if (jj > jF) { pF = badd(pF, sF); jF = jj; }
+  // per-control inputs of control g: lanes c = 0..3 of the k-group read {U base, feed-forward, lower, upper}[c], lane 7 the status
+  const char *pG = (const char *)Z;
+  int sG = 0;
+  if (gu && c < 4) {
+    const double *arr = c == 0 ? Ub : (c == 1 ? a.kff : (c == 2 ? a.as_lo : a.as_hi));
+    pG = (const char *)(arr + pbase * UD + g);
+    sG = UD * (int)D8;
+  } else if (gu && c == 7) {  // 4-byte entries read as 8 bytes: the low word counts (the buffer ends with 8 spare bytes)
+    pG = (const char *)(a.as_act + pbase * UD + g);
+    sG = UD * (int)sizeof(int);
+  }
+  // outputs of control g: lane 0 -> new base control, lane 1 -> feed-forward of the next round
+  char *pS = (char *)((c == 1 ? a.kff : a.Uo) + pbase * UD + (gu ? g : 0));
+  const bool st_lane = gu && c < 2;
+  const bool store_u = (c == 0) && gu;
+  // what a stage needs when it starts: F, this lane's gain slot, the per-control word of this lane, this lane's base-state row
+  struct Pipe { double F[KS], K, grp, xb, f; };
+  int jF = 0;  // stage pF / pG point at
+  auto fetch = [&](int jj, Pipe &q) {  // called in ascending stage order (a clamped repeat of the last stage leaves the pointers alone)
+    if (jj > jF) { pF = badd(pF, sF); pG += sG; jF = jj; }
 #pragma unroll
     for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? pF[r] : 0.0;
     const double kv = ldo(ubase(K_, (long long)(jj * (int)(64 * D8))), lrec);
     q.K = fK ? kv : 0.0;
-    q.k = ldo(ubase(kff_, uoff(jj)), lug);  // (k-groups >= udim read control 0 and ignore it, here and below)
-    q.act = *(const int *)((const char *)ubase(act_, uoff(jj) >> 1) + (lug >> 1));
-    q.lo = ldo(ubase(lo_, uoff(jj)), lug);
-    q.hi = ldo(ubase(hi_, uoff(jj)), lug);
-    q.ub = ldo(ubase(Ub_, uoff(jj)), lug);
-    ld_xrow(Xb_, jj, q.xb);
-    if (DEFECT) {  // r = f - x_prev
-      double fr[KS];
-      ld_xrow(f_, jj, fr);
-#pragma unroll
-      for (int r = 0; r < KS; r++) q.df[r] = fr[r] - q.xb[r];
-    }
+    q.grp = *(const double *)pG;
+    q.xb = ldo(ubase(Xb_, xoff(jj)), lx1);
+    if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lx1);
   };
 
   double xcol = 0.0;  // dx[oc] on valid state columns
   int nrel = 0, nadd = 0, nbad = 0;
   double vworst = 0.0;
-  const double inv_dual = 1.0 / (a.as_ctl ? a.as_ctl->dual_scale : 1.0);
+  const double inv_dual = 1.0 / ((a.as_ctl ? a.as_ctl->dual_scale : 1.0) * pwi);
   auto stage = [&](auto main_tag, const int j, const Pipe &cur) {
     constexpr bool MAIN = decltype(main_tag)::value;
     double Fr[KS];
 #pragma unroll
     for (int r = 0; r < KS; r++) Fr[r] = (!MAIN && j == 0 && L.cxv) ? 0.0 : cur.F[r];  // A~_0 = 0
-    const int actc = cur.act;
-    const double loc = cur.lo, hic = cur.hi, ubc = cur.ub;
+    // gather the per-control inputs in lane c = 0 (the other lanes of the k-group compute on whatever they get: ignored)
+    const double ubc = cur.grp;                // lane 0's own word
+    const double kc = dpp_d<0x55>(cur.grp);    // quad broadcast of lane 1
+    const double loc = dpp_d<0xAA>(cur.grp);   // lane 2
+    const double hic = dpp_d<0xFF>(cur.grp);   // lane 3
+    const int actc = __builtin_amdgcn_mov_dpp(__double2loint(cur.grp), 0x141, 0xF, 0xF, true);  // half-row mirror: lane 7 -> lane 0
     // base control of this stage: in the first round of a warm start the caller's U_prev, which must already BE the base point
     // of the stored set (inside its box, exactly on the bound where held) — else the caller's promise does not hold
     if (DEFECT) {
       const double snapped = actc == 1 ? loc : (actc == 2 ? hic : fmin(fmax(ubc, loc), hic));
-      nbad |= (gu && !(snapped == ubc)) ? 1 : 0;  // (also catches an empty box and a NaN)
+      nbad |= (store_u && !(snapped == ubc)) ? 1 : 0;  // (also catches an empty box and a NaN)
     } else {
-      nbad |= (gu && !(loc <= hic)) ? 1 : 0;  // an empty box ends the solve as the reference's does (NaN outputs)
+      nbad |= (store_u && !(loc <= hic)) ? 1 : 0;  // an empty box ends the solve as the reference's does (NaN outputs)
     }
     // du[g] in every lane of k-group g: the shared consensus step (identical in every particle, so are the decisions)
     // resp. the feedback law on the (clamped) state
     double draw;
     if (!MAIN && j < Nc) draw = gu ? a.duc[j * UD + g] : 0.0;
-    else draw = -row_allsum(cur.K * xcol) - cur.k;
+    else draw = -row_allsum(cur.K * xcol) - kc;
     const bool cnt_here = store_u && (MAIN || j >= Nc || i == 0);
-    const bool held = gu && actc != 0;
+    const bool held = store_u && actc != 0;
     const double lam = actc == 1 ? -a.as_big * draw : a.as_big * draw;  // multiplier of the held side
     const bool release = held && lam < -tol_l;
     const double zt = ubc + draw;
-    const bool vlo = gu && !held && zt < loc - a.as_tol_p * fmax(1.0, fabs(loc));
-    const bool vhi = gu && !held && !vlo && zt > hic + a.as_tol_p * fmax(1.0, fabs(hic));
+    const bool vlo = store_u && !held && zt < loc - a.as_tol_p * fmax(1.0, fabs(loc));
+    const bool vhi = store_u && !held && !vlo && zt > hic + a.as_tol_p * fmax(1.0, fabs(hic));
     const int anew = release ? 0 : (vlo ? 1 : (vhi ? 2 : actc));
     // held: no step (a released control starts the next round from its bound); a control that would leave its box is clamped
     // onto the bound and held from now on.  The new base control is exactly the bound on every held control.
     const double unew = held ? ubc : (vlo ? loc : (vhi ? hic : zt));
     const double dug = unew - ubc;
-    nbad |= (gu && !(draw == draw)) ? 1 : 0;
+    nbad |= (store_u && !(draw == draw)) ? 1 : 0;
     nrel += (cnt_here && release) ? 1 : 0;
     nadd += (cnt_here && (vlo || vhi)) ? 1 : 0;
     {  // size of the violation behind a change (diagnostic / acceptance of changes at round-off level)
       const double pv = vlo ? (loc - zt) / fmax(1.0, fabs(loc)) : (vhi ? (zt - hic) / fmax(1.0, fabs(hic)) : 0.0);
-      const double dv = release ? -lam * inv_dual / (a.pw ? a.pw[i] : 1.0) : 0.0;
+      const double dv = release ? -lam * inv_dual : 0.0;
       vworst = fmax(vworst, cnt_here ? fmax(pv, dv) : 0.0);
     }
     const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
     const double du_c = L.cu ? t : 0.0;
-    if (store_u) {
-      *(double *)((char *)ubase(Uo_, uoff(j)) + lug) = unew;
-      *(int *)((char *)ubase(act_, uoff(j) >> 1) + (lug >> 1)) = anew;
-      // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
-      // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
-      if (MAIN || j >= Nc) *(double *)((char *)ubase(kff_, uoff(j)) + lug) = actc ? -draw : 0.0;
-      else if (i == 0) a.as_delta[j * UD + g] = dug;  // the consensus step as applied (settled particles: g_i += H_i delta)
+    // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
+    // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
+    const double knew = actc ? -draw : 0.0;
+    if (MAIN || j >= Nc) {
+      const double k1 = dpp_d<0x00>(knew);  // quad broadcast of lane 0
+      if (st_lane) *(double *)pS = (c == 0) ? unew : k1;
+    } else if (store_u) {
+      *(double *)pS = unew;
+      if (i == 0) a.as_delta[j * UD + g] = dug;  // the consensus step as applied (settled particles: g_i += H_i delta)
     }
+    pS += UD * (int)D8;
+    if (store_u) *(int *)((char *)ubase(act_, uoff(j) >> 1) + (lug >> 1)) = anew;
     const double ycol = L.cxv ? xcol : du_c;
     double xr[KS];
 #pragma unroll
-    for (int r = 0; r < KS; r++) xr[r] = row_allsum(Fr[r] * ycol) + (DEFECT ? cur.df[r] : 0.0);
-    if (store_x) {
-#pragma unroll
-      for (int r = 0; r < KS; r++)
-        if (!PADX || L.row0 + r < XD) *(double *)((char *)ubase(Xo_, xoff(j)) + lxr + r * 8u) = cur.xb[r] + xr[r];
+    for (int r = 0; r < KS; r++) {
+      xr[r] = row_allsum(Fr[r] * ycol);
+      if (DEFECT) xr[r] += (c == r && own_x) ? cur.f - cur.xb : 0.0;  // the defect r = f - x_prev: only the owner of the row adds it
     }
-    // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2
+    if (own_x) {
+      double mine = xr[0];
+#pragma unroll
+      for (int r = 1; r < KS; r++) mine = (c == r) ? xr[r] : mine;
+      *(double *)((char *)ubase(Xo_, xoff(j)) + lx1) = cur.xb + mine;
+    }
+    // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2; the owner of that row is lane
+    // c >> 2 of the k-group
     double nx = 0.0;
 #pragma unroll
     for (int r = 0; r < KS; r++) {
-      const double tt = __shfl(xr[r], src_grp, 64);
+      const double tt = __shfl(xr[r], 16 * (c & 3) + r, 64);
       nx = ((c >> 2) == r) ? tt : nx;
     }
     xcol = L.cxv ? nx : 0.0;
@@ -692,7 +707,9 @@ void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
 }
 template <int XD, int UD>
 void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
-  static const int m2 = getenv("PMPC_AS_FWD_PF2_MAXM") ? atoi(getenv("PMPC_AS_FWD_PF2_MAXM")) : 3072;
+  // (two-stage prefetch everywhere since the merged loads freed the registers for 4 waves per SIMD: +0.8 % at 4096 particles;
+  //  PMPC_AS_FWD_PF2_MAXM=<M> puts larger launches back on the one-stage variant)
+  static const int m2 = getenv("PMPC_AS_FWD_PF2_MAXM") ? atoi(getenv("PMPC_AS_FWD_PF2_MAXM")) : (1 << 30);
   const dim3 grd(a.M), blk(64);
   if (a.M <= m2) {
     if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true>), grd, blk, 0, s, a);

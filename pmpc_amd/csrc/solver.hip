@@ -1062,7 +1062,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // leaves nothing to copy.  Returns 0 accepted, 1 not settled, 2 numerical failure.
   auto active_set_fast = [&](double dual_scale, int mode, int max_rounds) -> int {
     const double big = 1e30, tol_p = 1e-13;
-    w.as_act.ensure(nu * sizeof(int)); w.as_cntp.ensure((size_t)M * 3 * sizeof(int)); w.as_settled.ensure((size_t)M * sizeof(int));
+    w.as_act.ensure(nu * sizeof(int) + 8); w.as_cntp.ensure((size_t)M * 3 * sizeof(int)); w.as_settled.ensure((size_t)M * sizeof(int));
     w.as_ctl.ensure(sizeof(AsCtl)); w.as_delta.ensure((size_t)std::max(nc, 1) * D8);
     int *act = (int *)w.as_act.p;
     AsCtl *ctl = (AsCtl *)w.as_ctl.p;
@@ -1197,7 +1197,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     // generic kernels: a check pass + rollout per round, decisions on the host.  `big` never meets a normal-sized term in a sum (the penalty's target is a ZERO step), so it only has to dwarf every
     // H_uu entry: gains, H_uu^-1 and the step of a held control come out ~1e-30 relative and -big du_b is its multiplier
     const double big = 1e30, tol_p = 1e-13;
-    w.as_act.ensure(nu * sizeof(int)); w.as_cnt.ensure(4 * sizeof(int) + 8);
+    w.as_act.ensure(nu * sizeof(int) + 8); w.as_cnt.ensure(4 * sizeof(int) + 8);
     int *act = (int *)w.as_act.p, *cnt = (int *)w.as_cnt.p;
     unsigned long long *worst_dev = (unsigned long long *)(cnt + 4);
     double *Xtry = w.dX2.d(), *Utry = w.dU2.d();  // (free here: the corrector's difference step is already applied)
