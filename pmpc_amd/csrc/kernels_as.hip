@@ -45,7 +45,7 @@ namespace {
 // with the two prefetch register sets swapping roles (no rotation moves); the consensus stages and stage 0 (no incoming
 // state) go through the general body afterwards.
 // MODE — how far ahead a stage's data is requested:
-//   0 lean   early data (F, R, um, gu, df) one stage ahead, mid / late data (Q, xm, gx, Du) behind the Cholesky phase of the
+//   0 lean   early data (F, R, control word, f) one stage ahead, mid / late data (Q, base state below) behind the Cholesky phase of the
 //            stage above: <= 128 registers, 4 waves per SIMD (more than 3072 particles per GPU: the waves hide each other's latency)
 //   1 deep   everything one full stage ahead (3 waves per SIMD)
 //   2 deep2  everything TWO stages ahead (2 waves per SIMD): with at most two waves per SIMD — small shards, the few unsettled
@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   const bool fR = L.cu && gu;
   const unsigned lR = (unsigned)((fR ? g + UD * L.cb : 0) * D8);
   const unsigned lxr = (unsigned)(L.row0 * D8), lxc = (unsigned)((L.cxv ? L.oc : 0) * D8);
-  const unsigned lug = (unsigned)((gu ? g : 0) * D8), luc = (unsigned)((L.cu ? L.cb : 0) * D8);
-  const double regx_c = L.cxv ? regx : 0.0, regu_c = L.cu ? regu : 0.0;
+  const unsigned lug = (unsigned)((gu ? g : 0) * D8);
+  const double regx_c = L.cxv ? regx : 0.0;
   const bool umask = L.cu && g == L.cb;
   const bool diag_x = L.cxv && ((c & 3) == g);
   bool dmask[KS];
@@ -106,8 +106,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   // particle-local bases once (scalar registers); per stage only `stage index * block size` is added on the scalar unit
   const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
   const double *Xb_ = ubase(Xb, px), *Xr_ = ubase(a.X_ref, px), *Xp_ = ubase(a.X_prev, px), *f_ = ubase(a.f, px);
-  const double *Ub_ = ubase(Ub, pu), *Ur_ = ubase(a.U_ref, pu), *Up_ = ubase(a.U_prev, pu), *kff_ = ubase(a.kff, pu);
-  const double *act_ = ubase((const double *)a.as_act, pu >> 1);
+  const double *kff_ = ubase(a.kff, pu);
   const double *Q_ = ubase(a.Q, (long long)(pbase * (XD * XD)) * D8), *R_ = ubase(a.R, (long long)(pbase * (UD * UD)) * D8);
   const double *K_ = ubase(a.K, (long long)(pbase * 64) * D8);
   auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
@@ -135,22 +134,19 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     if (DEFECT) return 0.0;
     return regx_c * (ldo(ubase(Xb_, xoff(jj)), lxc) - ldo(ubase(Xp_, xoff(jj)), lxc));
   };
-  auto ld_df = [&](int jj) -> double {  // dynamics defect of the base point on the state columns
-    if (!DEFECT) return 0.0;
-    const double d = ldo(ubase(f_, xoff(jj)), lxc) - ldo(ubase(Xp_, xoff(jj)), lxc);
-    return L.cxv ? d : 0.0;
-  };
-  auto ld_um = [&](int jj) -> double {  // pw (u - u_ref), k-group g (groups >= udim read control 0; R is zero on their lanes)
-    return pwt * (ldo(ubase(Ub_, uoff(jj)), lug) - ldo(ubase(Ur_, uoff(jj)), lug));
-  };
-  auto ld_gu = [&](int jj) -> double {  // pw reg_u (u - u_prev) on the control columns
-    if (DEFECT) return 0.0;
-    return regu_c * (ldo(ubase(Ub_, uoff(jj)), luc) - ldo(ubase(Up_, uoff(jj)), luc));
-  };
-  auto ld_Du = [&](int jj) -> double {  // penalty of a held control, on the diagonal lanes (XP + b, b)
-    const int act = *(const int *)((const char *)ubase(act_, uoff(jj) >> 1) + (luc >> 1));
-    return (umask && act) ? a.as_big : 0.0;
-  };
+  // Per-control inputs of a stage in ONE load (the sweep's memory instructions are a cost of their own, see k_fwd_as): through a
+  // per-lane pointer the control quad of k-group g (lanes XP .. XP + 3) reads {u base, u_ref, status}[g] in its lanes 0, 1, 2,
+  // and lane 15 - XP - b of k-groups 0 / 1 reads u base[b] / u_prev[b] (a row mirror takes them to the control column XP + b).
+  const char *pC = (const char *)Z;
+  int sC = 0;
+  if (gu && c == XP) { pC = (const char *)(Ub + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
+  else if (gu && c == XP + 1) { pC = (const char *)(a.U_ref + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
+  else if (gu && c == XP + 2) { pC = (const char *)(a.as_act + (pbase + N - 1) * UD + g); sC = -UD * (int)sizeof(int); }  // (read as 8 bytes: spare bytes behind the buffer)
+  else if (!DEFECT && g < 2 && 15 - XP - c >= 0 && 15 - XP - c < UD) {
+    pC = (const char *)((g == 0 ? Ub : a.U_prev) + (pbase + N - 1) * UD + (15 - XP - c));
+    sC = -UD * (int)D8;
+  }
+  const double regu_s = (L.cu && g < 2) ? (g == 0 ? regu : -regu) : 0.0;  // reg_u (u - u_prev): the two terms summed over the k-groups
   auto ld_R = [&](int jj) -> double {
     const double v = ldo(ubase(R_, (long long)(jj * (int)(UD * UD * D8))), lR);
     return fR ? v : 0.0;
@@ -161,24 +157,25 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     *(double *)((char *)ubase(K_, (long long)(jj * (int)(64 * D8))) + lrec) = v;
   };
 
-  // prefetch register set of one stage: what it needs the moment it starts (F, R, um, gu, df of the stage) and — DEEP — its
-  // mid / late data (Q, xm, gx of the stage BELOW it, its own Du) as well
-  struct Pipe { double F[KS], R, um, gu, df, Q[KS], xm[KS], gx, Du; };
-  int jF = N - 1;  // stage pF points at
-  auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves pF alone)
-    if (jj < jF) { pF = badd(pF, sF); jF = jj; }
+  // prefetch register set of one stage: what it needs the moment it starts (F, R, control word, f of the stage) and — DEEP —
+  // its mid / late data (Q and the base point of the stage BELOW it) as well
+  struct Pipe { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
+  int jF = N - 1;  // stage pF / pC point at
+  auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves the pointers alone)
+    if (jj < jF) { pF = badd(pF, sF); pC += sC; jF = jj; }
 #pragma unroll
     for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? pF[r] : 0.0;
     q.R = ld_R(jj);
-    q.um = ld_um(jj);
-    q.gu = ld_gu(jj);
-    q.df = ld_df(jj);
+    q.ctl = *(const double *)pC;
+    if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lxc);
   };
-  auto fetch_late = [&](int jj, int jbelow, Pipe &q) {  // Du of stage jj; Q, xm, gx of stage jbelow (= jj - 1, clamped at 0)
-    q.Du = ld_Du(jj);
-    q.gx = ld_gx(jbelow);
+  // Q and the base point of stage jbelow (= jj - 1, clamped at 0) on the state COLUMNS: one load per array; the row-distributed
+  // copy the Q x product needs is made by lane shuffles when the stage consumes it
+  auto fetch_late = [&](int jj, int jbelow, Pipe &q) {
     ld_Q(jbelow, q.Q);
-    ld_xm(jbelow, q.xm);
+    q.xb = ldo(ubase(Xb_, xoff(jbelow)), lxc);
+    q.xr = ldo(ubase(Xr_, xoff(jbelow)), lxc);
+    if (!DEFECT) q.xp = ldo(ubase(Xp_, xoff(jbelow)), lxc);
   };
 
   double S[KS], s_row[KS], s_col;
@@ -197,6 +194,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     s_col = L.cxv ? part + ld_gx(N - 1) : 0.0;
     col_to_row<KS>(s_col, g, s_row);
   }
+  // DEFECT: x_prev of the stage being processed = the base state the stage above loaded as ITS stage below
+  double xb_carry = DEFECT ? ldo(ubase(Xb_, xoff(N - 1)), lxc) : 0.0;
 
   // one stage.  MAIN: a free stage with j >= 1 (no branches).  Returns nothing; the caller stops after stage 0.
   auto stage = [&](auto main_tag, const int j, const Pipe &cur, Pipe &nxt) {
@@ -206,10 +205,18 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     double Fr[KS], Qc[KS], xm_row[KS], gx_c, Du_c;
 #pragma unroll
     for (int r = 0; r < KS; r++) Fr[r] = (!MAIN && j == 0 && L.cxv) ? 0.0 : cur.F[r];  // stage 0 has no incoming state: A~_0 = 0
-    const double Rc = cur.R, um_g = cur.um, df_c = cur.df, gu_c = cur.gu;
-    gx_c = cur.gx; Du_c = cur.Du;
+    const double Rc = cur.R;
+    // control word: quad broadcasts inside the control quad, row mirror for the column terms
+    const double um_g = pwt * (dpp_d<0x00>(cur.ctl) - dpp_d<0x55>(cur.ctl));  // pw (u - u_ref)[g] (R is zero outside the control quad)
+    const int act_g = __builtin_amdgcn_mov_dpp(__double2loint(cur.ctl), 0xAA, 0xF, 0xF, true);
+    Du_c = (umask && act_g) ? a.as_big : 0.0;  // penalty of a held control, on the diagonal lanes (XP + b, b)
+    const double gu_c = DEFECT ? 0.0 : regu_s * dpp_d<0x140>(cur.ctl);  // +reg_u u[b] in k-group 0, -reg_u u_prev[b] in k-group 1
+    const double df_c = (DEFECT && L.cxv) ? cur.f - xb_carry : 0.0;     // dynamics defect of the base point on the state columns
+    if (DEFECT) xb_carry = cur.xb;
+    gx_c = DEFECT ? 0.0 : regx_c * (cur.xb - cur.xp);
+    col_to_row<KS>(pwt_x * (cur.xb - cur.xr), g, xm_row);
 #pragma unroll
-    for (int r = 0; r < KS; r++) { xm_row[r] = cur.xm[r]; Qc[r] = cur.Q[r]; }
+    for (int r = 0; r < KS; r++) Qc[r] = cur.Q[r];
     // mid / late data of the stage below: DEEP issues it now (a full stage ahead: lowest latency, most registers), the lean
     // variant behind the Cholesky phase of this stage (its registers are free again by then; the loads still have the rest of
     // this stage and the head of the next to land — with 4 waves per SIMD interleaved that covers the memory latency)
@@ -222,10 +229,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
       for (int r = 0; r < KS; r++) s_row[r] += row_allsum(S[r] * df_c);
     }
     // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
-    double hp = Rc * um_g;
+    double hp = fma(Rc, um_g, gu_c);
 #pragma unroll
     for (int r = 0; r < KS; r++) hp = fma(Fr[r], s_row[r], hp);
-    const double h_col = grp_allsum(hp) + gu_c;
+    const double h_col = grp_allsum(hp);
     double hu[UD];
 #pragma unroll
     for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
