@@ -29,8 +29,9 @@
 #define PMPC_AS_DEEP_WAVES 3  // occupancy of the deep-pipeline variant
 #endif
 #ifndef PMPC_AS_DEEP2_MAXM
-#define PMPC_AS_DEEP2_MAXM 0  // particles per GPU up to which the two-stages-ahead variant runs (0: never — at x12 u4 its three
-                              // register sets do not fit 256 registers without spilling, and it lost to the one-stage variant)
+#define PMPC_AS_DEEP2_MAXM 1024  // particles per GPU up to which the two-stages-ahead variant runs full sweeps (the partial sweeps of
+                                 // the later rounds always use it); 0: never.  Since the merged loads (13 memory instructions per
+                                 // stage) its three register sets fit: 166 - 185 registers, no scratch
 #endif
 #ifndef PMPC_AS_PINGPONG
 #define PMPC_AS_PINGPONG 0    // main loop: two stages per trip, the prefetch register sets swap roles (0: one stage + rotation moves)
@@ -696,7 +697,9 @@ void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
   // waves per SIMD this launch brings (1024 SIMDs): <= 2 deep2, <= 3 deep, else lean (see k_bwd_as)
   static const int m2 = getenv("PMPC_AS_DEEP2_MAXM") ? atoi(getenv("PMPC_AS_DEEP2_MAXM")) : PMPC_AS_DEEP2_MAXM;
   static const int m1 = getenv("PMPC_AS_DEEP_MAXM") ? atoi(getenv("PMPC_AS_DEEP_MAXM")) : PMPC_AS_DEEP_WAVES * 1024;
-  const int mode = a.M <= m2 ? 2 : (a.M <= m1 ? 1 : 0);
+  int mode = a.M <= m2 ? 2 : (a.M <= m1 ? 1 : 0);
+  // the DEFECT instantiation of the deep variant needs 127 registers (4 waves per SIMD without help): never the lean one
+  if (a.defect && mode == 0) mode = 1;
   const dim3 grd(a.M), blk(64);
 #define PMPC_BWD_AS(SK, DF)                                                                      \
   do {                                                                                           \
