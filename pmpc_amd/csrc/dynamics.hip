@@ -112,8 +112,11 @@ __device__ __forceinline__ void Quadrotor::eval(long long idx, int N, const doub
 #undef BE
 }
 
+#ifndef PMPC_LIN_THREADS
+#define PMPC_LIN_THREADS 256  // the model is evaluated by the first UNITS threads; all of them stream the records out
+#endif
 template <class Model>
-__global__ void __launch_bounds__(64) k_linearize(int N, long long tot, const double *x0, const double *X_prev, const double *U_prev,
+__global__ void __launch_bounds__(PMPC_LIN_THREADS) k_linearize(int N, long long tot, const double *x0, const double *X_prev, const double *U_prev,
                                                   const double *params, double *f, double *fx, double *fu) {
   constexpr int X = Model::X, U = Model::U, UNITS = Model::UNITS;
   constexpr int REC = X + X * X + X * U, LD = REC | 1;  // odd record stride: conflict-free LDS stores
@@ -126,9 +129,9 @@ __global__ void __launch_bounds__(64) k_linearize(int N, long long tot, const do
   }
   __syncthreads();
   const int n = (int)((tot - first) < UNITS ? (tot - first) : UNITS);
-  for (int e = t; e < n * X; e += 64) f[first * X + e] = rec[(e / X) * LD + e % X];
-  for (int e = t; e < n * X * X; e += 64) fx[first * (X * X) + e] = rec[(e / (X * X)) * LD + X + e % (X * X)];
-  for (int e = t; e < n * X * U; e += 64) fu[first * (X * U) + e] = rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
+  for (int e = t; e < n * X; e += PMPC_LIN_THREADS) f[first * X + e] = rec[(e / X) * LD + e % X];
+  for (int e = t; e < n * X * X; e += PMPC_LIN_THREADS) fx[first * (X * X) + e] = rec[(e / (X * X)) * LD + X + e % (X * X)];
+  for (int e = t; e < n * X * U; e += PMPC_LIN_THREADS) fu[first * (X * U) + e] = rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
 }
 
 template <class Model>
@@ -137,7 +140,7 @@ void launch_model(int N, int M, const double *x0, const double *X_prev, const do
   const long long tot = (long long)M * N;
   constexpr int REC = Model::X + Model::X * Model::X + Model::X * Model::U, LD = REC | 1;
   const unsigned grid = (unsigned)((tot + Model::UNITS - 1) / Model::UNITS);
-  hipLaunchKernelGGL((k_linearize<Model>), dim3(grid), dim3(64), Model::UNITS * LD * sizeof(double), s, N, tot, x0, X_prev, U_prev,
+  hipLaunchKernelGGL((k_linearize<Model>), dim3(grid), dim3(PMPC_LIN_THREADS), Model::UNITS * LD * sizeof(double), s, N, tot, x0, X_prev, U_prev,
                      params, f, fx, fu);
 }
 
