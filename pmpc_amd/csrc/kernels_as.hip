@@ -461,6 +461,61 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   double xcol = 0.0;  // dx[oc] on valid state columns
   int nrel = 0, nadd = 0, nbad = 0;
   double vworst = 0.0;
+  // consensus step of k-group g when this wave solves the consensus system itself (a.cons_G block partials; Nc == 1): lane e
+  // sums entry e of [H | g] in block order — the same operations in every wave, so every particle applies the same step —,
+  // then a Cholesky solve on lane-uniform values (arithmetic of k_cons_small's single-thread solve)
+  double dcons = 0.0;
+  if (a.cons_G) {
+    constexpr int nH = UD * UD, E = nH + UD;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (lane < E) {
+      const double *src = lane < nH ? a.cons_tH + lane : a.cons_tg + (lane - nH);
+      const int stride = lane < nH ? nH : UD;
+      int k = 0;
+      for (; k + 3 < a.cons_G; k += 4) {
+        a0 += src[(size_t)k * stride];
+        a1 += src[(size_t)(k + 1) * stride];
+        a2 += src[(size_t)(k + 2) * stride];
+        a3 += src[(size_t)(k + 3) * stride];
+      }
+      for (; k < a.cons_G; k++) a0 += src[(size_t)k * stride];
+    }
+    const double acc = (a0 + a1) + (a2 + a3);
+    double Lm[UD][UD], y[UD];
+    bool cbad = false;
+#pragma unroll
+    for (int q = 0; q < UD; q++) {
+      double d = readlane_d(acc, q + UD * q);
+#pragma unroll
+      for (int k = 0; k < q; k++) d -= Lm[q][k] * Lm[q][k];
+      cbad |= !(d > 0.0);
+      d = sqrt(cbad ? 1.0 : d);
+      Lm[q][q] = d;
+#pragma unroll
+      for (int p = q + 1; p < UD; p++) {
+        double v = readlane_d(acc, q + UD * p);  // upper triangle (the only one the sweeps fill)
+#pragma unroll
+        for (int k = 0; k < q; k++) v -= Lm[p][k] * Lm[q][k];
+        Lm[p][q] = v / d;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < UD; p++) {
+      double v = -readlane_d(acc, nH + p);
+#pragma unroll
+      for (int k = 0; k < p; k++) v -= Lm[p][k] * y[k];
+      y[p] = v / Lm[p][p];
+    }
+#pragma unroll
+    for (int p = UD - 1; p >= 0; p--) {
+      double v = y[p];
+#pragma unroll
+      for (int k = p + 1; k < UD; k++) v -= Lm[k][p] * y[k];
+      y[p] = v / Lm[p][p];
+    }
+    dcons = gu ? pick<UD>(y, g) : 0.0;
+    if (cbad && i == 0 && lane == 0) *a.fail = 2;
+  }
   const double inv_dual = 1.0 / ((a.as_ctl ? a.as_ctl->dual_scale : 1.0) * pwi);
   auto stage = [&](auto main_tag, const int j, const Pipe &cur) {
     constexpr bool MAIN = decltype(main_tag)::value;
@@ -484,7 +539,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     // du[g] in every lane of k-group g: the shared consensus step (identical in every particle, so are the decisions)
     // resp. the feedback law on the (clamped) state
     double draw;
-    if (!MAIN && j < Nc) draw = gu ? a.duc[j * UD + g] : 0.0;
+    if (!MAIN && j < Nc) draw = a.cons_G ? dcons : (gu ? a.duc[j * UD + g] : 0.0);
     else draw = -row_allsum(cur.K * xcol) - kc;
     const bool cnt_here = store_u && (MAIN || j >= Nc || i == 0);
     const bool held = store_u && actc != 0;

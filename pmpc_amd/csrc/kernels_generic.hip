@@ -719,6 +719,17 @@ void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int 
                      solve_now ? 1 : 0, Lc, duc, fail);
 }
 
+// first stage alone: block partials [G][nc*nc] at tmp, [G][nc] at tmp + 64 nc^2 (the consumers sum them in block order)
+int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, hipStream_t s) {
+  const int nH = nc * nc;
+  static const int per = getenv("PMPC_CONS_PER_PARTIAL") ? atoi(getenv("PMPC_CONS_PER_PARTIAL")) : 256;  // particles per block partial
+  int G = (M + per - 1) / per;
+  if (G > 64) G = 64;
+  hipLaunchKernelGGL(k_cons_small, dim3(G), dim3(1024), 0, s, Hc_part, gc_part, M, nc, 1, tmp, tmp + (size_t)64 * nH, 0, nullptr, nullptr,
+                     nullptr);
+  return G;
+}
+
 size_t lq_generic_lds_bytes(const LQArgs &a) { return lds_doubles(a.x, a.u, a.n) * sizeof(double); }
 
 void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s) {

@@ -107,6 +107,10 @@ struct LQArgs {
   // sharded active-set rounds with a consensus horizon: the previous round's change counters ride behind [Hc | gc] in this
   // round's consensus all-reduce (0 off, 1 first round of an attempt: nothing to carry yet, 2 later rounds)
   int as_merge;
+  // single rank, Nc = 1, active-set rounds: the consensus system is summed over cons_G block partials and solved by every
+  // wave of the forward sweep itself (kernels_as.hip) — one launch less per round.  cons_G = 0: a.duc holds the step.
+  const double *cons_tH, *cons_tg;
+  int cons_G;
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
@@ -162,6 +166,7 @@ void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_generic(const LQArgs &a, hipStream_t s);
 void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s);
+int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, hipStream_t s);  // -> number of partials
 void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, bool with_H, double *Hg, double *tmp, bool solve_now,
                        double *Lc, double *duc, int *fail, hipStream_t s);
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,

@@ -323,7 +323,15 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
       if (a.as_merge == 2)
         launch_as_ctl(const_cast<AsCtl *>(a.as_ctl), nullptr, a.M, (const int *)w.fail.p, 0, 1, 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s, tl);
     };
-    if (nc * nc + nc <= 32) {
+    static const bool wave_solve = [] { const char *e = getenv("PMPC_AS_WAVE_CONS"); return !e || atoi(e) != 0; }();
+    a.cons_G = 0;
+    if (fast && a.as_act && factor && !c->multi() && a.Nc == 1 && wave_solve) {
+      // active-set round on one rank with one consensus stage: block partials only — every wave of the forward sweep sums
+      // them (same order everywhere) and solves the u x u system itself: the second launch of the reduction is gone
+      a.cons_G = launch_cons_partials(a.Hc_part, a.gc_part, a.M, nc, w.red_tmp.d(), s);
+      a.cons_tH = w.red_tmp.d();
+      a.cons_tg = w.red_tmp.d() + (size_t)64 * nc * nc;
+    } else if (nc * nc + nc <= 32) {
       const bool solve_now = !c->multi();
       launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
       if (!solve_now) {
