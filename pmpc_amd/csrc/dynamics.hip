@@ -186,8 +186,8 @@ __global__ void __launch_bounds__(256) k_scp_residual(const double *X, const dou
 }  // namespace
 
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
-                         double *out, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), s));
+                         double *out, hipStream_t s, bool zero_out) {
+  if (zero_out) HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), s));  // (else: the caller vouches that *out is 0)
   long long nb = (2 * rows * 4 + 255) / 256;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_scp_residual, dim3((unsigned)nb), dim3(256), 0, s, X, Xp, rows, x, U, Up, rows, u, (unsigned long long *)out);

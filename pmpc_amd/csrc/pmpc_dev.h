@@ -260,4 +260,4 @@ void launch_slew_split(const double *Z, const double *W, double *X, double *U, l
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                       const double *params, double *f, double *fx, double *fu, hipStream_t s);
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
-                         double *out, hipStream_t s);
+                         double *out, hipStream_t s, bool zero_out = true);

@@ -1473,6 +1473,7 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
   bool lin_ready = false;  // the linearisation of iteration `done` is already enqueued (valid speculation of the previous one)
   try {
     HIP_CHECK(hipSetDevice(c->device));
+    HIP_CHECK(hipMemsetAsync(res, 0, (size_t)steps * sizeof(double), c->stream));  // (the residual kernel takes a maximum into its slot)
     for (; done < steps; done++) {
       double *Xp = (done & 1) ? XB : XA, *Up = (done & 1) ? UB : UA, *Xo = (done & 1) ? XA : XB, *Uo = (done & 1) ? UA : UB;
       if (!lin_ready) {
@@ -1484,10 +1485,12 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
       p.flags = p0->flags | PMPC_STATIC_CONS_BOUNDS;
       if (done > 0 || !first_cold) p.flags |= PMPC_PREV_IS_LAST_SOLUTION;
       else p.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;
+      bool res_dirty = false;  // the slot was zeroed with all the others when the loop started; a repeat must zero it again
       auto follow_up = [&, Xp, Up, Xo, Uo](bool with_next_lin) {  // residual of this iteration (+ the next linearisation)
         {
           ProfScope ps(c, 7);
-          launch_scp_residual(Xo, Xp, Uo, Up, (long long)p.M * (long long)p.N, (int)p.xdim, (int)p.udim, res + done, c->stream);
+          launch_scp_residual(Xo, Xp, Uo, Up, (long long)p.M * (long long)p.N, (int)p.xdim, (int)p.udim, res + done, c->stream, res_dirty);
+          res_dirty = true;
         }
         if (c->multi()) allreduce(c, res + done, 1, ncclFloat64, ncclMax);
         if (with_next_lin && done + 1 < steps) {
