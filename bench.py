@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--soc", action="store_true", help="quadrotor only: add the thrust cone ||(tau_x,tau_y)|| <= 0.3 T per stage "
                     "(config E's constraint set, fp64; pmpc_lsoc_solve_device)")
     ap.add_argument("--repeats", type=int, default=4, help="extra repeats of the timed window from a fresh SCP start (spread; outside `value`)")
+    ap.add_argument("--trace-steps", action="store_true", help="print (interior-point iterations, active-set rounds, factorisations) of every "
+                    "SCP iteration of the first window to stderr")
     ap.add_argument("--python-loop", action="store_true", help="drive the SCP loop from Python (one linearise / solve / residual call per "
                     "iteration) instead of pmpc_scp_loop_device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -290,6 +292,9 @@ def main():
     elapsed = window(2 if args.profile_all else 1)
     prof = solver.profile_read()
     timed = list(hist[args.warmup:])
+    if args.trace_steps and rank == 0:
+        print("per SCP iteration (ipm iterations, active-set rounds, factorisations):",
+              [(h[1]["ipm_iters"], h[1]["active_set_rounds"], h[1]["structured_solves"]) for h in hist], file=sys.stderr)
     # ---- repeats of the same window from a fresh SCP start: spread of the measurement; the last one carries HIP events around
     #      every launch class and around the sub-problem (aff_solve) as a whole — outside the reported region ------------------
     rep_s = [elapsed]
