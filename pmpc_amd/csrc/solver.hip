@@ -336,7 +336,12 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
       launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
       if (!solve_now) {
         merged_exchange();
-        launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
+        if (fast && a.as_act && factor && a.Nc == 1 && wave_solve) {
+          // sharded active-set round: the all-reduced [Hc | gc] is ONE partial for the forward sweep's waves to solve
+          a.cons_G = 1; a.cons_tH = Hc; a.cons_tg = gc;
+        } else {
+          launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
+        }
       }
     } else {
       if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
