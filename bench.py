@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--soc", action="store_true", help="quadrotor only: add the thrust cone ||(tau_x,tau_y)|| <= 0.3 T per stage "
                     "(config E's constraint set, fp64; pmpc_lsoc_solve_device)")
     ap.add_argument("--repeats", type=int, default=4, help="extra repeats of the timed window from a fresh SCP start (spread; outside `value`)")
+    ap.add_argument("--thrust-min", type=float, default=0.0, help="quadrotor: lower box of the thrust as a fraction of the hover thrust "
+                    "(default 0: the thrust cone's apex is feasible; > 0 keeps every cone away from its apex)")
     ap.add_argument("--trace-steps", action="store_true", help="print (interior-point iterations, active-set rounds, factorisations) of every "
                     "SCP iteration of the first window to stderr")
     ap.add_argument("--python-loop", action="store_true", help="drive the SCP loop from Python (one linearise / solve / residual call per "
@@ -187,6 +189,8 @@ def main():
     M_loc = M_total // world
     if args.model == "quadrotor":
         prob = dyn.make_quadrotor_problem(M=M_total, N=N, Nc=Nc)
+        if args.thrust_min > 0.0:  # hover thrust = half the upper box (make_quadrotor_problem: T <= 2 m g)
+            prob["u_l"][..., 0] = args.thrust_min * 0.5 * prob["u_u"][..., 0]
         model, x, u = MODEL_QUADROTOR, 12, 4
     else:
         prob = dyn.make_unicycle_problem(M=M_total, N=N, Nc=Nc)
@@ -362,7 +366,8 @@ def main():
             "config": {"workload": (f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                     "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
                                     if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 else
-                                    f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u" + (" + thrust cone per stage (config E constraints, fp64)" if args.soc else ""))
+                                    f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u" + (" + thrust cone per stage (config E constraints, fp64)" if args.soc else "")
+                                    + (f", thrust >= {args.thrust_min} x hover" if args.thrust_min > 0.0 else ""))
                                    + f"; timed window = SCP iterations {w0}..{w1} from the cold start X_prev = x0, U_prev = U_ref "
                                      "(the active-set round count falls as the SCP loop converges, so the rate depends on the window)",
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",
