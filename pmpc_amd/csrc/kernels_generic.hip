@@ -13,6 +13,7 @@
 // A: the linearised dynamics chain (:219-303); consensus controls (first Nc stages) are shared
 // decision variables (:17-61, :231-244) -> per-particle condensed (H_i, g_i) summed over particles.
 #include "pmpc_dev.h"
+#include "as_ctl_dev.h"
 
 namespace {
 
@@ -636,12 +637,19 @@ __global__ void __launch_bounds__(256) k_cons_solve_blocked(const double *Hc, do
 // only, stored factor.
 __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, int with_H,
                                                      double *outH, double *outg, int solve_now, double *Lc, double *duc,
-                                                     int *fail) {
+                                                     int *fail, AsCtlCall pend) {
   __shared__ double red[32][33];
   __shared__ double y[8];
+  // one block more than partials when a round-control call rides along: it takes the decision about the PREVIOUS round
+  // (counters of its forward sweep -> done / status / tolerance of the next forward sweep), see as_ctl_dev.h
+  const int nblk = pend.ctl ? (int)gridDim.x - 1 : (int)gridDim.x;
+  if (pend.ctl && (int)blockIdx.x == nblk) {
+    as_ctl_block(pend.ctl, pend.cnt_part, pend.M, pend.fail, 1, 1, 0, pend.mirror, pend.mirror_seq, pend.seq, nullptr, pend.viol);
+    return;
+  }
   const int tid = threadIdx.x, e = tid & 31, pl = tid >> 5;
   const int nH = nc * nc, E = with_H ? nH + nc : nc;
-  const int per = (M + gridDim.x - 1) / gridDim.x, i0 = blockIdx.x * per, i1 = min(M, i0 + per);
+  const int per = (M + nblk - 1) / nblk, i0 = blockIdx.x * per, i1 = min(M, i0 + per);
   const bool isH = with_H && e < nH;
   double acc = 0.0;
   if (e < E) {
@@ -710,23 +718,23 @@ void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int 
   double *Hc = Hg, *gc = Hg + nH;
   if (G <= 1) {
     hipLaunchKernelGGL(k_cons_small, dim3(1), dim3(1024), 0, s, Hc_part, gc_part, M, nc, with_H ? 1 : 0, Hc, gc, solve_now ? 1 : 0,
-                       Lc, duc, fail);
+                       Lc, duc, fail, AsCtlCall{});
     return;
   }
   double *tH = tmp, *tg = tmp + (size_t)64 * nH;
-  hipLaunchKernelGGL(k_cons_small, dim3(G), dim3(1024), 0, s, Hc_part, gc_part, M, nc, with_H ? 1 : 0, tH, tg, 0, Lc, duc, fail);
+  hipLaunchKernelGGL(k_cons_small, dim3(G), dim3(1024), 0, s, Hc_part, gc_part, M, nc, with_H ? 1 : 0, tH, tg, 0, Lc, duc, fail, AsCtlCall{});
   hipLaunchKernelGGL(k_cons_small, dim3(1), dim3(1024), 0, s, (const double *)tH, (const double *)tg, G, nc, with_H ? 1 : 0, Hc, gc,
-                     solve_now ? 1 : 0, Lc, duc, fail);
+                     solve_now ? 1 : 0, Lc, duc, fail, AsCtlCall{});
 }
 
 // first stage alone: block partials [G][nc*nc] at tmp, [G][nc] at tmp + 64 nc^2 (the consumers sum them in block order)
-int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, hipStream_t s) {
+int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, const AsCtlCall &pend, hipStream_t s) {
   const int nH = nc * nc;
   static const int per = getenv("PMPC_CONS_PER_PARTIAL") ? atoi(getenv("PMPC_CONS_PER_PARTIAL")) : 256;  // particles per block partial
   int G = (M + per - 1) / per;
   if (G > 64) G = 64;
-  hipLaunchKernelGGL(k_cons_small, dim3(G), dim3(1024), 0, s, Hc_part, gc_part, M, nc, 1, tmp, tmp + (size_t)64 * nH, 0, nullptr, nullptr,
-                     nullptr);
+  hipLaunchKernelGGL(k_cons_small, dim3(G + (pend.ctl ? 1 : 0)), dim3(1024), 0, s, Hc_part, gc_part, M, nc, 1, tmp, tmp + (size_t)64 * nH, 0,
+                     nullptr, nullptr, nullptr, pend);
   return G;
 }
 

@@ -166,7 +166,19 @@ void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_generic(const LQArgs &a, hipStream_t s);
 void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s);
-int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, hipStream_t s);  // -> number of partials
+// a round-control call (k_as_ctl's arguments) that rides in the next consensus-partials launch instead of a launch of its own
+struct AsCtlCall {
+  AsCtl *ctl;  // null: nothing pending
+  const int *cnt_part;
+  int M;
+  const int *fail;
+  AsCtl *mirror;
+  unsigned long long *mirror_seq;
+  unsigned long long seq;
+  const double *viol;
+};
+int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, const AsCtlCall &pend,
+                         hipStream_t s);  // -> number of partials
 void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, bool with_H, double *Hg, double *tmp, bool solve_now,
                        double *Lc, double *duc, int *fail, hipStream_t s);
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,

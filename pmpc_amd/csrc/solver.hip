@@ -176,6 +176,7 @@ struct ProfCat {
 };
 
 struct pmpc_ctx {
+  AsCtlCall as_pend{};  // round control of the previous active-set round, to ride in the next consensus-partials launch (structured_solve)
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
   double partial_ms = 0.0;  // class 4 of the last pmpc_profile_read
   long long partial_n = 0;
@@ -328,7 +329,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
     if (fast && a.as_act && factor && !c->multi() && a.Nc == 1 && wave_solve) {
       // active-set round on one rank with one consensus stage: block partials only — every wave of the forward sweep sums
       // them (same order everywhere) and solves the u x u system itself: the second launch of the reduction is gone
-      a.cons_G = launch_cons_partials(a.Hc_part, a.gc_part, a.M, nc, w.red_tmp.d(), s);
+      a.cons_G = launch_cons_partials(a.Hc_part, a.gc_part, a.M, nc, w.red_tmp.d(), c->as_pend, s);
+      c->as_pend.ctl = nullptr;
       a.cons_tH = w.red_tmp.d();
       a.cons_tg = w.red_tmp.d() + (size_t)64 * nc * nc;
     } else if (nc * nc + nc <= 32) {
@@ -1102,6 +1104,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       launch_as_setup(st, mode, 0, act, p->U_out, big, s);
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     }
+    // (same conditions as the in-wave consensus solve of structured_solve: one rank, one consensus stage)
+    static const bool fuse_env = !(getenv("PMPC_AS_FUSE_CTL") && atoi(getenv("PMPC_AS_FUSE_CTL")) == 0) &&
+                                 !(getenv("PMPC_AS_WAVE_CONS") && atoi(getenv("PMPC_AS_WAVE_CONS")) == 0);
+    const bool fuse_ctl = fuse_env && !c->multi() && Nc == 1;
+    c->as_pend.ctl = nullptr;
     int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
     int n_batches_at_hook = -1000;  // batches waited for since the speculation hook fired (in THIS attempt)
     AsCtl h;
@@ -1135,6 +1142,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s);
           allreduce(c, ctl->cnt, 4, ncclInt32, ncclSum);
           launch_as_ctl(ctl, nullptr, M, (const int *)w.fail.p, 0, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
+        } else if (!last && fuse_ctl) {
+          // the decision about this round rides in the next round's consensus-partials launch (structured_solve): its factor
+          // sweep does not need it (settled particles leave it at once), its forward sweep sees it
+          c->as_pend = AsCtlCall{ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq,
+                                 b.as_viol};
         } else {
           launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s,
                         nullptr, b.as_viol);
