@@ -13,6 +13,7 @@
 // A: the linearised dynamics chain (:219-303); consensus controls (first Nc stages) are shared
 // decision variables (:17-61, :231-244) -> per-particle condensed (H_i, g_i) summed over particles.
 #include "pmpc_dev.h"
+#include <cstdlib>
 #include "as_ctl_dev.h"
 
 namespace {
@@ -635,6 +636,163 @@ __global__ void __launch_bounds__(256) k_cons_solve_blocked(const double *Hc, do
 // order by gridDim.x slices (stage 1: outH/outg hold one partial per slice) and a final single block
 // (stage 2, gridDim.x == 1, solve_now) sums the slices and solves the dense system.  with_H = 0: gradient
 // only, stored factor.
+// LDS-resident variant of k_cons_solve_blocked for 16 < nc <= 88 (the whole factor in LDS, 1024 threads, no global
+// read-modify-write between panels) with the inverses of the 16 x 16 diagonal blocks kept next to the factor: the panel solve
+// of the factorisation and both substitutions become small matrix products instead of 16-step dependent chains.
+// Lc: nc x nc factor (column-major lower) followed by ceil(nc / 16) inverse blocks of 16 x 17 doubles (for the vector-only
+// solves that follow a factorisation).  Same arithmetic order for every caller: all ranks get the same bits.
+__global__ void __launch_bounds__(1024) k_cons_solve_lds(const double *Hc, double *Lc, const double *gc, double *duc, int nc, int factor,
+                                                         int *fail) {
+  extern __shared__ double sm[];
+  double *Ls = sm;                          // factor, column-major, lower triangle
+  double *y = Ls + (size_t)nc * nc;         // right-hand side / solution
+  double *Dg = y + nc;                      // current diagonal block L_kk, Dg[l * 17 + c]
+  const int npan = (nc + 15) / 16;
+  double *Di = Dg + 16 * 17;                // inverses of ALL diagonal blocks, Di[p * 272 + l * 17 + c]
+  double *DiG = Lc + (size_t)nc * nc;
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  if (factor) {
+    for (int e = tid; e < nc * nc; e += nth) {
+      const int r = e % nc, cc = e / nc;
+      Ls[e] = r >= cc ? Hc[cc + (size_t)nc * r] : 0.0;  // lower triangle of L from the UPPER triangle of Hc
+    }
+    __syncthreads();
+    for (int kb = 0, pn = 0; kb < nc; kb += 16, pn++) {
+      const int bs = min(16, nc - kb), rem = nc - kb - bs;
+      if (tid < 64) {  // diagonal block: one wave, registers + readlane (as in k_cons_solve_blocked)
+        double a[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) a[cc] = (lane < bs && cc <= lane) ? Ls[(kb + lane) + (size_t)nc * (kb + cc)] : ((cc == lane) ? 1.0 : 0.0);
+        bool bad = false;
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+          double d = rl_d(a[p], p);
+          if (!(d > 0.0)) { bad = true; d = 1.0; }
+          const double sd = sqrt(d), rd = 1.0 / sd;
+          a[p] = (lane == p) ? sd : a[p] * rd;
+#pragma unroll
+          for (int cc = p + 1; cc < 16; cc++) {
+            const double t = rl_d(a[p], cc);
+            a[cc] = (lane >= cc) ? fma(-a[p], t, a[cc]) : a[cc];
+          }
+        }
+        if (bad && lane == 0) *fail = 2;
+        if (lane < 16) {
+#pragma unroll
+          for (int cc = 0; cc < 16; cc++) {
+            Dg[lane * 17 + cc] = a[cc];
+            if (lane < bs && cc <= lane) Ls[(kb + lane) + (size_t)nc * (kb + cc)] = a[cc];
+          }
+        }
+        // inverse of the block: lane c < 16 solves L x = e_c (column c of L^-1) by forward substitution on its own registers,
+        // rows of L broadcast by readlane from the lanes that hold them
+        double xcol[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          double v = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = 0; k < r; k++) v = fma(-rl_d(a[k], r), xcol[k], v);  // a[k] in lane r = L[r][k]
+          xcol[r] = v / rl_d(a[r], r);
+        }
+        if (lane < 16) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) Di[pn * 272 + r * 17 + lane] = (r >= lane) ? xcol[r] : 0.0;
+        }
+      }
+      __syncthreads();
+      // panel below the block: X = A L_kk^-T, i.e. X[R][c] = sum_{k <= c} A[R][k] Linv[c][k]: independent entries
+      for (int e = tid; e < rem * 16; e += nth) {
+        const int r = e % rem, cc = e / rem;
+        if (cc < bs) {
+          const int R = kb + bs + r;
+          double v = 0.0;
+          for (int k = 0; k <= cc; k++) v = fma(Ls[R + (size_t)nc * (kb + k)], Di[pn * 272 + cc * 17 + k], v);
+          // results go to a scratch column block first (the inputs of other entries of the same row are still being read)
+          sm[(size_t)nc * nc + nc + 16 * 17 + npan * 272 + (size_t)cc * nc + r] = v;
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < rem * bs; e += nth) {
+        const int r = e % rem, cc = e / rem;
+        Ls[(kb + bs + r) + (size_t)nc * (kb + cc)] = sm[(size_t)nc * nc + nc + 16 * 17 + npan * 272 + (size_t)cc * nc + r];
+      }
+      __syncthreads();
+      // trailing update, 4 x 4 register tiles over the lower triangle
+      const int nb4 = (rem + 3) / 4, total = nb4 * (nb4 + 1) / 2, base = kb + bs;
+      for (int e = tid; e < total; e += nth) {
+        int br = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while (br * (br + 1) / 2 > e) br--;
+        while ((br + 1) * (br + 2) / 2 <= e) br++;
+        const int bc = e - br * (br + 1) / 2, r0 = 4 * br, c0 = 4 * bc;
+        double acc[4][4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) acc[ii][jj] = 0.0;
+        for (int k = 0; k < bs; k++) {
+          double pr[4], pc[4];
+#pragma unroll
+          for (int ii = 0; ii < 4; ii++) {
+            pr[ii] = (r0 + ii < rem) ? Ls[(base + r0 + ii) + (size_t)nc * (kb + k)] : 0.0;
+            pc[ii] = (c0 + ii < rem) ? Ls[(base + c0 + ii) + (size_t)nc * (kb + k)] : 0.0;
+          }
+#pragma unroll
+          for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) acc[ii][jj] = fma(pr[ii], pc[jj], acc[ii][jj]);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+          for (int jj = 0; jj < 4; jj++) {
+            const int rr = r0 + ii, cc = c0 + jj;
+            if (rr < rem && cc <= rr) Ls[(base + rr) + (size_t)nc * (base + cc)] -= acc[ii][jj];
+          }
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < nc * nc; e += nth) Lc[e] = Ls[e];
+    for (int e = tid; e < npan * 272; e += nth) DiG[e] = Di[e];
+  } else {
+    for (int e = tid; e < nc * nc; e += nth) Ls[e] = Lc[e];
+    for (int e = tid; e < npan * 272; e += nth) Di[e] = DiG[e];
+  }
+  for (int e = tid; e < nc; e += nth) y[e] = -gc[e];
+  __syncthreads();
+  for (int kb = 0, pn = 0; kb < nc; kb += 16, pn++) {  // L z = b
+    const int bs = min(16, nc - kb), rem = nc - kb - bs;
+    double v = 0.0;
+    if (tid < bs)
+      for (int k = 0; k <= tid; k++) v = fma(Di[pn * 272 + tid * 17 + k], y[kb + k], v);
+    __syncthreads();
+    if (tid < bs) y[kb + tid] = v;
+    __syncthreads();
+    for (int r = tid; r < rem; r += nth) {
+      const int R = kb + bs + r;
+      double t = y[R];
+      for (int k = 0; k < bs; k++) t = fma(-Ls[R + (size_t)nc * (kb + k)], y[kb + k], t);
+      y[R] = t;
+    }
+    __syncthreads();
+  }
+  for (int pn = npan - 1; pn >= 0; pn--) {  // L' x = z
+    const int kb = pn * 16, bs = min(16, nc - kb);
+    double v = 0.0;
+    if (tid < bs)
+      for (int k = tid; k < bs; k++) v = fma(Di[pn * 272 + k * 17 + tid], y[kb + k], v);  // (L_kk^-T)[tid][k] = Linv[k][tid]
+    __syncthreads();
+    if (tid < bs) y[kb + tid] = v;
+    __syncthreads();
+    for (int r = tid; r < kb; r += nth) {
+      double t = y[r];
+      for (int k = 0; k < bs; k++) t = fma(-Ls[(kb + k) + (size_t)nc * r], y[kb + k], t);
+      y[r] = t;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nc; e += nth) duc[e] = y[e];
+}
+
 __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, int with_H,
                                                      double *outH, double *outg, int solve_now, double *Lc, double *duc,
                                                      int *fail, AsCtlCall pend) {
@@ -754,6 +912,34 @@ void launch_fwd_generic(const LQArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_fwd_generic, dim3(a.M), dim3(WV), (2 * a.n + a.u) * sizeof(double), s, a);
 }
 
+// [Hc | gc] in one pass: entries e < EH come from srcH (stride EH), the rest from srcG (stride EG); dst = [G][EH + EG]
+__global__ void __launch_bounds__(256) k_reduce_particles_hg(const double *srcH, const double *srcG, double *dst, int M, int EH, int EG) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int e = blockIdx.x * 64 + tx, E = EH + EG;
+  double acc = 0.0;
+  if (e < E) {
+    const double *src = e < EH ? srcH + e : srcG + (e - EH);
+    const int stride = e < EH ? EH : EG;
+    for (int i = blockIdx.y * 4 + ty; i < M; i += 4 * gridDim.y) acc += src[(size_t)i * stride];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && e < E) dst[(size_t)blockIdx.y * E + e] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+// Hg = [Hc | gc] (contiguous, as the all-reduce wants it) from the particle partials: two launches instead of four
+void launch_reduce_particles_hg(const double *Hc_part, const double *gc_part, double *tmp, double *Hg, int M, int nc, hipStream_t s) {
+  const int EH = nc * nc, E = EH + nc;
+  int gy = (M + 3) / 4;
+  if (gy > 64) gy = 64;
+  dim3 blk(64, 4), grd((E + 63) / 64, gy);
+  if (gy == 1) {
+    hipLaunchKernelGGL(k_reduce_particles_hg, grd, blk, 0, s, Hc_part, gc_part, Hg, M, EH, nc);
+  } else {
+    hipLaunchKernelGGL(k_reduce_particles_hg, grd, blk, 0, s, Hc_part, gc_part, tmp, M, EH, nc);
+    hipLaunchKernelGGL(k_reduce_particles, dim3((E + 63) / 64, 1), blk, 0, s, (const double *)tmp, Hg, gy, E);
+  }
+}
 void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s) {
   int gy = (M + 3) / 4;
   if (gy > 64) gy = 64;
@@ -768,6 +954,14 @@ void launch_reduce_particles(const double *src, double *tmp, double *dst, int M,
 
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s) {
+  // LDS-resident factor (+ inverse diagonal blocks + a 16-column scratch panel): up to nc = 80 inside 64 KB
+  const int npan = (nc + 15) / 16;
+  const size_t lds_full = ((size_t)nc * nc + nc + 16 * 17 + (size_t)npan * 272 + (size_t)16 * nc) * sizeof(double);
+  static const bool lds_on = !(getenv("PMPC_CONS_LDS") && atoi(getenv("PMPC_CONS_LDS")) == 0);
+  if (lds_on && nc > 16 && lds_full <= 64 * 1024) {
+    hipLaunchKernelGGL(k_cons_solve_lds, dim3(1), dim3(1024), lds_full, s, (const double *)Hc, Lc, gc, duc, nc, factor ? 1 : 0, fail);
+    return;
+  }
   const size_t lds = ((size_t)17 * nc + 16 * 17) * sizeof(double);
   if (nc > 16 && lds <= 64 * 1024)
     hipLaunchKernelGGL(k_cons_solve_blocked, dim3(1), dim3(256), lds, s, (const double *)Hc, Lc, gc, duc, nc, factor ? 1 : 0, fail);

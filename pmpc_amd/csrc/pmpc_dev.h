@@ -165,6 +165,7 @@ size_t lq_generic_lds_bytes(const LQArgs &a);
 void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_generic(const LQArgs &a, hipStream_t s);
+void launch_reduce_particles_hg(const double *Hc_part, const double *gc_part, double *tmp, double *Hg, int M, int nc, hipStream_t s);
 void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s);
 // a round-control call (k_as_ctl's arguments) that rides in the next consensus-partials launch instead of a launch of its own
 struct AsCtlCall {

@@ -346,8 +346,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
         }
       }
     } else {
-      if (factor) launch_reduce_particles(a.Hc_part, w.red_tmp.d(), Hc, a.M, nc * nc, s);
-      launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
+      if (factor) launch_reduce_particles_hg(a.Hc_part, a.gc_part, w.red_tmp.d(), Hc, a.M, nc, s);  // (gc sits right behind Hc)
+      else launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
       merged_exchange();
       launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
     }
@@ -715,7 +715,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
   w.red_tmp.ensure((size_t)64 * ((size_t)nc * nc + nc) * D8);
   w.Hg.ensure(((size_t)nc * nc + nc + 4) * D8);  // (+ 4: change counters of the active-set rounds, sharded runs)
-  w.Lc.ensure((size_t)nc * nc * D8); w.duc.ensure((size_t)nc * D8);
+  w.Lc.ensure(((size_t)nc * nc + (size_t)((nc + 15) / 16) * 272) * D8);  // (+ the inverse diagonal blocks of k_cons_solve_lds)
+  w.duc.ensure((size_t)nc * D8);
   w.sc.ensure(sizeof(IpmScal)); w.fail.ensure(sizeof(int)); w.xch.ensure((size_t)c->world * 8 * D8);
   const bool fresh_parts = w.part_sum.bytes == 0;
   w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_cnt.ensure(2 * PMPC_RED_BLOCKS * D8);
