@@ -87,8 +87,20 @@ __device__ __forceinline__ const double *ubase(const double *arr, long long off)
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (const double *)(((unsigned long long)hi << 32) | lo);
 }
+// loads / stores through pointers the compiler can no longer prove to be global (selected per lane between several arrays):
+// without the address-space cast they become FLAT instructions, which also tie up the LDS counter the lane shuffles wait on
+typedef const double __attribute__((address_space(1))) *gcptr_d;
+typedef double __attribute__((address_space(1))) *gptr_d;
+__device__ __forceinline__ double gld(const void *p) { return *(gcptr_d)(unsigned long long)p; }
+__device__ __forceinline__ void gst(void *p, double v) { *(gptr_d)(unsigned long long)p = v; }
 __device__ __forceinline__ double ldo(const double *base, unsigned boff) {  // uniform base + 32-bit byte offset
-  return *(const double *)((const char *)base + boff);
+  return *(gcptr_d)((const __attribute__((address_space(1))) char *)(unsigned long long)base + boff);
+}
+__device__ __forceinline__ void gsto(const double *base, unsigned boff, double v) {  // store, same addressing
+  *(gptr_d)((__attribute__((address_space(1))) char *)(unsigned long long)base + boff) = v;
+}
+__device__ __forceinline__ void gsto_i(const double *base, unsigned boff, int v) {
+  *(int __attribute__((address_space(1))) *)((__attribute__((address_space(1))) char *)(unsigned long long)base + boff) = v;
 }
 
 // unconditional load from a per-lane VALID address, zeroed by a select (no exec-mask branch);

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   const bool frec = (L.cxv || L.cu) && gu;
   const unsigned lrec = (unsigned)(lane * D8);
   auto st_rec = [&](int jj, double v) {  // this lane's slot of the stage's factor record: one coalesced 512-byte store
-    *(double *)((char *)ubase(K_, (long long)(jj * (int)(64 * D8))) + lrec) = v;
+    gsto(ubase(K_, (long long)(jj * (int)(64 * D8))), lrec, v);
   };
 
   // prefetch register set of one stage: what it needs the moment it starts (F, R, control word, f of the stage) and — DEEP —
@@ -166,9 +166,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves the pointers alone)
     if (jj < jF) { pF = badd(pF, sF); pC += sC; jF = jj; }
 #pragma unroll
-    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? pF[r] : 0.0;
+    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? gld(pF + r) : 0.0;
     q.R = ld_R(jj);
-    q.ctl = *(const double *)pC;
+    q.ctl = gld(pC);
     if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lxc);
   };
   // Q and the base point of stage jbelow (= jj - 1, clamped at 0) on the state COLUMNS: one load per array; the row-distributed
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     double kq = L.cu ? rec * pick<UD>(hu, L.cb) : 0.0;
     kq += dpp_d<0xB1>(kq);
     kq += dpp_d<0x4E>(kq);
-    if (c == XP && gu) *(double *)((char *)ubase(kff_, uoff(j)) + lug) = kq;
+    if (c == XP && gu) gsto(ubase(kff_, uoff(j)), lug, kq);
     if (!MAIN && j == 0) return;
     // ---- s_{j-1} = h_x - K' hu + g_x,j-1 -------------------------------------------------------------
     const double red2 = grp_allsum(fma(-Kreg, hug, p2q));
@@ -451,10 +451,10 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   auto fetch = [&](int jj, Pipe &q) {  // called in ascending stage order (a clamped repeat of the last stage leaves the pointers alone)
     if (jj > jF) { pF = badd(pF, sF); pG += sG; jF = jj; }
 #pragma unroll
-    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? pF[r] : 0.0;
+    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? gld(pF + r) : 0.0;
     const double kv = ldo(ubase(K_, (long long)(jj * (int)(64 * D8))), lrec);
     q.K = fK ? kv : 0.0;
-    q.grp = *(const double *)pG;
+    q.grp = gld(pG);
     q.xb = ldo(ubase(Xb_, xoff(jj)), lx1);
     if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lx1);
   };
@@ -569,13 +569,13 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     const double knew = actc ? -draw : 0.0;
     if (MAIN || j >= Nc) {
       const double k1 = dpp_d<0x00>(knew);  // quad broadcast of lane 0
-      if (st_lane) *(double *)pS = (c == 0) ? unew : k1;
+      if (st_lane) gst(pS, (c == 0) ? unew : k1);
     } else if (store_u) {
-      *(double *)pS = unew;
+      gst(pS, unew);
       if (i == 0) a.as_delta[j * UD + g] = dug;  // the consensus step as applied (settled particles: g_i += H_i delta)
     }
     pS += UD * (int)D8;
-    if (store_u) *(int *)((char *)ubase(act_, uoff(j) >> 1) + (lug >> 1)) = anew;
+    if (store_u) gsto_i(ubase(act_, uoff(j) >> 1), lug >> 1, anew);
     const double ycol = L.cxv ? xcol : du_c;
     double xr[KS];
 #pragma unroll
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       double mine = xr[0];
 #pragma unroll
       for (int r = 1; r < KS; r++) mine = (c == r) ? xr[r] : mine;
-      *(double *)((char *)ubase(Xo_, xoff(j)) + lx1) = cur.xb + mine;
+      gsto(ubase(Xo_, xoff(j)), lx1, cur.xb + mine);
     }
     // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2; the owner of that row is lane
     // c >> 2 of the k-group
