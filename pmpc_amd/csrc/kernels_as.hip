@@ -398,6 +398,16 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // each through a per-lane pointer, quad / row DPP moves gather them in lane c = 0, the only lane whose decisions count; the
 // base state comes in ONE load (lane c < KS of k-group g owns row row0 + c) and the new state leaves in ONE store; the new
 // base control and the next feed-forward leave in ONE store (lanes c = 0 and 1 through a per-lane pointer).
+//
+// MFMA form (r02; the first version of this sweep did the two products as row sums over DPP moves): per stage the state
+// update and the feedback are ONE 16 x 16 tile product,
+//     [dx_j ; K_{j+1}..] = [[fx_j, fu_j], [K_j, 0]] [dx_{j-1} ; du_j]   in two passes (K dx first: du needs it, then + B du),
+// and the C layout of the result (lane (c, g), register r <-> row g + 4r) is exactly the B-operand layout of the next
+// stage's state, so the state never moves between lanes: no row sums over DPP moves (36 per stage before), no lane
+// shuffles (2 LDS round trips per stage before).  The tile is the A operand: lanes (c, g) load T[c][g + 4r] — state rows from
+// fx / fu, the udim gain rows from the factor record — with one per-lane pointer, KS + 1 loads per stage (as many as before).
+// Columns 0..3 of the product carry the same state vector (so every lane of a k-group that stores or decides has it), the
+// other twelve stay zero.
 template <int XD, int UD, bool DEFECT, bool PF2>
 __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
@@ -411,23 +421,35 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   const size_t pbase = (size_t)i * N;
   const bool gu = g < UD;
   const double *Z = a.zeros;
-  const bool fF = L.cxv || L.cu;
-  const double *pF = L.cxv ? a.fx + pbase * (XD * XD) + XD * L.oc + L.row0
-                           : (L.cu ? a.fu + pbase * (XD * UD) + XD * L.cb + L.row0 : Z);
-  const int sF = fF ? (int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
+  // The stage matrix T = [[fx, fu], [K, 0]] ((XP + udim) x 16, kernel coordinates) as the A operand of the MFMA chain: this
+  // lane supplies T[rho = c][kappa = g + 4r], r = 0 .. KS (kappa < XP: state column, original index KS g + r; kappa = XP + g:
+  // control column g).  State rows rho < XP read fx / fu (original row pi(rho) = L.oc), gain rows rho = XP + b read row b of
+  // the factor record (record[kernel column + 16 b]); every other lane reads the zero buffer through a zero stride.
+  const double *pA = Z, *pB = Z;
+  int sAr = 0, sAj = 0, sBj = 0;  // byte strides: between the steps r < KS, between stages (A), between stages (B: step KS)
+  if (L.cxv) {
+    pA = a.fx + pbase * (XD * XD) + (size_t)XD * (KS * g) + L.oc;
+    sAr = XD * (int)D8; sAj = XD * XD * (int)D8;
+    if (gu) { pB = a.fu + pbase * (XD * UD) + (size_t)XD * g + L.oc; sBj = XD * UD * (int)D8; }
+  } else if (L.cu) {
+    pA = a.K + pbase * 64 + 16 * L.cb + g;
+    sAr = 4 * (int)D8; sAj = 64 * (int)D8;
+  }
+  bool vA[KS];  // (padding: state column KS g + r beyond xdim -> zero; the record holds zeros there already)
+#pragma unroll
+  for (int r = 0; r < KS; r++) vA[r] = !L.cxv || !PADX || (KS * g + r < XD);
   const double *Xb = DEFECT ? a.X_prev : a.Xb, *Ub = DEFECT ? a.U_prev : a.Ub;
   // sign tolerance of the multipliers, in units of THIS particle's cost weight (a down-weighted particle of the cone path has
   // proportionally small multipliers: an absolute tolerance would freeze its weakly active bounds)
   const double pwi = a.pw ? a.pw[i] : 1.0;
   const double tol_l = (a.as_ctl ? a.as_ctl->tol_l : a.as_tol_l) * pwi;
   // uniform stage bases + per-lane constant byte offsets (see k_bwd_as)
-  const unsigned lug = (unsigned)((gu ? g : 0) * D8), lrec = (unsigned)(lane * D8);
+  const unsigned lug = (unsigned)((gu ? g : 0) * D8);
   const bool own_x = c < KS && (!PADX || L.row0 + c < XD);  // this lane owns state row row0 + c
   const unsigned lx1 = own_x ? (unsigned)((L.row0 + c) * D8) : 0u;
-  const bool fK = L.cxv && gu;
   const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
   const double *Xb_ = ubase(Xb, px), *f_ = ubase(a.f, px), *Xo_ = ubase(a.Xo, px);
-  const double *act_ = ubase((const double *)a.as_act, pu >> 1), *K_ = ubase(a.K, (long long)(pbase * 64) * D8);
+  const double *act_ = ubase((const double *)a.as_act, pu >> 1);
   auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
   auto uoff = [&](int jj) { return (long long)(jj * (int)(UD * D8)); };
   // per-control inputs of control g: lanes c = 0..3 of the k-group read {U base, feed-forward, lower, upper}[c], lane 7 the status
@@ -445,21 +467,25 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   char *pS = (char *)((c == 1 ? a.kff : a.Uo) + pbase * UD + (gu ? g : 0));
   const bool st_lane = gu && c < 2;
   const bool store_u = (c == 0) && gu;
-  // what a stage needs when it starts: F, this lane's gain slot, the per-control word of this lane, this lane's base-state row
-  struct Pipe { double F[KS], K, grp, xb, f; };
-  int jF = 0;  // stage pF / pG point at
+  // what a stage needs when it starts: this lane's entries of T, the per-control word of this lane, this lane's base-state row
+  struct Pipe { double T[KS + 1], grp, xb, f; };
+  int jF = 0;  // stage the pointers point at
   auto fetch = [&](int jj, Pipe &q) {  // called in ascending stage order (a clamped repeat of the last stage leaves the pointers alone)
-    if (jj > jF) { pF = badd(pF, sF); pG += sG; jF = jj; }
+    if (jj > jF) { pA = badd(pA, sAj); pB = badd(pB, sBj); pG += sG; jF = jj; }
 #pragma unroll
-    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? gld(pF + r) : 0.0;
-    const double kv = ldo(ubase(K_, (long long)(jj * (int)(64 * D8))), lrec);
-    q.K = fK ? kv : 0.0;
+    for (int r = 0; r < KS; r++) {
+      const double t = gld((const char *)pA + (vA[r] ? r * sAr : 0));
+      q.T[r] = vA[r] ? t : 0.0;
+    }
+    q.T[KS] = gld(pB);
     q.grp = gld(pG);
     q.xb = ldo(ubase(Xb_, xoff(jj)), lx1);
     if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lx1);
   };
 
-  double xcol = 0.0;  // dx[oc] on valid state columns
+  double V[KS];  // dx in the MFMA's B / C layout: V[r] = dx[kernel row g + 4r], the same in every lane of the k-group that counts (c < 4)
+#pragma unroll
+  for (int r = 0; r < KS; r++) V[r] = 0.0;
   int nrel = 0, nadd = 0, nbad = 0;
   double vworst = 0.0;
   // consensus step of k-group g when this wave solves the consensus system itself (a.cons_G block partials; Nc == 1): lane e
@@ -520,9 +546,13 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   const double inv_dual = 1.0 / ((a.as_ctl ? a.as_ctl->dual_scale : 1.0) * pwi);
   auto stage = [&](auto main_tag, const int j, const Pipe &cur) {
     constexpr bool MAIN = decltype(main_tag)::value;
-    double Fr[KS];
+    // first pass: [A dx ; K dx] of the incoming state (stage 0 has none: A~_0 = 0 and nothing to feed back)
+    v4d D = {0.0, 0.0, 0.0, 0.0};
+    if (MAIN || j > 0) {
 #pragma unroll
-    for (int r = 0; r < KS; r++) Fr[r] = (!MAIN && j == 0 && L.cxv) ? 0.0 : cur.F[r];  // A~_0 = 0
+      for (int r = 0; r < KS; r++) D = mfma(cur.T[r], V[r], D);
+    }
+    const double raw = D[KS];  // (K dx)[g] in every lane of k-group g
     // gather the per-control inputs in lane c = 0 (the other lanes of the k-group compute on whatever they get: ignored)
     const double ubc = cur.grp;                // lane 0's own word
     const double kc = dpp_d<0x55>(cur.grp);    // quad broadcast of lane 1
@@ -541,7 +571,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     // resp. the feedback law on the (clamped) state
     double draw;
     if (!MAIN && j < Nc) draw = a.cons_G ? dcons : (gu ? a.duc[j * UD + g] : 0.0);
-    else draw = -row_allsum(cur.K * xcol) - kc;
+    else draw = -raw - kc;
     const bool cnt_here = store_u && (MAIN || j >= Nc || i == 0);
     const bool held = store_u && actc != 0;
     const double lam = actc == 1 ? -a.as_big * draw : a.as_big * draw;  // multiplier of the held side
@@ -563,8 +593,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       const double dv = release ? -lam * inv_dual : 0.0;
       vworst = fmax(vworst, cnt_here ? fmax(pv, dv) : 0.0);
     }
-    const double t = __shfl(dug, 16 * (L.cu ? L.cb : 0), 64);
-    const double du_c = L.cu ? t : 0.0;
+    const double du_q = dpp_d<0x00>(dug);  // the decision of lane 0, in the four lanes of the k-group whose columns are kept
     // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
     // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
     const double knew = actc ? -draw : 0.0;
@@ -577,28 +606,23 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     }
     pS += UD * (int)D8;
     if (store_u) gsto_i(ubase(act_, uoff(j) >> 1), lug >> 1, anew);
-    const double ycol = L.cxv ? xcol : du_c;
-    double xr[KS];
-#pragma unroll
-    for (int r = 0; r < KS; r++) {
-      xr[r] = row_allsum(Fr[r] * ycol);
-      if (DEFECT) xr[r] += (c == r && own_x) ? cur.f - cur.xb : 0.0;  // the defect r = f - x_prev: only the owner of the row adds it
+    // second pass: + B du.  The C layout of the result IS the B layout of the next stage's state: nothing moves.
+    D[KS] = 0.0;
+    D = mfma(cur.T[KS], (c < 4 && gu) ? du_q : 0.0, D);
+    if (DEFECT) {  // the defect r = f - x_prev of row KS g + r sits in lane c = r of the k-group: quad broadcasts
+      const double dfo = own_x ? cur.f - cur.xb : 0.0;
+      D[0] += dpp_d<0x00>(dfo);
+      if (KS > 1) D[1] += dpp_d<0x55>(dfo);
+      if (KS > 2) D[2] += dpp_d<0xAA>(dfo);
     }
     if (own_x) {
-      double mine = xr[0];
+      double mine = D[0];
 #pragma unroll
-      for (int r = 1; r < KS; r++) mine = (c == r) ? xr[r] : mine;
+      for (int r = 1; r < KS; r++) mine = (c == r) ? D[r] : mine;
       gsto(ubase(Xo_, xoff(j)), lx1, cur.xb + mine);
     }
-    // next column-distributed state: kernel column c lives in k-group c & 3, register c >> 2; the owner of that row is lane
-    // c >> 2 of the k-group
-    double nx = 0.0;
 #pragma unroll
-    for (int r = 0; r < KS; r++) {
-      const double tt = __shfl(xr[r], 16 * (c & 3) + r, 64);
-      nx = ((c >> 2) == r) ? tt : nx;
-    }
-    xcol = L.cxv ? nx : 0.0;
+    for (int r = 0; r < KS; r++) V[r] = (c < 4) ? D[r] : 0.0;  // (the other columns of the tile carry nothing: kept at zero)
   };
 
   const int jmin = Nc > 1 ? Nc : 1;  // MAIN covers the free stages jmin .. N-1
@@ -608,6 +632,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     // Prefetch distance: TWO stages.  With one wave per SIMD (small shards, the later rounds' few unsettled particles) a stage
     // of this sweep is shorter than the HBM latency, so data requested one stage ahead would still pin every stage to that
     // latency.  Three register sets in a ring; the main loop runs three stages per trip so that their roles are static (no moves).
+    // (Three stages ahead, four sets, four stages per trip: measured 40 % SLOWER at every size — not kept.)
     Pipe P0, P1, P2;
     fetch(0, P0);
     fetch(clampN(1), P1);
