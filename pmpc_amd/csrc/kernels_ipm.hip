@@ -439,7 +439,10 @@ __global__ void __launch_bounds__(TB) k_ipm_exchange(int phase, int do_pack, int
 // included), with complementarity exactly zero.  act: 0 free, 1 at the lower bound, 2 at the upper bound.
 __global__ void __launch_bounds__(TB) k_as_setup(Slab s, int from_ipm, int keep_base, int *act, double *ztry, double big) {
   for (long long k = blockIdx.x * (long long)TB + threadIdx.x; k < s.count; k += (long long)gridDim.x * TB) {
-    const double lo = s.lo[k], hi = s.hi[k], z = s.z[k];
+    const double lo = s.lo[k], hi = s.hi[k];
+    // shared controls: ONE base value for every particle — particle 0's (a caller's U_prev may not have them equal)
+    const long long per = (long long)s.N * s.d;
+    const double z = (s.is_u && (k / s.d) % s.N < s.Nc) ? s.z[k % per] : s.z[k];
     int a;
     if (from_ipm == 2) {  // cold: the boxes the equality-only optimum violates
       a = z < lo ? 1 : (z > hi ? 2 : 0);

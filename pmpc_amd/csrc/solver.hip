@@ -1101,7 +1101,10 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
       ProfScope ps(c, 5);
       Slab st = su;
-      st.z = w.U.d(); st.D = nullptr; st.w = nullptr;
+      // the previous solution: this context's copy, or — a caller inside an SCP loop that hands it back as U_prev (promise flag;
+      // no copy was kept then) with a consensus horizon the no-rollout start above does not cover — the caller's U_prev
+      st.z = (mode == 0 && !w.as_U_valid) ? const_cast<double *>(p->U_prev) : w.U.d();
+      st.D = nullptr; st.w = nullptr;
       launch_as_setup(st, mode, 0, act, p->U_out, big, s);
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     }
@@ -1295,7 +1298,10 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     return 1;
   };
   const bool as_can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && Nc <= 1 && fast;
-  if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || as_can_defect)) {
+  // (the caller's U_prev is the stored set's solution; one rank only: the shared controls' base must be the same on every rank,
+  //  which only this context's own copy guarantees when a caller breaks its promise)
+  const bool as_prev_is_base = fast && !c->multi() && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
+  if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || as_can_defect || as_prev_is_base)) {
     a.Dx = a.wx = nullptr;
     const int r = active_set_solve(w.as_scale, 0, 8);
     if (r == 0) return finish(0);

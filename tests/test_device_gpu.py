@@ -334,6 +334,10 @@ def test_scp_like_sequence_without_rollout(case, oracle):
         assert status == 0 and rel(Xl, Xo) < 1e-9 and rel(Ul, Uo) < 1e-9, (t, info, rel(Xl, Xo), rel(Ul, Uo))
         if t in (1, 2, 4):
             assert info["ipm_iters"] == 0 and info["active_set_rounds"] >= 1, (t, info)
+            # warm: the rounds alone, no equality-only solve in front of them (also with several consensus stages, where the
+            # base point is the caller's U_prev by rollout instead of the no-rollout start)
+            if Nc > 1 and t in (1, 2):
+                assert info["structured_solves"] == info["active_set_rounds"], (t, info)
     s.close()
 
 
