@@ -664,11 +664,18 @@ __global__ void __launch_bounds__(1024) k_cons_solve_lds(const double *Hc, doubl
 #pragma unroll
         for (int cc = 0; cc < 16; cc++) a[cc] = (lane < bs && cc <= lane) ? Ls[(kb + lane) + (size_t)nc * (kb + cc)] : ((cc == lane) ? 1.0 : 0.0);
         bool bad = false;
+        double rdv[16];  // reciprocal diagonal of the block's factor (lane-uniform)
 #pragma unroll
         for (int p = 0; p < 16; p++) {
           double d = rl_d(a[p], p);
           if (!(d > 0.0)) { bad = true; d = 1.0; }
-          const double sd = sqrt(d), rd = 1.0 / sd;
+          // 1 / sqrt(d) by the hardware seed + two Newton steps (full double accuracy; sqrt + divide on this dependent chain
+          // were most of the kernel's time for small systems)
+          double rd = __builtin_amdgcn_rsq(d);
+          rd = fma(rd, fma(-0.5 * d * rd, rd, 0.5), rd);
+          rd = fma(rd, fma(-0.5 * d * rd, rd, 0.5), rd);
+          const double sd = d * rd;
+          rdv[p] = rd;
           a[p] = (lane == p) ? sd : a[p] * rd;
 #pragma unroll
           for (int cc = p + 1; cc < 16; cc++) {
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(1024) k_cons_solve_lds(const double *Hc, doubl
           double v = (r == lane) ? 1.0 : 0.0;
 #pragma unroll
           for (int k = 0; k < r; k++) v = fma(-rl_d(a[k], r), xcol[k], v);  // a[k] in lane r = L[r][k]
-          xcol[r] = v / rl_d(a[r], r);
+          xcol[r] = v * rdv[r];
         }
         if (lane < 16) {
 #pragma unroll
