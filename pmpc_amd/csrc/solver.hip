@@ -1211,7 +1211,9 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     }
     // the next solve's warm start: a caller inside an SCP loop (promise flag) hands the solution back as U_prev, which is then
     // the base point itself — no copy; any other caller's next warm start snaps THIS copy into its boxes
-    w.as_U_valid = !(p->flags & PMPC_PREV_IS_LAST_SOLUTION);
+    // (sharded with several consensus stages: neither the no-rollout start nor the caller's U_prev serves — see the warm attempt
+    //  below — so the copy is kept there too)
+    w.as_U_valid = !(p->flags & PMPC_PREV_IS_LAST_SOLUTION) || (c->multi() && Nc > 1);
     if (w.as_U_valid) HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_out, nu * D8, hipMemcpyDeviceToDevice, s));
     outputs_written = true;
     w.as_key = as_key;  // the stored set (+ w.U) start the next solve of this shape

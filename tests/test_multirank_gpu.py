@@ -221,4 +221,4 @@ def test_bench_calling_pattern_sharded_over_mock_ranks():
 
     root = Path(__file__).resolve().parents[1]
     r = subprocess.run([sys.executable, "tools/debug/sharded_scp_loop.py", "64"], cwd=str(root), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "SHARDED_SCP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "SHARDED_SCP_OK" in r.stdout and "SHARDED_NCN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

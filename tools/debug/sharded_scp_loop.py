@@ -118,3 +118,59 @@ for world in (2, 4):
     print(f"library loop, world {world}: rel diff X {ex:.2e} U {eu:.2e}; residual diff {np.max(np.abs(rw / r1 - 1)):.1e}; ranks agree: {len({tuple(i) for i in infos}) == 1}")
     assert ex < 1e-9 and eu < 1e-9 and np.max(np.abs(rw / r1 - 1)) < 1e-9 and len({tuple(i) for i in infos}) == 1
 print("SHARDED_SCP_OK")
+
+
+# ---- full consensus (Nc = N) inside an SCP loop with the promise flags: every later solve must be warm (rounds only) on
+#      one rank and on mock ranks alike, and the sharded loop must equal the single-rank one ----
+def run_world_ncn(world, Mn=64, Nn=12):
+    from tests.support.problems import rand_problem
+    rng = np.random.default_rng(5)
+    args, kw = rand_problem(rng, Mn, Nn, 4, 2, 0.25)
+    x0, f0, fx0, fu0, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    pert = [(0.03 * rng.standard_normal(f0.shape), 1 + 0.03 * rng.standard_normal(fx0.shape), 1 + 0.03 * rng.standard_normal(fu0.shape)) for _ in range(4)]
+    Ml = Mn // world
+    _group[0] += 1
+    group, out, errs = _group[0], [None] * world, []
+
+    def rank_fn(rank):
+        try:
+            sl = slice(rank * Ml, (rank + 1) * Ml)
+            dev = lambda a: torch.tensor(np.ascontiguousarray(a[sl]), dtype=torch.float64, device="cuda")
+            T = lambda a: dev(np.swapaxes(a, -1, -2))
+            s = DeviceSolver(0)
+            if world > 1:
+                assert s.lib.pmpc_comm_init_mock(s.h, rank, world, group) == 0
+                s.rank, s.world = rank, world
+            Xp, Up, infos = X_prev.copy(), U_prev.copy(), []
+            for t in range(4):
+                f, fx, fu = f0 + pert[t][0], fx0 * pert[t][1], fu0 * pert[t][2]
+                X, U, status = s.lqp_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(Xp), U_prev=dev(Up), Q=T(Q), R=T(R), X_ref=dev(X_ref),
+                                           U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=-1, symmetric_cost=True, lu=dev(kw["u_l"]),
+                                           uu=dev(kw["u_u"]), static_cons_bounds=t > 0, prev_is_last_solution=t > 0)
+                s.sync()
+                assert status == 0
+                i = dict(s.last_info)
+                infos.append((i["ipm_iters"], i["active_set_rounds"], i["structured_solves"]))
+                Xp[sl], Up[sl] = X.cpu().numpy(), U.cpu().numpy()
+            out[rank] = (Xp[sl].copy(), Up[sl].copy(), infos)
+            s.close()
+        except Exception as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errs, errs
+    return np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out]), [o[2] for o in out]
+
+
+Xn, Un, in1 = run_world_ncn(1)
+print("full consensus, single rank (ipm, rounds, factorisations):", in1[0])
+assert all(i[0] == 0 and i[1] == i[2] for i in in1[0][1:]), "a later solve was not warm-started"
+for world in (2, 4):
+    Xw, Uw, infos = run_world_ncn(world)
+    eu = np.linalg.norm(Uw - Un) / np.linalg.norm(Un)
+    print(f"full consensus, world {world}: rel diff U {eu:.2e}; {infos[0]}; ranks agree: {len({tuple(i) for i in infos}) == 1}")
+    assert eu < 1e-9 and len({tuple(i) for i in infos}) == 1
+    assert all(i[0] == 0 and i[1] == i[2] for i in infos[0][1:]), "a later sharded solve was not warm-started"
+print("SHARDED_NCN_OK")
