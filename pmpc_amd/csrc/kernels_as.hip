@@ -564,6 +564,8 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     if (DEFECT) {
       const double snapped = actc == 1 ? loc : (actc == 2 ? hic : fmin(fmax(ubc, loc), hic));
       nbad |= (store_u && !(snapped == ubc)) ? 1 : 0;  // (also catches an empty box and a NaN)
+      // a shared control has ONE base value: the caller's U_prev must hold particle 0's in every particle
+      if (!MAIN && j < Nc) nbad |= (store_u && !(ubc == Ub[(size_t)j * UD + g])) ? 1 : 0;
     } else {
       nbad |= (store_u && !(loc <= hic)) ? 1 : 0;  // an empty box ends the solve as the reference's does (NaN outputs)
     }

@@ -604,6 +604,14 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
   bool kv[KS];  // k index g + 4r is a real state
 #pragma unroll
   for (int r = 0; r < KS; r++) kv[r] = (KS * g + r) < XD;
+  // no-rollout warm start (a.defect: the base point is the linearisation point, off the linearised dynamics by r_j = f_j -
+  // x_prev_j): the defects of the EARLIER consensus stages reach stage j's state as d_{j-1}, d_j = A~_j d_{j-1} + r_j, and the
+  // coupling block Y_j turns that into a term Y_j d_{j-1} of the condensed gradient which no backward sweep can form.  One
+  // more column (c = 0) through the same products, by the wave that owns the first tile.
+  const bool dd = a.defect != nullptr && blockIdx.y == 0;
+  double Dm[KS];
+#pragma unroll
+  for (int r = 0; r < KS; r++) Dm[r] = 0.0;
 
   for (int j = jstart; j < Nc; j++) {
     // A operand of A~_j: lane (c, g), step r <-> fx_j[pi(c)][pi(g + 4r)];  of Y_j: record[(g + 4r) + 16 c], rows c < UD
@@ -615,6 +623,22 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
       Yop[r] = (j > 0 && c < UD) ? rec[(g + 4 * r) + 16 * c] : 0.0;
     }
     const double *fu = a.fu + (pbase + j) * (XD * UD);
+    if (dd) {
+      v4d o = {0.0, 0.0, 0.0, 0.0}, n = {0.0, 0.0, 0.0, 0.0};
+      if (j > 0) {
+#pragma unroll
+        for (int r = 0; r < KS; r++) o = mfma(Yop[r], Dm[r], o);
+#pragma unroll
+        for (int r = 0; r < KS; r++) n = mfma(Aop[r], Dm[r], n);
+        if (c == 0 && g < UD) a.gc_part[(size_t)i * nc + j * UD + g] += o[0];
+      }
+#pragma unroll
+      for (int r = 0; r < KS; r++) {
+        const bool mine = c == 0 && kv[r];
+        const size_t e = (pbase + j) * XD + KS * g + r;
+        Dm[r] = mine ? n[r] + (a.defect[mine ? e : 0] - a.X_prev[mine ? e : 0]) : 0.0;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < COND_TPW; k++) {
       const int qt = 16 * (t0 + k);

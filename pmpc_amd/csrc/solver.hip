@@ -1094,10 +1094,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
     // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout, nothing
     // written before the sweep.  The forward sweep verifies that U_prev IS the base point of the stored set.
-    // (consensus horizons Nc <= 1 only: with several consensus stages the condensed gradient of stage j would also need
-    // Y_j d_{j-1}, d = the defect propagated FORWARD through the earlier consensus stages — a term no backward sweep can
-    // form; found by the config-B full-consensus test, which a single accepted round got wrong by 8 %)
-    const bool use_defect = mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && Nc <= 1;
+    // (with several consensus stages the condensed gradient of stage j also needs Y_j d_{j-1}, d = the defect propagated
+    // FORWARD through the earlier consensus stages — a term no backward sweep can form: the condensing kernel, which walks
+    // those stages forward anyway, carries d as one more column (k_cond_fast).  Found by the config-B full-consensus test,
+    // which a single accepted round without the term got wrong by 8 %)
+    const bool use_defect = mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
     if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
       ProfScope ps(c, 5);
       Slab st = su;
@@ -1299,7 +1300,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     }
     return 1;
   };
-  const bool as_can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && Nc <= 1 && fast;
+  const bool as_can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && fast;
   // (the caller's U_prev is the stored set's solution; one rank only: the shared controls' base must be the same on every rank,
   //  which only this context's own copy guarantees when a caller breaks its promise)
   const bool as_prev_is_base = fast && !c->multi() && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
