@@ -45,8 +45,7 @@ __device__ __forceinline__ void Unicycle::eval(long long idx, int N, const doubl
   const double n1 = u2 * sa * v0 + T * u1 * u2 * sa + u1 * ca - s0 * u2 * v0 - c0 * u1;
   const double n2 = -(u2 * ca * v0 - u1 * sa + T * u1 * u2 * ca) + c0 * u2 * v0 - s0 * u1;
   fo[0] = px + n1 * iu22; fo[1] = py + n2 * iu22; fo[2] = v0 + T * u1; fo[3] = a;
-  for (int k = 0; k < 16; k++) A[k] = 0.0;
-  for (int k = 0; k < 8; k++) B[k] = 0.0;
+  // (A and B arrive zeroed: the whole block clears the record buffer before the model runs, k_linearize)
   // column-major blocks: A[r + 4*t] = dF_r/dx_t
   A[0 + 4 * 0] = 1.0; A[1 + 4 * 1] = 1.0; A[2 + 4 * 2] = 1.0; A[3 + 4 * 3] = 1.0;
   A[0 + 4 * 2] = (u2 * sa - s0 * u2) * iu22;
@@ -87,8 +86,7 @@ __device__ __forceinline__ void Quadrotor::eval(long long idx, int N, const doub
   fo[9] = wx + dt * (tx - (Jz - Jy) * wy * wz) / Jx;
   fo[10] = wy + dt * (ty - (Jx - Jz) * wz * wx) / Jy;
   fo[11] = wz + dt * (tz - (Jy - Jx) * wx * wy) / Jz;
-  for (int k = 0; k < 144; k++) A[k] = 0.0;
-  for (int k = 0; k < 48; k++) B[k] = 0.0;
+  // (A and B arrive zeroed: the whole block clears the record buffer before the model runs, k_linearize)
 #define AE(r, t) A[(r) + 12 * (t)]
 #define BE(r, t) B[(r) + 12 * (t)]
   for (int k = 0; k < 12; k++) AE(k, k) = 1.0;
@@ -124,6 +122,9 @@ __global__ void __launch_bounds__(PMPC_LIN_THREADS) k_linearize(int N, long long
   extern __shared__ double rec[];
   const int t = threadIdx.x;
   const long long first = (long long)blockIdx.x * UNITS;
+  // the Jacobians are mostly zeros: cleared by all threads at once instead of ~200 serial LDS stores in every model thread
+  for (int e = t; e < UNITS * LD; e += PMPC_LIN_THREADS) rec[e] = 0.0;
+  __syncthreads();
   if (t < UNITS && first + t < tot) {
     double *mine = rec + t * LD;
     Model::eval(first + t, N, x0, X_prev, U_prev, params, mine, mine + X, mine + X + X * X);
