@@ -11,6 +11,9 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dims = [(12, 4), (12, 2), (10, 4), (8, 4), (6, 3), (5, 2), (4, 2), (4, 1), (3, 3), (2, 1), (9, 5), (13, 2)]
+if "--all-dims" in sys.argv:  # every (xdim, udim) pair the MFMA kernels are compiled for (fast_common.h, PMPC_FAST_DIMS)
+    dims = [(12, 4), (12, 3), (12, 2), (10, 4), (10, 2), (9, 4), (9, 3), (8, 4), (8, 2), (7, 3), (6, 4), (6, 3), (6, 2), (5, 3), (5, 2),
+            (4, 4), (4, 3), (4, 2), (4, 1), (3, 3), (3, 2), (3, 1), (2, 2), (2, 1), (1, 1)]
 worst, fails, solves = 0.0, [], 0
 t0 = time.time()
 for k in range(n):
