@@ -12,6 +12,7 @@
 // in all three stacks, so every store instruction writes 64 consecutive doubles (8-byte stores scattered inside each
 // thread's own 1152-byte block reached 1.9 TB/s; the staged version is write-bandwidth bound).
 #include "pmpc_dev.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace {
@@ -111,58 +112,12 @@ __device__ __forceinline__ void Quadrotor::eval(long long idx, int N, const doub
 #undef BE
 }
 
-#ifndef PMPC_LIN_THREADS
-#define PMPC_LIN_THREADS 256  // the model is evaluated by the first UNITS threads; all of them stream the records out
-#endif
-template <class Model>
-__global__ void __launch_bounds__(PMPC_LIN_THREADS) k_linearize(int N, long long tot, const double *x0, const double *X_prev, const double *U_prev,
-                                                  const double *params, double *f, double *fx, double *fu) {
-  constexpr int X = Model::X, U = Model::U, UNITS = Model::UNITS;
-  constexpr int REC = X + X * X + X * U, LD = REC | 1;  // odd record stride: conflict-free LDS stores
-  extern __shared__ double rec[];
-  const int t = threadIdx.x;
-  const long long first = (long long)blockIdx.x * UNITS;
-  // the Jacobians are mostly zeros: cleared by all threads at once instead of ~200 serial LDS stores in every model thread
-  for (int e = t; e < UNITS * LD; e += PMPC_LIN_THREADS) rec[e] = 0.0;
-  __syncthreads();
-  if (t < UNITS && first + t < tot) {
-    double *mine = rec + t * LD;
-    Model::eval(first + t, N, x0, X_prev, U_prev, params, mine, mine + X, mine + X + X * X);
-  }
-  __syncthreads();
-  const int n = (int)((tot - first) < UNITS ? (tot - first) : UNITS);
-  for (int e = t; e < n * X; e += PMPC_LIN_THREADS) f[first * X + e] = rec[(e / X) * LD + e % X];
-  for (int e = t; e < n * X * X; e += PMPC_LIN_THREADS) fx[first * (X * X) + e] = rec[(e / (X * X)) * LD + X + e % (X * X)];
-  for (int e = t; e < n * X * U; e += PMPC_LIN_THREADS) fu[first * (X * U) + e] = rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
-}
-
-template <class Model>
-void launch_model(int N, int M, const double *x0, const double *X_prev, const double *U_prev, const double *params, double *f,
-                  double *fx, double *fu, hipStream_t s) {
-  const long long tot = (long long)M * N;
-  constexpr int REC = Model::X + Model::X * Model::X + Model::X * Model::U, LD = REC | 1;
-  const unsigned grid = (unsigned)((tot + Model::UNITS - 1) / Model::UNITS);
-  hipLaunchKernelGGL((k_linearize<Model>), dim3(grid), dim3(PMPC_LIN_THREADS), Model::UNITS * LD * sizeof(double), s, N, tot, x0, X_prev, U_prev,
-                     params, f, fx, fu);
-}
-
-}  // namespace
-
-void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
-                      const double *params, double *f, double *fx, double *fu, hipStream_t s) {
-  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, s);
-  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, s);
-}
-
-// SCP residual of pmpc/scp_mpc.py:397-403: max over (particle, stage) of the 2-norms of X - X_prev and U - U_prev, in one
-// pass.  4 lanes share a row (each a contiguous quarter of it), 2-step quad sum; the maximum is taken over the SQUARED norms
-// (one square root per thread at the end, not per row), block max, then an atomic max on the bit pattern of the result.
-namespace {
-__global__ void __launch_bounds__(256) k_scp_residual(const double *X, const double *Xp, long long rows_x, int x, const double *U,
-                                                      const double *Up, long long rows_u, int u, unsigned long long *out_bits) {
+// one 256-thread block of the SCP residual (k_scp_residual's work; also run by extra blocks of k_linearize)
+__device__ __forceinline__ void residual_block(int bid, int nblk, const double *X, const double *Xp, long long rows_x, int x, const double *U,
+                                               const double *Up, long long rows_u, int u, unsigned long long *out_bits) {
   __shared__ double sh[256];
   const int sub = threadIdx.x & 3;
-  const long long grp = (blockIdx.x * 256LL + threadIdx.x) >> 2, ngrp = ((long long)gridDim.x * 256) >> 2;
+  const long long grp = (bid * 256LL + threadIdx.x) >> 2, ngrp = ((long long)nblk * 256) >> 2;
   const int qx = (x + 3) / 4, qu = (u + 3) / 4;
   double m = 0.0;
   for (long long r = grp; r < rows_x + rows_u; r += ngrp) {  // (the 4 lanes of a group run the same trip count)
@@ -185,15 +140,98 @@ __global__ void __launch_bounds__(256) k_scp_residual(const double *X, const dou
   }
   if (threadIdx.x == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(sh[0]));
 }
+struct ResArgs {  // residual of the iteration just finished, riding in the launch that linearises the next one (nblk = 0: none)
+  const double *X, *Xp, *U, *Up;
+  long long rows;
+  int x, u, nblk;
+  unsigned long long *out_bits;
+};
+#ifndef PMPC_LIN_THREADS
+#define PMPC_LIN_THREADS 256  // the model is evaluated by the first UNITS threads; all of them stream the records out
+#endif
+template <class Model>
+__global__ void __launch_bounds__(PMPC_LIN_THREADS) k_linearize(int N, long long tot, const double *x0, const double *X_prev, const double *U_prev,
+                                                  const double *params, double *f, double *fx, double *fu, ResArgs res) {
+  constexpr int X = Model::X, U = Model::U, UNITS = Model::UNITS;
+  {
+    const int glin = (int)gridDim.x - res.nblk;  // the last res.nblk blocks compute the residual (independent work, one launch)
+    if ((int)blockIdx.x >= glin) {
+      residual_block((int)blockIdx.x - glin, res.nblk, res.X, res.Xp, res.rows, res.x, res.U, res.Up, res.rows, res.u, res.out_bits);
+      return;
+    }
+  }
+  constexpr int REC = X + X * X + X * U, LD = REC | 1;  // odd record stride: conflict-free LDS stores
+  extern __shared__ double rec[];
+  const int t = threadIdx.x;
+  const long long first = (long long)blockIdx.x * UNITS;
+  // the Jacobians are mostly zeros: cleared by all threads at once instead of ~200 serial LDS stores in every model thread
+  for (int e = t; e < UNITS * LD; e += PMPC_LIN_THREADS) rec[e] = 0.0;
+  __syncthreads();
+  if (t < UNITS && first + t < tot) {
+    double *mine = rec + t * LD;
+    Model::eval(first + t, N, x0, X_prev, U_prev, params, mine, mine + X, mine + X + X * X);
+  }
+  __syncthreads();
+  const int n = (int)((tot - first) < UNITS ? (tot - first) : UNITS);
+  for (int e = t; e < n * X; e += PMPC_LIN_THREADS) f[first * X + e] = rec[(e / X) * LD + e % X];
+  for (int e = t; e < n * X * X; e += PMPC_LIN_THREADS) fx[first * (X * X) + e] = rec[(e / (X * X)) * LD + X + e % (X * X)];
+  for (int e = t; e < n * X * U; e += PMPC_LIN_THREADS) fu[first * (X * U) + e] = rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
+}
+
+template <class Model>
+void launch_model(int N, int M, const double *x0, const double *X_prev, const double *U_prev, const double *params, double *f,
+                  double *fx, double *fu, const ResArgs &res, hipStream_t s) {
+  const long long tot = (long long)M * N;
+  constexpr int REC = Model::X + Model::X * Model::X + Model::X * Model::U, LD = REC | 1;
+  const unsigned grid = (unsigned)((tot + Model::UNITS - 1) / Model::UNITS);
+  hipLaunchKernelGGL((k_linearize<Model>), dim3(grid + (unsigned)res.nblk), dim3(PMPC_LIN_THREADS), Model::UNITS * LD * sizeof(double), s, N, tot, x0,
+                     X_prev, U_prev, params, f, fx, fu, res);
+}
+
+}  // namespace
+
+static long long residual_blocks(long long rows) {
+  long long nb = (2 * rows * 4 + 255) / 256;
+  // one atomic max per block on ONE address: few blocks for small inputs (13 instead of 18 us at 512 particles x 50 stages),
+  // enough of them to cover the memory latency for large ones
+  const long long cap = rows >= 200000 ? 1024 : 256;
+  return nb > cap ? cap : nb;
+}
+
+void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
+                      const double *params, double *f, double *fx, double *fu, hipStream_t s) {
+  ResArgs none;
+  memset(&none, 0, sizeof(none));
+  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, none, s);
+  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, none, s);
+}
+
+// the same with the SCP residual of (Xr, Xrp, Ur, Urp) computed by extra blocks of the launch (the SCP loop's follow-up of an
+// iteration: residual of the iteration + linearisation of the next — independent work); *res_out must be 0 on entry
+void launch_linearize_with_residual(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
+                                    const double *params, double *f, double *fx, double *fu, const double *Xr, const double *Xrp,
+                                    const double *Ur, const double *Urp, int x, int u, double *res_out, hipStream_t s) {
+  ResArgs r;
+  r.X = Xr; r.Xp = Xrp; r.U = Ur; r.Up = Urp; r.rows = (long long)M * N; r.x = x; r.u = u;
+  r.nblk = (int)residual_blocks(r.rows);
+  r.out_bits = (unsigned long long *)res_out;
+  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, r, s);
+  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, r, s);
+}
+
+// SCP residual of pmpc/scp_mpc.py:397-403: max over (particle, stage) of the 2-norms of X - X_prev and U - U_prev, in one
+// pass.  4 lanes share a row (each a contiguous quarter of it), 2-step quad sum; the maximum is taken over the SQUARED norms
+// (one square root per thread at the end, not per row), block max, then an atomic max on the bit pattern of the result.
+namespace {
+__global__ void __launch_bounds__(256) k_scp_residual(const double *X, const double *Xp, long long rows_x, int x, const double *U,
+                                                      const double *Up, long long rows_u, int u, unsigned long long *out_bits) {
+  residual_block((int)blockIdx.x, (int)gridDim.x, X, Xp, rows_x, x, U, Up, rows_u, u, out_bits);
+}
 }  // namespace
 
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
                          double *out, hipStream_t s, bool zero_out) {
   if (zero_out) HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double), s));  // (else: the caller vouches that *out is 0)
-  long long nb = (2 * rows * 4 + 255) / 256;
-  // one atomic max per block on ONE address: few blocks for small inputs (13 instead of 18 us at 512 particles x 50 stages),
-  // enough of them to cover the memory latency for large ones
-  const long long cap = rows >= 200000 ? 1024 : 256;
-  if (nb > cap) nb = cap;
+  const long long nb = residual_blocks(rows);
   hipLaunchKernelGGL(k_scp_residual, dim3((unsigned)nb), dim3(256), 0, s, X, Xp, rows, x, U, Up, rows, u, (unsigned long long *)out);
 }

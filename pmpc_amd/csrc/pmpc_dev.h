@@ -272,5 +272,8 @@ void launch_slew_split(const double *Z, const double *W, double *X, double *U, l
                        const double *cons_lo, const double *cons_hi, hipStream_t s);
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                       const double *params, double *f, double *fx, double *fu, hipStream_t s);
+void launch_linearize_with_residual(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
+                                    const double *params, double *f, double *fx, double *fu, const double *Xr, const double *Xrp,
+                                    const double *Ur, const double *Urp, int x, int u, double *res_out, hipStream_t s);
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
                          double *out, hipStream_t s, bool zero_out = true);

@@ -1514,13 +1514,21 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
       else p.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;
       bool res_dirty = false;  // the slot was zeroed with all the others when the loop started; a repeat must zero it again
       auto follow_up = [&, Xp, Up, Xo, Uo](bool with_next_lin) {  // residual of this iteration (+ the next linearisation)
+        const bool next = with_next_lin && done + 1 < steps;
+        if (next && !res_dirty && !c->multi()) {  // both in ONE launch (independent work)
+          ProfScope ps(c, 6);
+          launch_linearize_with_residual(model, (int)p.N, (int)p.M, p.x0, Xo, Uo, params, F[cur ^ 1][0], F[cur ^ 1][1], F[cur ^ 1][2], Xo, Xp, Uo,
+                                         Up, (int)p.xdim, (int)p.udim, res + done, c->stream);
+          res_dirty = true;
+          return;
+        }
         {
           ProfScope ps(c, 7);
           launch_scp_residual(Xo, Xp, Uo, Up, (long long)p.M * (long long)p.N, (int)p.xdim, (int)p.udim, res + done, c->stream, res_dirty);
           res_dirty = true;
         }
         if (c->multi()) allreduce(c, res + done, 1, ncclFloat64, ncclMax);
-        if (with_next_lin && done + 1 < steps) {
+        if (next) {
           ProfScope ps(c, 6);
           launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xo, Uo, params, F[cur ^ 1][0], F[cur ^ 1][1], F[cur ^ 1][2], c->stream);
         }
