@@ -363,6 +363,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
 int fail_after_error(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info) {
   Workspace &w = c->ws;
   w.as_key = w.warm_key = w.soc_key = w.cons_key = w.xb_block_key = -1;
+  c->as_pend.ctl = nullptr;
   c->staged.clear();
   (void)hipGetLastError();
   try {
