@@ -98,17 +98,20 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
 
 #define PMPC_COLD_START 64u /* do not start the interior-point iteration from the iterate remembered from the previous
                                solve of the same shape (see "warm start" in DESIGN.md section 2) */
-#define PMPC_STATIC_CONS_BOUNDS 128u /* sharded runs: the caller guarantees that the bounds of the consensus controls (global
-                                       particle 0's lu / uu on the stages < Nc) are the ones of the previous solve of this shape,
-                                       as inside an SCP loop (pmpc/scp_mpc.py passes the same u_l / u_u every iteration): the
-                                       library reuses the copy it broadcast then instead of two collectives per solve */
+#define PMPC_STATIC_CONS_BOUNDS 128u /* the caller guarantees that the CONTENTS of lu / uu (same device arrays) are those of the
+                                       previous solve of this shape, as inside an SCP loop (pmpc/scp_mpc.py passes the same
+                                       u_l / u_u every iteration).  The library then reuses (a) its working copy of the control
+                                       boxes (the caller's, with global particle 0's on the consensus stages) and (b), sharded,
+                                       the consensus bounds it broadcast then instead of two collectives per solve.  This
+                                       promise is NOT checked on the device: a caller that changes lu / uu in place between
+                                       solves (a moving trust region) must leave the flag off. */
 #define PMPC_PREV_IS_LAST_SOLUTION 256u /* the caller guarantees that X_prev / U_prev ARE the X_out / U_out of the previous solve
-                                          of this shape and that lu / uu are unchanged, as in an SCP loop
-                                          (pmpc/scp_mpc.py:313,430: X_prev, U_prev = X, U).  A warm-started solve then takes
-                                          the linearisation point itself as its first base point — its dynamics defect is
-                                          f - X_prev, elementwise — instead of rolling the old controls out again (one
-                                          sequential sweep less).  Checked on the device: a broken promise costs time, not
-                                          correctness. */
+                                          of this shape, as in an SCP loop (pmpc/scp_mpc.py:313,430: X_prev, U_prev = X, U).
+                                          A warm-started solve then takes the linearisation point itself as its first base
+                                          point — its dynamics defect is f - X_prev, elementwise — instead of rolling the old
+                                          controls out again (one sequential sweep less).  Checked on the device (U_prev must be
+                                          the base point of the stored set under the boxes this solve uses): a broken promise
+                                          costs time, not correctness. */
 
 typedef struct pmpc_problem {
   size_t xdim, udim, N, M; /* M = particles held by THIS rank */

@@ -8,13 +8,19 @@
  *     z = [ U_cons (Nc*udim) ; U_free particle-major (M*Nf*udim) ; X particle-major (M*N*xdim) ]
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
- * this file.  PARITY PINNED ONLY WEAKLY: the reference's own tests hold no numeric
- * golden vector for this path (PMPC.jl/test/runtests.jl:33-41 asserts !isnan only) and
- * Julia/OSQP cannot run in the build container.  The one reference-produced output that
- * exists — the 50-row (obj, resid) table stored in examples/gpu_solver.ipynb, 4 digits,
- * M = 1, u-box — is reproduced through this assembly (tests/test_host_logic.py);
- * consensus (M > 1), slew and state-bound branches stay UNPINNED: they are held only by
- * the KKT certificate (lqp_oracle.py) and the reference's Python SCP loop run over it.
+ * this file.  PARITY PINNED by reference-held OUTPUT (the reference's own tests hold no numeric
+ * golden vector for this path — PMPC.jl/test/runtests.jl:33-41 asserts !isnan only — and
+ * Julia/OSQP cannot run in the build container): seven (obj, resid) tables that the
+ * reference's Julia + ECOS stack printed into its committed notebooks, 4 significant digits,
+ * transcribed by tests/golden/make_golden.py into tests/golden/ref_*.npz and reproduced
+ * through this assembly by tests/test_host_logic.py (CPU) and tests/test_golden_gpu.py (GPU):
+ * hard control boxes (examples/gpu_solver.ipynb), slew + log-barrier smoothing
+ * (tests/root_testing.ipynb cells 3-4), consensus with M = 20 / Nc = 5 and the
+ * eps-anchored particle weights (tests/root_testing.ipynb cells 10-11), and four more
+ * (DESIGN.md section 7).  Still UNPINNED by any reference output — nothing in the
+ * reference exercises them with recorded numbers: state boxes, slew_reg0 / slew_um1,
+ * M > 500, k < M; those are held by the KKT certificate (lqp_oracle.py), two independent
+ * derivations agreeing to 1e-15 and the reference's Python SCP loop run over this oracle.
  *
  * Every function cites the reference lines it follows.  Indices are 0-based here
  * (the reference is 1-based Julia); array layouts are the C-ABI layouts of

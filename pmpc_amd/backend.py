@@ -45,6 +45,10 @@ def jl2py(x, keep: int = 1):
 
 
 _BLOCK_BIT = {2: 0, 3: 1, 6: 2, 7: 3}  # positions of fx, fu, Q, R -> bit of the `rowmajor` mask (include/pmpc_abi.h)
+# True: always go through the reference's two symbols `c_lqp_solve` / `c_lcone_solve` with Fortran-contiguous arrays, exactly as
+# pmpc/static_backend.py:71-102 calls pmpcjl (host transposition included) — never through the row-major extension entries.
+REFERENCE_SYMBOLS_ONLY = False
+CALLS: Dict[str, int] = {}  # library entry point -> number of calls (tests assert which symbol a path used)
 
 
 def _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1):
@@ -79,7 +83,7 @@ def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, 
     for k, z in enumerate((x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg, slew_reg0, slew_um1)):
         z = np.asarray(z, dtype=np.float64)
         bit = _BLOCK_BIT.get(k)
-        if bit is not None and not z.flags.f_contiguous and z.transpose(3, 2, 0, 1).flags.c_contiguous:
+        if bit is not None and not REFERENCE_SYMBOLS_ONLY and not z.flags.f_contiguous and z.transpose(3, 2, 0, 1).flags.c_contiguous:
             # `py2jl` view of a C-ordered (M, N, row, col) stack: the blocks are row-major.  The reference transposes them on
             # the host here (f_style cast, static_backend.py:83-101); libpmpc_hip does it in HBM after the upload instead.
             rowmajor |= 1 << bit
@@ -94,6 +98,7 @@ def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, 
         extra = tuple(extra[:1]) + (rowmajor,)  # the `solver` string only selects the conic back end upstream
         if entry == "pmpc_lcone_solve_host":
             extra = extra + (cone_k,)  # the `k` setting cannot cross the reference's C ABI; the extension entry carries it
+    CALLS[entry] = CALLS.get(entry, 0) + 1
     getattr(lib, entry)(ptr(X_out), ptr(U_out), xdim, udim, N, M, int(Nc), *[ptr(a) for a in arrs[:14]], float(reg_x),
                         float(reg_u), *[ptr(a) for a in arrs[14:]], int(verbose), *extra)
     # pmpc/static_backend.py:103
@@ -111,6 +116,14 @@ def lcone_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, l
                 slew_um1, smooth_alpha=1e1, verbose=False, solver="ecos", k=None):
     """pmpc/static_backend.py:107-191.  `k` (the reference's worst-k setting, PMPC.jl/src/main.jl:204-227) is reachable only
     through pyjulia upstream; here it rides on the extension entry point `pmpc_lcone_solve_host`."""
+    if k is not None:
+        # main.jl:204-205: k = k >= 0 ? k : M.  k = 0 is legal upstream (the objective loses its epigraph offset) and k > M is
+        # not clamped there; neither is implemented here — refused instead of silently read as k = M
+        k = int(k)
+        if k < 0:
+            k = None
+        elif k == 0 or k > x0.shape[-1]:
+            raise ValueError(f"lcone_solve: k = {k} is not supported (1 <= k <= M = {x0.shape[-1]}, or negative / None for k = M)")
     extra = (float(smooth_alpha), str(solver).encode())
     return _call("c_lcone_solve", Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
                  slew_reg, slew_reg0, slew_um1, verbose, extra, cone_k=k)
@@ -139,9 +152,23 @@ def _aff_solve_stage_cone(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg
     s = _SOC_SOLVER
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
     tm = lambda a: torch.as_tensor(np.ascontiguousarray(np.swapaxes(a, -1, -2)), dtype=torch.float64, device="cuda")
+    # the reference applies extra_cstrs INSIDE its cone solve, i.e. together with the eps-anchored objective, smoothing and the
+    # worst-k setting (PMPC.jl/src/main.jl:293-316); this path minimises the plain sum with hard boxes: say so, do not ignore
+    ignored = [k for k in ("smooth_alpha", "smooth_cstr", "k", "weights") if solver_settings.get(k) is not None
+               and not (k == "smooth_alpha" and isinstance(solver_settings[k], float) and math.isnan(solver_settings[k]))]
+    if ignored:
+        raise ValueError(f"extra_cstrs (stage-wise second-order cone): solver_settings {ignored} are not supported together with a "
+                         "stage cone (this path minimises the plain sum of the particle costs with hard boxes)")
     u_int = solver_settings.get("soc_u_interior")
-    if u_int is None:  # box centre, pulled inside the cone along v if necessary is the caller's business: ask for it
-        u_int = 0.5 * (np.asarray(u_l)[0, 0] + np.asarray(u_u)[0, 0])
+    lo_all, hi_all = np.asarray(u_l, dtype=np.float64), np.asarray(u_u, dtype=np.float64)
+    if u_int is None:  # a point strictly inside EVERY stage's box: the centre of the intersection of the boxes
+        u_int = 0.5 * (lo_all.reshape(-1, lo_all.shape[-1]).max(0) + hi_all.reshape(-1, hi_all.shape[-1]).min(0))
+    u_int = np.asarray(u_int, dtype=np.float64).reshape(-1)
+    margin = float(np.dot(soc["v"], u_int) + soc["v0"] - np.linalg.norm(np.asarray(soc["W"]) @ u_int + soc["w0"]))
+    if not (np.all(lo_all < u_int) and np.all(u_int < hi_all) and margin > 0.0):
+        raise ValueError("extra_cstrs (stage-wise second-order cone): solver_settings['soc_u_interior'] must lie strictly inside "
+                         f"every stage's control box and the cone (cone margin {margin:.3e}); the default — the centre of the "
+                         "boxes' intersection — does not: pass one explicitly")
     Nc = solver_settings.get("Nc", -1)
     X, U, status = s.lsoc_solve(f=t(f), fx=tm(fx), fu=tm(fu), X_prev=t(X_prev), U_prev=t(U_prev), Q=tm(Q), R=tm(R), X_ref=t(X_ref),
                                 U_ref=t(U_ref), reg_x=float(reg_x), reg_u=float(reg_u), Nc=Nc, x0=t(x0), lu=t(u_l), uu=t(u_u),

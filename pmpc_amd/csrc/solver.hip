@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -255,15 +256,23 @@ struct ProfScope {  // HIP events on the solver's own stream around one launch (
   }
 };
 
-// wait until the device has published sequence number `want` into host-coherent memory: poll (a blit kernel + stream sync
-// costs ~25 us of idle GPU per read); fall back to a stream sync after ~2 s
-void wait_published(pmpc_ctx *c, volatile unsigned long long *seq, unsigned long long want) {
-  bool seen = false;
-  for (long long spin = 0; spin < (1LL << 31); spin++) {
-    if (*seq == want) { seen = true; break; }
-    __builtin_ia32_pause();
+// Poll a host-coherent word the device publishes into (a blit kernel + stream sync costs ~25 us of idle GPU per read).
+// Bounded by WALL-CLOCK time: after `limit_s` seconds of polling (a hung or very slow device) the caller falls back to a
+// stream synchronisation, which reports device errors.  The clock is read every 1024 polls only.
+template <class Pred>
+bool spin_until(Pred ready, double limit_s = 2.0) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    for (int k = 0; k < 1024; k++) {
+      if (ready()) return true;
+      __builtin_ia32_pause();
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) return ready();
   }
-  if (!seen) {
+}
+// wait until the device has published sequence number `want` into host-coherent memory; stream sync after 2 s of polling
+void wait_published(pmpc_ctx *c, volatile unsigned long long *seq, unsigned long long want) {
+  if (!spin_until([&] { return *seq == want; })) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (*seq != want) {
       fprintf(stderr, "pmpc_hip: device scalars were never published\n");
@@ -362,7 +371,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
 // device still takes work, status 2.  Never throws.
 int fail_after_error(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info) {
   Workspace &w = c->ws;
-  w.as_key = w.warm_key = w.soc_key = w.cons_key = w.xb_block_key = -1;
+  w.as_key = w.warm_key = w.soc_key = w.cons_key = w.xb_block_key = w.su_key = -1;
+  w.as_U_valid = false;
   c->as_pend.ctl = nullptr;
   c->staged.clear();
   (void)hipGetLastError();
@@ -815,14 +825,16 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   if (has_ub) {
     const double *lo = p->lu, *hi = p->uu;
     const long long sukey = ((((long long)u * 131 + N) * 1000003 + M) * 131 + Nc);
-    if (Nc > 0 && (M > 1 || c->multi()) && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && (p->flags & PMPC_STATIC_CONS_BOUNDS || !c->multi()) &&
-        w.su_key == sukey && w.su_src_lo == p->lu && w.su_src_hi == p->uu && w.su.lo.bytes >= nu * D8) {
-      // inside an SCP loop (the caller vouches: boxes unchanged) the working copy of the previous solve — the caller's boxes with
-      // particle 0's on the consensus stages — still stands: two 6.5 MB copies and a kernel per solve saved
+    if (Nc > 0 && (M > 1 || c->multi()) && (p->flags & PMPC_STATIC_CONS_BOUNDS) && w.su_key == sukey && w.su_src_lo == p->lu &&
+        w.su_src_hi == p->uu && w.su.lo.bytes >= nu * D8) {
+      // the caller vouches EXPLICITLY (PMPC_STATIC_CONS_BOUNDS, on any rank count) that the CONTENTS of lu / uu are those of the
+      // previous solve of this shape, as inside an SCP loop: the working copy made then — the caller's boxes with particle 0's on
+      // the consensus stages — still stands: two 6.5 MB copies and a kernel per solve saved.  Nothing on the device compares
+      // contents, so without the flag the copy is remade (a caller that moves a trust region in place just leaves the flag off).
       lo = w.su.lo.d(); hi = w.su.hi.d();
     } else if (Nc > 0 && (M > 1 || c->multi())) {  // consensus bounds = global particle 0's (lqp_utils.jl:329-330)
+      w.su_key = -1;  // (valid again only once every copy below is enqueued: a throw in between must not leave a half-built copy trusted)
       w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
-      w.su_key = sukey; w.su_src_lo = p->lu; w.su_src_hi = p->uu;
       HIP_CHECK(hipMemcpyAsync(w.su.lo.p, p->lu, nu * D8, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipMemcpyAsync(w.su.hi.p, p->uu, nu * D8, hipMemcpyDeviceToDevice, s));
       if (c->multi()) {
@@ -844,6 +856,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       }
       launch_cons_bounds(w.su.lo.d(), w.su.hi.d(), M, N, u, Nc, s);
       lo = w.su.lo.d(); hi = w.su.hi.d();
+      w.su_key = sukey; w.su_src_lo = p->lu; w.su_src_hi = p->uu;
     }
     setup_slab(su, w.su, nu, u, true, lo, hi, w.U.d(), w.dU.d());
   }
@@ -1170,12 +1183,10 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       // with the sequence number of the round that published it: wait for any of this batch's numbers
       {
         const unsigned long long lo_seq = c->as_seq - (unsigned long long)batch + 1, hi_seq = c->as_seq;
-        bool seen = false;
-        for (long long spin = 0; spin < (1LL << 31) && !seen; spin++) {
+        const bool seen = spin_until([&] {
           const unsigned long long v = *(volatile unsigned long long *)&c->mirror->as_seq;
-          if (v >= lo_seq && v <= hi_seq) seen = true;
-          else __builtin_ia32_pause();
-        }
+          return v >= lo_seq && v <= hi_seq;
+        });
         if (!seen) {
           HIP_CHECK(hipStreamSynchronize(s));
           const unsigned long long v = *(volatile unsigned long long *)&c->mirror->as_seq;
@@ -1554,6 +1565,16 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
     c->post_batch = nullptr;
     if (infos && done < steps) { memset(&infos[done], 0, sizeof(pmpc_info)); infos[done].status = 2; }
     fail_after_error(c, nullptr, nullptr);
+    // both trajectory pairs hold unfinished iterates now: NaN, as every single-solve entry does with its outputs (res[done..] is
+    // undefined); never throws
+    try {
+      const double nan = std::numeric_limits<double>::quiet_NaN();
+      const long long ex = (long long)p.M * p.N * p.xdim, eu = (long long)p.M * p.N * p.udim;
+      for (double *b : {XA, XB}) if (b) launch_fill(b, nan, ex, c->stream);
+      for (double *b : {UA, UB}) if (b) launch_fill(b, nan, eu, c->stream);
+      HIP_WARN(hipStreamSynchronize(c->stream));
+    } catch (...) {
+    }
   }
   if (last_in_out) *last_in_out = done & 1;
   return done;

@@ -46,7 +46,7 @@ class Problem(Mapping):
         self.M = kw.get("M")
         self.solver_settings = {}
         for name, value in _OPTION_DEFAULTS.items():
-            object.__setattr__(self, name, value)
+            setattr(self, name, value)
         # array fields: the caller's value where given, the default otherwise — both go through __setattr__, which checks the
         # shape against the inferred dimensions and tiles over the particle axis
         fields = _array_defaults(self._dims["N"], self._dims["xdim"], self._dims["udim"])
@@ -59,7 +59,8 @@ class Problem(Mapping):
                 setattr(self, name, value)
         for name in _DIM_MAP:
             setattr(self, name, fields[name])
-        self.__dict__.setdefault("Nc", 0)
+        if not hasattr(self, "Nc"):  # (a subclass may define Nc as a class attribute: pmpc/problem_struct.py:57-58)
+            self.Nc = 0
 
     # ---- dimensions ------------------------------------------------------------------------------------
     @staticmethod
