@@ -8,8 +8,9 @@
 namespace {
 
 __device__ inline void as_ctl_block(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch,
-                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq, double *tail, const double *viol) {
-  __shared__ int sh[3][1024];
+                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq, double *tail, const double *viol,
+                                                 const int *open_part = nullptr) {
+  __shared__ int sh[4][1024];
   __shared__ double shv[1024];
   if (ctl->done) {  // nothing ran in this round: republish (the host may be waiting on this sequence number)
     if (threadIdx.x == 0 && decide && last_of_batch && mirror) {
@@ -20,32 +21,35 @@ __device__ inline void as_ctl_block(AsCtl *ctl, const int *cnt_part, int M, cons
     return;
   }
   if (reduce) {
-    int r = 0, d = 0, b = 0;
+    int r = 0, d = 0, b = 0, op = 0;
     double vw = 0.0;
     for (int i = threadIdx.x; i < M; i += 1024) {
       r += cnt_part[3 * i]; d += cnt_part[3 * i + 1]; b |= cnt_part[3 * i + 2];
       if (viol) vw = fmax(vw, viol[i]);
+      if (open_part) op += open_part[i];
     }
-    sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b; shv[threadIdx.x] = vw;
+    sh[0][threadIdx.x] = r; sh[1][threadIdx.x] = d; sh[2][threadIdx.x] = b; sh[3][threadIdx.x] = op; shv[threadIdx.x] = vw;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
       if (threadIdx.x < o) {
         sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
         sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
         sh[2][threadIdx.x] |= sh[2][threadIdx.x + o];
+        sh[3][threadIdx.x] += sh[3][threadIdx.x + o];
         shv[threadIdx.x] = fmax(shv[threadIdx.x], shv[threadIdx.x + o]);
       }
       __syncthreads();
     }
     if (threadIdx.x == 0 && viol && ctl->round < 16) ctl->worst[ctl->round] = shv[0];  // (local to this rank when sharded: a diagnostic)
     if (threadIdx.x == 0) {
-      if (tail) { tail[0] = sh[0][0]; tail[1] = sh[1][0]; tail[2] = sh[2][0]; tail[3] = *fail; }
-      else { ctl->cnt[0] = sh[0][0]; ctl->cnt[1] = sh[1][0]; ctl->cnt[2] = sh[2][0]; ctl->cnt[3] = *fail; }
+      if (tail) { tail[0] = sh[0][0]; tail[1] = sh[1][0]; tail[2] = sh[2][0]; tail[3] = *fail; tail[4] = sh[3][0]; }
+      else { ctl->cnt[0] = sh[0][0]; ctl->cnt[1] = sh[1][0]; ctl->cnt[2] = sh[2][0]; ctl->cnt[3] = *fail; ctl->open = sh[3][0]; }
     }
   }
   if (threadIdx.x == 0 && decide) {
     if (tail) {  // all-reduced sums (exact in fp64: small integers)
       for (int k = 0; k < 4; k++) ctl->cnt[k] = (int)(tail[k] < 2e9 ? tail[k] : 2e9);
+      ctl->open = (int)(tail[4] < 2e9 ? tail[4] : 2e9);
     }
     const int rel = ctl->cnt[0], add = ctl->cnt[1], bad = ctl->cnt[2], fl = ctl->cnt[3];
     const int round = ctl->round;  // rounds completed before this one
@@ -53,9 +57,11 @@ __device__ inline void as_ctl_block(AsCtl *ctl, const int *cnt_part, int M, cons
     const int changes = rel + add;
     int done = 0, status = 1;
     if (bad || fl) { done = 1; status = 2; }
-    else if (changes == 0) { done = 1; status = 0; }
-    else {
-      if (changes * 2 > ctl->last_changes && ++ctl->stalls >= 2) done = 1;  // not contracting: leave it to the interior-point iteration
+    else if (changes == 0 && ctl->open == 0) { done = 1; status = 0; }
+    else if (changes == 0) {  // the set stands; the boundary cones' Newton iteration is still converging (quadratically): go on
+      if (round + 1 >= ctl->max_rounds) done = 1;
+    } else {
+      if (changes * 2 > ctl->last_changes && ++ctl->stalls >= ctl->stall_limit) done = 1;  // not contracting: leave it to the interior-point iteration
       ctl->last_changes = changes;
       if (round + 1 >= ctl->max_rounds) done = 1;
     }

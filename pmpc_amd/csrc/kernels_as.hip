@@ -53,7 +53,10 @@ namespace {
 //   2 deep2  everything TWO stages ahead (2 waves per SIMD): with at most two waves per SIMD — small shards, the few unsettled
 //            particles of the later rounds — a stage is shorter than the HBM latency, and data requested one stage ahead would
 //            pin every stage to that latency
-template <int XD, int UD, int MODE, bool SKIP, bool DEFECT>
+// CONE: stage cones ride along (kernels_cone.hip prepares their Newton terms per round): a full (u x u) block cone_H added to H_uu
+// — loaded like R — and a vector cone_g added to the control gradient — it comes in with the control word (lane XP + 3 of the
+// control quad), so the sweep pays ONE more load per stage.  Consensus stages: the owner's particle 0 alone adds them.
+template <int XD, int UD, int MODE, bool SKIP, bool DEFECT, bool CONE = false>
 __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_WAVES : PMPC_AS_LEAN_WAVES)) k_bwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
@@ -101,6 +104,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   const unsigned lug = (unsigned)((gu ? g : 0) * D8);
   const double regx_c = L.cxv ? regx : 0.0;
   const bool umask = L.cu && g == L.cb;
+  const double umask_d = umask ? 1.0 : 0.0;
   const bool diag_x = L.cxv && ((c & 3) == g);
   bool dmask[KS];
 #pragma unroll
@@ -144,6 +148,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   if (gu && c == XP) { pC = (const char *)(Ub + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
   else if (gu && c == XP + 1) { pC = (const char *)(a.U_ref + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
   else if (gu && c == XP + 2) { pC = (const char *)(a.as_act + (pbase + N - 1) * UD + g); sC = -UD * (int)sizeof(int); }  // (read as 8 bytes: spare bytes behind the buffer)
+  else if (CONE && gu && c == XP + 3) { pC = (const char *)(a.cone_g + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
   else if (!DEFECT && g < 2 && 15 - XP - c >= 0 && 15 - XP - c < UD) {
     pC = (const char *)((g == 0 ? Ub : a.U_prev) + (pbase + N - 1) * UD + (15 - XP - c));
     sC = -UD * (int)D8;
@@ -151,6 +156,11 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   const double regu_s = (L.cu && g < 2) ? (g == 0 ? regu : -regu) : 0.0;  // reg_u (u - u_prev): the two terms summed over the k-groups
   auto ld_R = [&](int jj) -> double {
     const double v = ldo(ubase(R_, (long long)(jj * (int)(UD * UD * D8))), lR);
+    return fR ? v : 0.0;
+  };
+  const double *CH_ = CONE ? ubase(a.cone_H, (long long)(pbase * (UD * UD)) * D8) : Z;
+  auto ld_CH = [&](int jj) -> double {  // cone block entry [g][cb], laid out like R
+    const double v = ldo(ubase(CH_, (long long)(jj * (int)(UD * UD * D8))), lR);
     return fR ? v : 0.0;
   };
   const bool frec = (L.cxv || L.cu) && gu;
@@ -161,7 +171,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 
   // prefetch register set of one stage: what it needs the moment it starts (F, R, control word, f of the stage) and — DEEP —
   // its mid / late data (Q and the base point of the stage BELOW it) as well
-  struct Pipe { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
+  struct PipeCone { double ch; };
+  struct PipeNone {};
+  struct Pipe : std::conditional_t<CONE, PipeCone, PipeNone> { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
   int jF = N - 1;  // stage pF / pC point at
   auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves the pointers alone)
     if (jj < jF) { pF = badd(pF, sF); pC += sC; jF = jj; }
@@ -170,6 +182,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     q.R = ld_R(jj);
     q.ctl = gld(pC);
     if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lxc);
+    if constexpr (CONE) q.ch = ld_CH(jj);
   };
   // Q and the base point of stage jbelow (= jj - 1, clamped at 0) on the state COLUMNS: one load per array; the row-distributed
   // copy the Q x product needs is made by lane shuffles when the stage consumes it
@@ -212,7 +225,15 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     const double um_g = pwt * (dpp_d<0x00>(cur.ctl) - dpp_d<0x55>(cur.ctl));  // pw (u - u_ref)[g] (R is zero outside the control quad)
     const int act_g = __builtin_amdgcn_mov_dpp(__double2loint(cur.ctl), 0xAA, 0xF, 0xF, true);
     Du_c = (umask && act_g) ? a.as_big : 0.0;  // penalty of a held control, on the diagonal lanes (XP + b, b)
-    const double gu_c = DEFECT ? 0.0 : regu_s * dpp_d<0x140>(cur.ctl);  // +reg_u u[b] in k-group 0, -reg_u u_prev[b] in k-group 1
+    const double gu_c0 = DEFECT ? 0.0 : regu_s * dpp_d<0x140>(cur.ctl);  // +reg_u u[b] in k-group 0, -reg_u u_prev[b] in k-group 1
+    const bool cone_here = CONE && (MAIN || !cons || own0);
+    // cone_g[g] sits in lane XP + 3 of the control quad; lane (XP + g, g) adds it.  The broadcast must run with ALL lanes enabled (a
+    // DPP move reads 0 from a disabled lane): masked by a multiplication, not by a select the compiler could turn into a branch
+    // around the move (it did: the gradient term was silently dropped)
+    double gu_c = gu_c0;
+    if constexpr (CONE) gu_c = fma(dpp_d<0xFF>(cur.ctl), cone_here ? umask_d : 0.0, gu_c0);
+    double Hcone = 0.0;
+    if constexpr (CONE) Hcone = cone_here ? cur.ch : 0.0;
     const double df_c = (DEFECT && L.cxv) ? cur.f - xb_carry : 0.0;     // dynamics defect of the base point on the state columns
     if (DEFECT) xb_carry = cur.xb;
     gx_c = DEFECT ? 0.0 : regx_c * (cur.xb - cur.xp);
@@ -249,7 +270,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
         p2q = fma(Qc[r], xm_row[r], p2q);
       }
     }
-    H[KS] = fma(pwt, Rc, (umask ? regu : 0.0) + (cons ? 0.0 : Du_c));
+    if constexpr (CONE) H[KS] = fma(pwt, Rc, (umask ? regu : 0.0) + (cons ? 0.0 : Du_c + Hcone));
+    else H[KS] = fma(pwt, Rc, (umask ? regu : 0.0) + (cons ? 0.0 : Du_c));
     v4d G = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
@@ -261,7 +283,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
       // consensus stage: no minimisation.  Export the condensed gradient block and the diagonal Hessian block Huu; keep
       // Y_j = H_ux in the factor record (k_cond_fast) and carry P_{j-1} = H_xx on as the cost-to-go
       double v = H[KS];
-      if (own0) v += Du_c;
+      if (own0) v += CONE ? Du_c + Hcone : Du_c;
       const int nc = Nc * UD;
       if (L.cu && gu) a.Hc_part[(size_t)i * nc * nc + (size_t)(j * UD + g) + (size_t)nc * (j * UD + L.cb)] = v;
       st_rec(j, (L.cxv && gu) ? H[KS] : 0.0);
@@ -408,7 +430,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // fx / fu, the udim gain rows from the factor record — with one per-lane pointer, KS + 1 loads per stage (as many as before).
 // Columns 0..3 of the product carry the same state vector (so every lane of a k-group that stores or decides has it), the
 // other twelve stay zero.
-template <int XD, int UD, bool DEFECT, bool PF2>
+// CONE: also records each stage's own Newton step u_b + du BEFORE clamping (a.as_uraw: the cone multiplier updates of
+// kernels_cone.hip are valid for that step only) — a third lane of the per-control store, no further instruction.
+template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false>
 __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
@@ -464,8 +488,8 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     sG = UD * (int)sizeof(int);
   }
   // outputs of control g: lane 0 -> new base control, lane 1 -> feed-forward of the next round
-  char *pS = (char *)((c == 1 ? a.kff : a.Uo) + pbase * UD + (gu ? g : 0));
-  const bool st_lane = gu && c < 2;
+  char *pS = (char *)((c == 1 ? a.kff : ((CONE && c == 2) ? a.as_uraw : a.Uo)) + pbase * UD + (gu ? g : 0));
+  const bool st_lane = gu && c < (CONE ? 3 : 2);
   const bool store_u = (c == 0) && gu;
   // what a stage needs when it starts: this lane's entries of T, the per-control word of this lane, this lane's base-state row
   struct Pipe { double T[KS + 1], grp, xb, f; };
@@ -601,10 +625,13 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     const double knew = actc ? -draw : 0.0;
     if (MAIN || j >= Nc) {
       const double k1 = dpp_d<0x00>(knew);  // quad broadcast of lane 0
-      if (st_lane) gst(pS, (c == 0) ? unew : k1);
-    } else if (store_u) {
-      gst(pS, unew);
-      if (i == 0) a.as_delta[j * UD + g] = dug;  // the consensus step as applied (settled particles: g_i += H_i delta)
+      const double z1 = CONE ? dpp_d<0x00>(zt) : 0.0;
+      if (st_lane) gst(pS, (c == 0) ? unew : ((CONE && c == 2) ? z1 : k1));
+    } else {
+      // (one branch for both stores: the quad broadcast must see lane 0 enabled wherever the compiler puts it)
+      const double z1 = CONE ? dpp_d<0x00>(zt) : 0.0;
+      if (store_u || (CONE && gu && c == 2)) gst(pS, (c == 0) ? unew : z1);
+      if (store_u && i == 0) a.as_delta[j * UD + g] = dug;  // the consensus step as applied (settled particles: g_i += H_i delta)
     }
     pS += UD * (int)D8;
     if (store_u) gsto_i(ubase(act_, uoff(j) >> 1), lug >> 1, anew);
@@ -682,6 +709,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     a.as_cnt[3 * i + 1] = (int)d;
     a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
     if (a.as_settled_out) a.as_settled_out[i] = (r == 0.0 && d == 0.0 && !(b > 0.0)) ? 1 : 0;
+    if (CONE) a.as_open[i] = 0;  // (counted by the cone pass that follows)
   }
 }
 
@@ -691,11 +719,12 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
 // decide = 1.  Sharded: reduce = 1 (local counters -> ctl->cnt), all-reduce of ctl->cnt, then decide = 1.
 // ------------------------------------------------------------------------------------------------
 // control block of a fresh attempt (one thread): replaces a host -> device copy and a memset per solve
-__global__ void k_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale) {
+__global__ void k_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, int stall_limit) {
   if (threadIdx.x == 0) {
     *fail = 0;
     AsCtl h = {};
     h.max_rounds = max_rounds;
+    h.stall_limit = stall_limit;
     h.last_changes = 0x7fffffff;
     h.dual_scale = dual_scale;
     h.tol_l = dual_scale * 1e-11;
@@ -707,10 +736,18 @@ __global__ void k_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_sc
 // consensus all-reduce instead of in a collective of their own — reduce = 1 packs the local sums into tail[0..3], decide = 1
 // reads the all-reduced values from there.
 __global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch,
-                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq, double *tail, const double *viol) {
-  as_ctl_block(ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol);
+                                                 AsCtl *mirror, unsigned long long *mirror_seq, unsigned long long seq, double *tail, const double *viol,
+                                                 const int *open_part) {
+  as_ctl_block(ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol, open_part);
 }
 
+// (xdim, udim) pairs with CONE instantiations of the two sweeps (a subset: every pair costs ten more kernels to compile)
+template <int XD, int UD>
+constexpr bool cone_dims() {
+  return UD >= 2 && ((XD == 12 && UD == 4) || (XD == 8 && UD == 4) || (XD == 6 && UD == 4) || (XD == 4 && UD == 4) || (XD == 9 && UD == 3) ||
+                     (XD == 6 && UD == 3) || (XD == 5 && UD == 3) || (XD == 3 && UD == 3) || (XD == 8 && UD == 2) || (XD == 4 && UD == 2) ||
+                     (XD == 2 && UD == 2));
+}
 template <int XD, int UD>
 void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
   // waves per SIMD this launch brings (1024 SIMDs): <= 2 deep2, <= 3 deep, else lean (see k_bwd_as)
@@ -719,7 +756,24 @@ void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
   int mode = a.M <= m2 ? 2 : (a.M <= m1 ? 1 : 0);
   // the DEFECT instantiation of the deep variant needs 127 registers (4 waves per SIMD without help): never the lean one
   if (a.defect && mode == 0) mode = 1;
-  const dim3 grd(a.M), blk(64);
+ const dim3 grd(a.M), blk(64);
+  if (a.cone_H) {  // stage cones: the deep variants only (one more register per prefetch set)
+    if constexpr (cone_dims<XD, UD>()) {
+      if (mode == 0) mode = 1;
+      if (a.defect) {
+        if (mode == 2) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, false, true, true>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_as<XD, UD, 1, false, true, true>), grd, blk, 0, s, a);
+      } else if (a.as_settled_in) {
+        hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, true, false, true>), grd, blk, 0, s, a);
+      } else {
+        if (mode == 2) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, false, false, true>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_as<XD, UD, 1, false, false, true>), grd, blk, 0, s, a);
+      }
+      return;
+    } else {
+      abort();  // (solver.hip asks cone_as_dims_supported first)
+    }
+  }
 #define PMPC_BWD_AS(SK, DF)                                                                      \
   do {                                                                                           \
     if (mode == 2) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, SK, DF>), grd, blk, 0, s, a);         \
@@ -740,6 +794,15 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
   //  PMPC_AS_FWD_PF2_MAXM=<M> puts larger launches back on the one-stage variant)
   static const int m2 = getenv("PMPC_AS_FWD_PF2_MAXM") ? atoi(getenv("PMPC_AS_FWD_PF2_MAXM")) : (1 << 30);
   const dim3 grd(a.M), blk(64);
+  if (a.as_uraw) {
+    if constexpr (cone_dims<XD, UD>()) {
+      if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true>), grd, blk, 0, s, a);
+      else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true>), grd, blk, 0, s, a);
+      return;
+    } else {
+      abort();
+    }
+  }
   if (a.M <= m2) {
     if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true>), grd, blk, 0, s, a);
     else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true>), grd, blk, 0, s, a);
@@ -751,6 +814,12 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
 
 }  // namespace
 
+bool cone_as_dims_supported(int x, int u) {
+#define X(xd, ud) if (x == xd && u == ud) return cone_dims<xd, ud>();
+  PMPC_FAST_DIMS(X)
+#undef X
+  return false;
+}
 void launch_bwd_as(const LQArgs &a, hipStream_t s) {
 #define X(xd, ud) if (a.x == xd && a.u == ud) { launch_bwd_as_t<xd, ud>(a, s); return; }
   PMPC_FAST_DIMS(X)
@@ -764,9 +833,10 @@ void launch_fwd_as(const LQArgs &a, hipStream_t s) {
   abort();
 }
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
-                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail, const double *viol) {
-  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(1024), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol);
+                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail, const double *viol, const int *open_part) {
+  hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(1024), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol,
+                     open_part);
 }
-void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s) {
-  hipLaunchKernelGGL(k_as_begin, dim3(1), dim3(64), 0, s, ctl, fail, max_rounds, dual_scale);
+void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s, int stall_limit) {
+  hipLaunchKernelGGL(k_as_begin, dim3(1), dim3(64), 0, s, ctl, fail, max_rounds, dual_scale, stall_limit);
 }

@@ -809,7 +809,7 @@ __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, cons
   // (counters of its forward sweep -> done / status / tolerance of the next forward sweep), see as_ctl_dev.h
   const int nblk = pend.ctl ? (int)gridDim.x - 1 : (int)gridDim.x;
   if (pend.ctl && (int)blockIdx.x == nblk) {
-    as_ctl_block(pend.ctl, pend.cnt_part, pend.M, pend.fail, 1, 1, 0, pend.mirror, pend.mirror_seq, pend.seq, nullptr, pend.viol);
+    as_ctl_block(pend.ctl, pend.cnt_part, pend.M, pend.fail, 1, 1, 0, pend.mirror, pend.mirror_seq, pend.seq, nullptr, pend.viol, pend.open_part);
     return;
   }
   const int tid = threadIdx.x, e = tid & 31, pl = tid >> 5;

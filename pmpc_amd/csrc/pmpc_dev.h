@@ -42,6 +42,10 @@ struct AsCtl {
   int status;        // 0 accepted (set unchanged: the optimum), 1 not settled (stalled / round limit), 2 numerical failure
   int round;         // rounds completed
   int max_rounds, last_changes, stalls;
+  int stall_limit;   // rounds whose changes may fail to halve before the attempt is given up (2; stage cones: 8 — their case changes
+                     // thin out slowly while the boundary cones' Newton iteration converges)
+  int open;          // stage cones whose Newton iteration has not converged yet (no case change, but |ds|, |dz| or |Phi| above
+                     // tolerance), all ranks: the set counts as settled only when this is zero as well
   int cnt[4];        // {released, activated, bad (NaN / empty box / broken promise), failure flag} of the last round (all ranks)
   int hist[16][2];   // per round: released, activated
   double tol_l;      // sign tolerance of the multipliers for the NEXT round
@@ -111,6 +115,13 @@ struct LQArgs {
   // wave of the forward sweep itself (kernels_as.hip) — one launch less per round.  cons_G = 0: a.duc holds the step.
   const double *cons_tH, *cons_tg;
   int cons_G;
+  // stage cones on the active-set sweeps (kernels_cone.hip prepares them per round): Newton terms of every (particle, stage) — a full
+  // (u x u) block added to H_uu and a vector added to the control gradient (consensus stages: once, by the owner's particle 0) — and
+  // the forward sweep's record of each stage's own Newton step u_b + du BEFORE clamping (the cone multiplier updates are valid for
+  // that step only).  Null = no cones (the CONE instantiations are not launched).
+  const double *cone_H, *cone_g;
+  double *as_uraw;
+  int *as_open;    // per particle: open stage cones (zeroed by the forward sweep, counted by the cone pass)
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
@@ -177,6 +188,7 @@ struct AsCtlCall {
   unsigned long long *mirror_seq;
   unsigned long long seq;
   const double *viol;
+  const int *open_part;  // per-particle open stage cones (null: none)
 };
 int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, const AsCtlCall &pend,
                          hipStream_t s);  // -> number of partials
@@ -204,9 +216,36 @@ void launch_bwd_as(const LQArgs &a, hipStream_t s);
 void launch_fwd_as(const LQArgs &a, hipStream_t s);
 // round control: reduce the per-particle counters into ctl->cnt (+ failure flag) and / or decide (done, status, next tolerance);
 // publishes ctl to the host-coherent mirror with sequence number `seq` when the rounds are over or the batch ends
-void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s);  // fresh control block of an attempt, *fail = 0
+void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s, int stall_limit = 2);  // fresh control block of an attempt, *fail = 0
+// `tail`: 5 doubles {released, activated, bad, failure, open cones} (sharded runs)
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,
-                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail = nullptr, const double *viol = nullptr);
+                   unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail = nullptr, const double *viol = nullptr,
+                   const int *open_part = nullptr);
+
+// ---- kernels_cone.hip (stage-wise second-order cones inside the active-set rounds) --------------------------------------------
+// One elementwise pass per round, thread = (particle, stage): FINISH the round just swept (cone multipliers from each stage's own
+// Newton step, new case of the projection's generalised Jacobian, change / open counters) and PREPARE the next one (Newton terms
+// cone_H, cone_g from the new base point and multipliers).  Semismooth Newton on  s - Proj_K(s - z) = 0,  s = A u + c:
+//   interior (s - z in K): cone off;   polar: s -> 0 (apex) by penalty + multiplier;   else: ONE equality along e- = (1, -wh)/sqrt2
+//   (penalty + multiplier) and the finite curvature (1 - theta)/theta on the tangential directions.
+struct ConeArgs {
+  int M, N, u, q, Nc, owner;
+  const double *U, *Uraw;     // new base controls / each stage's raw Newton step (finish); U alone for the first preparation
+  const double *A, *c;        // cone data, device: A = [v'; W] ((q+1) x u, row-major), c = (v0, w0)
+  const double *R;            // cost blocks (penalty scale rho = rho_scale * (trace(R)/u + reg_u))
+  double reg_u, rho_scale;
+  double *z, *rec;            // multipliers (M,N,q+1) and the per-stage record of the prepared round (M,N,PMPC_CONE_REC)
+  double *H, *g;              // outputs: Newton terms (M,N,u,u) column-major blocks, (M,N,u)
+  int *cnt, *settled, *open;  // per particle: as_cnt (3 ints: case changes are added to [1]), settled flag (cleared), open cones
+  const int *done;
+  int finish;                 // 0: prepare only (first round of an attempt)
+  double tol_step, tol_phi, dual_scale;
+};
+#define PMPC_CONE_REC 12
+bool cone_as_supported(int u, int q);
+bool cone_as_dims_supported(int x, int u);  // kernels_as.hip: (xdim, udim) pairs with CONE instantiations of the sweeps
+void launch_cone_step(const ConeArgs &a, hipStream_t s);
+void launch_cone_drop_redundant_lo(double *lo, const double *A, const double *c, int q, long long rows, int u, hipStream_t s);
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_block_transpose(const double *in, double *out, int rows, int cols, long long n, hipStream_t s);

@@ -148,7 +148,8 @@ struct Workspace {
   DevBuf soc_cl, soc_cu, soc_cc;  // second-order (Mehrotra) terms
   DevBuf soc_wU, soc_wzl, soc_wzu, soc_wzc;  // remembered early iterate (warm start of the cone path)
   long long soc_key = -1;
-  DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift
+  DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift (path following) / Newton terms of the cones (active-set rounds)
+  DevBuf cone_A, cone_c, cone_z, cone_rec, cone_uraw, as_open;  // stage cones inside the active-set rounds (kernels_cone.hip)
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
@@ -323,11 +324,11 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
     if (fast && factor) launch_cond_fast(a, s);
     // sharded active-set rounds: the previous round's change counters travel behind [Hc | gc] (one collective per round
     // instead of two); the decision about that round is taken right behind the all-reduce, before this round's forward sweep
-    const size_t tail = (a.as_merge && factor) ? 4 : 0;
+    const size_t tail = (a.as_merge && factor) ? 5 : 0;  // {released, activated, bad, failure, open cones}
     double *tl = Hc + (size_t)nc * nc + nc;
     auto merged_exchange = [&]() {
-      if (a.as_merge == 2) launch_as_ctl(const_cast<AsCtl *>(a.as_ctl), a.as_cnt, a.M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, tl);
-      else if (a.as_merge == 1) HIP_CHECK(hipMemsetAsync(tl, 0, 4 * sizeof(double), s));
+      if (a.as_merge == 2) launch_as_ctl(const_cast<AsCtl *>(a.as_ctl), a.as_cnt, a.M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, tl, nullptr, a.as_open);
+      else if (a.as_merge == 1) HIP_CHECK(hipMemsetAsync(tl, 0, 5 * sizeof(double), s));
       if (factor) allreduce(c, Hc, (size_t)nc * nc + nc + tail, ncclFloat64, ncclSum);
       else allreduce(c, gc, nc, ncclFloat64, ncclSum);
       if (a.as_merge == 2)
@@ -445,7 +446,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
                    &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
-                   &w.sa_cl, &w.sa_ch};
+                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -721,11 +722,12 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     size_t kb = nu * a.n * D8, rb = (size_t)M * N * 64 * D8;
     w.K.ensure(kb > rb ? kb : rb);
   }
-  w.Hinv.ensure(nu * u * D8); w.kff.ensure(nu * D8);
+  w.Hinv.ensure(nu * u * D8);
+  w.kff.ensure(nu * D8);
   w.gc_part.ensure((size_t)M * nc * D8); w.Hc_part.ensure((size_t)M * nc * nc * D8);
   w.scratch.ensure((size_t)M * 3 * a.n * nc * D8);
   w.red_tmp.ensure((size_t)64 * ((size_t)nc * nc + nc) * D8);
-  w.Hg.ensure(((size_t)nc * nc + nc + 4) * D8);  // (+ 4: change counters of the active-set rounds, sharded runs)
+  w.Hg.ensure(((size_t)nc * nc + nc + 5) * D8);  // (+ 4: change counters of the active-set rounds, sharded runs)
   w.Lc.ensure(((size_t)nc * nc + (size_t)((nc + 15) / 16) * 272) * D8);  // (+ the inverse diagonal blocks of k_cons_solve_lds)
   w.duc.ensure((size_t)nc * D8);
   w.sc.ensure(sizeof(IpmScal)); w.fail.ensure(sizeof(int)); w.xch.ensure((size_t)c->world * 8 * D8);
@@ -824,7 +826,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   if (has_xb) setup_slab(sx, w.sx, nx, x, false, p->lx, p->ux, w.X.d(), w.dX.d());
   if (has_ub) {
     const double *lo = p->lu, *hi = p->uu;
-    const long long sukey = ((((long long)u * 131 + N) * 1000003 + M) * 131 + Nc);
+    const long long sukey = (((((long long)u * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (soc ? 1 : 0));  // (the cone solver's copy drops a box side)
     if (Nc > 0 && (M > 1 || c->multi()) && (p->flags & PMPC_STATIC_CONS_BOUNDS) && w.su_key == sukey && w.su_src_lo == p->lu &&
         w.su_src_hi == p->uu && w.su.lo.bytes >= nu * D8) {
       // the caller vouches EXPLICITLY (PMPC_STATIC_CONS_BOUNDS, on any rank count) that the CONTENTS of lu / uu are those of the
@@ -862,15 +864,46 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   }
   const int B = PMPC_RED_BLOCKS;
 
-  if (soc) {
+  if (soc && (has_xb || p->weights || a.any_slew || p->soc_u_interior == nullptr || (p->soc_q > 0 && (!p->soc_W || !p->soc_w0 || !p->soc_v)) ||
+              u > 8 || p->soc_q > 4)) {
+    fprintf(stderr, "pmpc_hip: pmpc_lsoc_solve_device supports control boxes + one stage cone (udim <= 8, soc_q <= 4), no state boxes / "
+                    "weights / slew, and needs soc_u_interior\n");
+    return finish(2);
+  }
+  // Stage cones inside the active-set rounds (kernels_cone.hip: semismooth Newton on the cones' natural map, boxes by the
+  // primal-dual active-set rule) — warm-started from the previous solve's set and multipliers, cold-started from soc_u_interior;
+  // the path-following iteration below is the fallback.  PMPC_CONE_AS=0 switches it off.
+  static const bool cone_as_env = !(getenv("PMPC_CONE_AS") && atoi(getenv("PMPC_CONE_AS")) == 0);
+  const bool cone_as = soc && cone_as_env && fast && p->soc_q > 0 && cone_as_supported(u, (int)p->soc_q) && cone_as_dims_supported(x, u);
+  if (soc && !has_ub && cone_as) {  // no boxes: the active-set sweeps still read them — unbounded working copies
+    w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
+    w.su_key = -1;
+    launch_fill(w.su.lo.d(), -std::numeric_limits<double>::infinity(), (long long)nu, s);
+    launch_fill(w.su.hi.d(), std::numeric_limits<double>::infinity(), (long long)nu, s);
+    setup_slab(su, w.su, nu, u, true, w.su.lo.d(), w.su.hi.d(), w.U.d(), w.dU.d());
+  }
+  if (soc && has_ub) {
+    // working copy of the control boxes on every path of the cone solver: particle 0's on the consensus stages, and a lower
+    // side that the cone implies (thrust >= 0 next to the thrust cone) dropped — see k_cone_drop_lo
+    if (su.lo == p->lu) {
+      w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
+      w.su_key = -1;
+      HIP_CHECK(hipMemcpyAsync(w.su.lo.p, p->lu, nu * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(w.su.hi.p, p->uu, nu * D8, hipMemcpyDeviceToDevice, s));
+      su.lo = w.su.lo.d(); su.hi = w.su.hi.d();
+    }
+  }
+  if (soc && p->soc_q > 0) {  // cone data as one block A = [v'; W], c = (v0, w0) for kernels_cone.hip
+    w.cone_A.ensure((size_t)(p->soc_q + 1) * u * D8); w.cone_c.ensure((size_t)(p->soc_q + 1) * D8);
+    HIP_CHECK(hipMemcpyAsync(w.cone_A.p, p->soc_v, (size_t)u * D8, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(w.cone_A.d() + u, p->soc_W, (size_t)p->soc_q * u * D8, hipMemcpyDeviceToDevice, s));
+    launch_fill(w.cone_c.d(), p->soc_v0, 1, s);  // (by value: no asynchronous read of the caller's struct)
+    HIP_CHECK(hipMemcpyAsync(w.cone_c.d() + 1, p->soc_w0, (size_t)p->soc_q * D8, hipMemcpyDeviceToDevice, s));
+    if (has_ub) launch_cone_drop_redundant_lo(w.su.lo.d(), w.cone_A.d(), w.cone_c.d(), (int)p->soc_q, (long long)M * N, u, s);
+  }
+  auto soc_interior_point = [&]() -> int {
     reset_scalars();
     // ---- stage-wise control cones: primal-dual path following on the same Riccati kernels (kernels_soc.hip) ----------
-    if (has_xb || p->weights || a.any_slew || p->soc_u_interior == nullptr || (p->soc_q > 0 && (!p->soc_W || !p->soc_w0 || !p->soc_v)) ||
-        u > 8 || p->soc_q > 4) {
-      fprintf(stderr, "pmpc_hip: pmpc_lsoc_solve_device supports control boxes + one stage cone (udim <= 8, soc_q <= 4), no state boxes / "
-                      "weights / slew, and needs soc_u_interior\n");
-      return finish(2);
-    }
     const int q = (int)p->soc_q;
     w.Hadd.ensure(nu * u * D8); w.wu_soc.ensure(nu * D8);
     const size_t ncz = (size_t)M * N * (q + 1);
@@ -1045,7 +1078,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     inf.mu = mu;
     if (verbose) printf("pmpc_hip: stage cones: status %d after %d Newton steps\n", status, newton);
     return finish(status);
-  }
+  };
 
   // returns 0: the equality-only optimum satisfies every box (done), 1: boxes violated (interior-point phase), 2: failure
   auto equality_phase = [&]() -> int {
@@ -1074,7 +1107,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // If the set does not settle the interior-point iteration runs (on), its state untouched.  The rounds act on the control
   // boxes (a state cannot be moved onto its bound without leaving the dynamics; state boxes that do not bind are verified at
   // acceptance, see below); not in barrier mode.  DESIGN.md section 2.4.
-  const long long as_key_pre = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0);
+  const long long as_key_pre = (((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0)) * 8 + (soc ? 1 + (long long)p->soc_q : 0);
   static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
   static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
   static const bool as_skip_on = !(getenv("PMPC_AS_SKIP") && atoi(getenv("PMPC_AS_SKIP")) == 0);
@@ -1104,7 +1137,24 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     b.as_viol = w.as_viol.d();
     b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
     w.as_key = -1;
-    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s);  // control block of this attempt (+ cleared failure flag)
+    // stage cones (mode 0 warm / 3 cold): Newton terms per round from kernels_cone.hip, see the header there
+    const bool cone = cone_as && (mode == 0 || mode == 3);
+    ConeArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    if (cone) {
+      const int q = (int)p->soc_q;
+      const size_t rows = (size_t)M * N;
+      w.Hadd.ensure(nu * u * D8); w.wu_soc.ensure(nu * D8); w.cone_uraw.ensure(nu * D8); w.as_open.ensure((size_t)M * sizeof(int));
+      const bool z_new = w.cone_z.ensure(rows * (q + 1) * D8), rec_new = w.cone_rec.ensure(rows * PMPC_CONE_REC * D8);
+      if (z_new || rec_new) w.as_key = -1;
+      b.cone_H = w.Hadd.d(); b.cone_g = w.wu_soc.d(); b.as_uraw = w.cone_uraw.d(); b.as_open = (int *)w.as_open.p;
+      ca.M = M; ca.N = N; ca.u = u; ca.q = q; ca.Nc = Nc; ca.owner = a.owner;
+      ca.A = w.cone_A.d(); ca.c = w.cone_c.d(); ca.R = p->R; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
+      ca.z = w.cone_z.d(); ca.rec = w.cone_rec.d(); ca.H = w.Hadd.d(); ca.g = w.wu_soc.d();
+      ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done;
+      ca.tol_step = 1e-6; ca.tol_phi = 1e-9; ca.dual_scale = dual_scale;
+    }
+    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s, cone ? 8 : 2);  // control block of this attempt (+ cleared failure flag)
     // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
     // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout, nothing
     // written before the sweep.  The forward sweep verifies that U_prev IS the base point of the stored set.
@@ -1113,7 +1163,13 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     // those stages forward anyway, carries d as one more column (k_cond_fast).  Found by the config-B full-consensus test,
     // which a single accepted round without the term got wrong by 8 %)
     const bool use_defect = mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
-    if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
+    if (mode == 3) {  // cold start of the cone rounds: every control at the caller's interior point, nothing held, no multipliers
+      ProfScope ps(c, 5);
+      HIP_CHECK(hipMemsetAsync(act, 0, nu * sizeof(int) + 8, s));
+      HIP_CHECK(hipMemsetAsync(w.cone_z.p, 0, (size_t)M * N * (p->soc_q + 1) * D8, s));
+      launch_soc_fill_u(p->U_out, p->soc_u_interior, (long long)nu, u, s);
+      launch_rollout_fast(b, p->U_out, p->X_out, s);
+    } else if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
       ProfScope ps(c, 5);
       Slab st = su;
       // the previous solution: this context's copy, or — a caller inside an SCP loop that hands it back as U_prev (promise flag;
@@ -1128,6 +1184,13 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
                                  !(getenv("PMPC_AS_WAVE_CONS") && atoi(getenv("PMPC_AS_WAVE_CONS")) == 0);
     const bool fuse_ctl = fuse_env && !c->multi() && Nc == 1;
     c->as_pend.ctl = nullptr;
+    const int *open_part = cone ? (const int *)w.as_open.p : nullptr;
+    if (cone) {  // Newton terms of the first round, from the first base point and the stored multipliers
+      ProfScope ps(c, 5);
+      ca.finish = 0;
+      ca.U = use_defect ? p->U_prev : p->U_out;
+      launch_cone_step(ca, s);
+    }
     int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
     int n_batches_at_hook = -1000;  // batches waited for since the speculation hook fired (in THIS attempt)
     AsCtl h;
@@ -1150,25 +1213,30 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         c->as_seq++;
         structured_solve(c, b, true, true, /*prep_done=*/true);
         ProfScope ps(c, 5);
+        if (cone) {  // finish this round's cones (multipliers, cases, counters — BEFORE the round control reads them), prepare the next
+          ca.finish = 1;
+          ca.U = p->U_out; ca.Uraw = w.cone_uraw.d();
+          launch_cone_step(ca, s);
+        }
         if (merge) {
           if (last) {
             double *tl = w.Hg.d() + (size_t)nc * nc + nc;
-            launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, tl);
-            allreduce(c, tl, 4, ncclFloat64, ncclSum);
+            launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, tl, nullptr, open_part);
+            allreduce(c, tl, 5, ncclFloat64, ncclSum);
             launch_as_ctl(ctl, nullptr, M, (const int *)w.fail.p, 0, 1, 1, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s, tl);
           }
-        } else if (c->multi()) {  // no consensus exchange to ride on: one sum for all four
-          launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s);
-          allreduce(c, ctl->cnt, 4, ncclInt32, ncclSum);
+        } else if (c->multi()) {  // no consensus exchange to ride on: one sum for all five (open cones + the four counters: contiguous)
+          launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 0, 0, nullptr, nullptr, 0, s, nullptr, nullptr, open_part);
+          allreduce(c, &ctl->open, 5, ncclInt32, ncclSum);
           launch_as_ctl(ctl, nullptr, M, (const int *)w.fail.p, 0, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s);
         } else if (!last && fuse_ctl) {
           // the decision about this round rides in the next round's consensus-partials launch (structured_solve): its factor
           // sweep does not need it (settled particles leave it at once), its forward sweep sees it
           c->as_pend = AsCtlCall{ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq,
-                                 b.as_viol};
+                                 b.as_viol, open_part};
         } else {
           launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s,
-                        nullptr, b.as_viol);
+                        nullptr, b.as_viol, open_part);
         }
       }
       if (round == 0 && c->post_batch) {  // the caller's follow-up work goes in behind the rounds before anything is read back
@@ -1198,7 +1266,64 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (verbose)
         for (int r = round; r < h.round && r < 16; r++)
           printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest violation behind a change %.2e)\n",
-                 mode == 2 ? "cold" : (mode ? "finish" : "warm"), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
+                 mode >= 2 ? "cold" : (mode ? "finish" : "warm"), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
+      if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
+      if (verbose > 1 && cone) {  // debugging aid: the active cones' records (small problems only)
+        HIP_CHECK(hipStreamSynchronize(s));
+        const int q1 = (int)p->soc_q + 1;
+        std::vector<double> hz((size_t)M * N * q1), hr((size_t)M * N * PMPC_CONE_REC), hu(nu), hraw(nu), hg(nu);
+        HIP_CHECK(hipMemcpy(hz.data(), w.cone_z.p, hz.size() * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hr.data(), w.cone_rec.p, hr.size() * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hu.data(), p->U_out, nu * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hraw.data(), w.cone_uraw.p, nu * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hg.data(), w.wu_soc.p, nu * D8, hipMemcpyDeviceToHost));
+        {
+          std::vector<int> hcnt((size_t)M * 3);
+          HIP_CHECK(hipMemcpy(hcnt.data(), w.as_cntp.p, hcnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+          std::vector<int> hact(nu);
+          HIP_CHECK(hipMemcpy(hact.data(), w.as_act.p, nu * sizeof(int), hipMemcpyDeviceToHost));
+          printf("   act:");
+          for (size_t k = 0; k < nu && k < 24; k++) printf(" %d", hact[k]);
+          printf("\n   as_cnt:");
+          for (int v : hcnt) printf(" %d", v);
+          printf(" | U of particle 0:");
+          for (int k = 0; k < N * u && k < 12; k++) printf(" %.6e", hu[k]);
+          printf(" | uraw:");
+          for (int k = 0; k < N * u && k < 12; k++) printf(" %.6e", hraw[k]);
+          printf(" | cone_g:");
+          for (int k = 0; k < N * u && k < 12; k++) printf(" %.3e", hg[k]);
+          printf("\n");
+        }
+        int shown = 0;
+        for (size_t k = 0; k < (size_t)M * N && shown < 6; k++) {
+          if (hr[k * PMPC_CONE_REC] == 0.0) continue;
+          shown++;
+          printf("   cone (%zu,%zu) case %g rho %.3e curv %.3e nu %.6e | s_b", k / N, k % N, hr[k * PMPC_CONE_REC], hr[k * PMPC_CONE_REC + 1], hr[k * PMPC_CONE_REC + 2], hr[k * PMPC_CONE_REC + 3]);
+          for (int r = 0; r < q1; r++) printf(" %.9e", hr[k * PMPC_CONE_REC + 4 + (q1 - 1) + r]);
+          printf(" | z");
+          for (int r = 0; r < q1; r++) printf(" %.9e", hz[k * q1 + r]);
+          printf(" | u");
+          for (int r = 0; r < u; r++) printf(" %.9e", hu[k * u + r]);
+          printf(" | uraw");
+          for (int r = 0; r < u; r++) printf(" %.9e", hraw[k * u + r]);
+          printf(" | g");
+          for (int r = 0; r < u; r++) printf(" %.3e", hg[k * u + r]);
+          {
+            std::vector<double> hk(u), hH((size_t)u * u);
+            std::vector<int> ha(u);
+            HIP_CHECK(hipMemcpy(hk.data(), w.kff.d() + k * u, u * D8, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(ha.data(), (int *)w.as_act.p + k * u, u * sizeof(int), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(hH.data(), w.Hadd.d() + k * u * u, (size_t)u * u * D8, hipMemcpyDeviceToHost));
+            printf(" | kff");
+            for (int r = 0; r < u; r++) printf(" %.3e", hk[r]);
+            printf(" | act");
+            for (int r = 0; r < u; r++) printf(" %d", ha[r]);
+            printf(" | Hdiag");
+            for (int r = 0; r < u; r++) printf(" %.3e", hH[r * (u + 1)]);
+          }
+          printf("\n");
+        }
+      }
       inf.structured_solves += h.round - round;
       inf.active_set_rounds += h.round - round;
       round = h.round;
@@ -1312,6 +1437,27 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     }
     return 1;
   };
+  if (soc) {
+    if (cone_as) {
+      static const int cone_cold_rounds = getenv("PMPC_CONE_AS_COLD") ? atoi(getenv("PMPC_CONE_AS_COLD")) : 16;
+      const bool can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
+      const bool prev_is_base = !c->multi() && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
+      int r = 1;
+      if (as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || can_defect || prev_is_base)) {
+        r = active_set_fast(w.as_scale, 0, 14);
+        if (r == 0) return finish(0);
+        if (verbose) printf("pmpc_hip: warm cone rounds not settled (%d): cold start\n", r);
+      }
+      if (cone_cold_rounds > 0) {
+        if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+        r = active_set_fast(1.0, 3, cone_cold_rounds);
+        if (r == 0) return finish(0);
+        if (verbose) printf("pmpc_hip: cold cone rounds not settled (%d): path-following iteration\n", r);
+      }
+      HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+    }
+    return soc_interior_point();
+  }
   const bool as_can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && fast;
   // (the caller's U_prev is the stored set's solution; one rank only: the shared controls' base must be the same on every rank,
   //  which only this context's own copy guarantees when a caller breaks its promise)

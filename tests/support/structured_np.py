@@ -92,7 +92,8 @@ class StructuredLQ:
         self.allreduce = allreduce or (lambda a: a)  # sums (H,g) over shards
 
     def factor(self, Dx=None, Du=None, Dc=None):
-        """Dx (M,N,x), Du (M,N,u) extra diagonals (Du ignored on consensus stages), Dc (Nc*u,)."""
+        """Dx (M,N,x), Du (M,N,u) extra diagonals — or (M,N,u,u) full symmetric blocks — (Du ignored on consensus stages),
+        Dc (Nc*u,) diagonal or (Nc*u, Nc*u) full block of the summed consensus system."""
         p = self.p
         M, N, x, u, Nc = p.M, p.N, p.x, p.u, p.Nc
         w = u if p.slew else 0
@@ -114,7 +115,7 @@ class StructuredLQ:
         self.Huu_inv = np.zeros((M, N, u, u))
         for j in range(N - 1, Nc - 1, -1):
             H = np.einsum("mab,mac,mcd->mbd", F[:, j], S, F[:, j])
-            H[:, n:, n:] += p.Rt[:, j] + Du[:, j][..., None] * np.eye(u)
+            H[:, n:, n:] += p.Rt[:, j] + (Du[:, j] if Du.ndim == 4 else Du[:, j][..., None] * np.eye(u))  # (ndim 4: full u x u blocks)
             if w and j > 0:
                 H[:, n:, x:n] -= p.s[:, None, None] * np.eye(u)
                 H[:, x:n, n:] -= p.s[:, None, None] * np.eye(u)
@@ -151,7 +152,7 @@ class StructuredLQ:
             self.Phi = Phi
             Hsum = self.allreduce(Hc.sum(0))
             if Dc is not None:
-                Hsum = Hsum + np.diag(Dc)
+                Hsum = Hsum + (Dc if np.ndim(Dc) == 2 else np.diag(Dc))
             self.Hc_chol = np.linalg.cholesky(Hsum)
         return self
 
