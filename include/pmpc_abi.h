@@ -138,6 +138,19 @@ typedef struct pmpc_problem {
   const double *soc_W, *soc_w0, *soc_v;
   double soc_v0;
   const double *soc_u_interior;
+  /* General form of the stage cones (pmpc_lsoc_solve_device; the structured case of the reference's `extra_cstrs` tuples,
+   * PMPC.jl/src/main.jl:293-316, that stays inside ONE stage's controls): `cone_count` cones on the controls of every
+   * (particle, stage); cone k has cone_sizes[k] + 1 rows — cone_sizes[k] = 0: a linear row s >= 0 (several of them: a
+   * stage-wise polytope), >= 1: the second-order cone |s[1..]| <= s[0] —, s = A u + c with the rows of all cones stacked:
+   * cone_A (rows x udim, row-major), cone_c (rows), both DEVICE pointers.  cone_per_stage = 0: one (A, c) for every stage;
+   * 1: per (particle, stage) data, (M, N, rows, udim) / (M, N, rows) — the consensus stages use particle 0's.  cone_sizes is a
+   * HOST array.  At most 4 cones, 8 rows, cone size <= 3.  cone_count = 0: the single cone soc_* above.  Solved by the
+   * active-set rounds (kernels_cone.hip) from soc_u_interior (or from U_prev if that is NULL); the general form has no
+   * path-following fallback: rounds that do not settle are a failed solve (status 1). */
+  size_t cone_count;
+  const int *cone_sizes;
+  const double *cone_A, *cone_c;
+  int cone_per_stage;
   /* cone path only (pmpc_lcone_solve_device): the reference's `k` setting (PMPC.jl/src/main.jl:204-227), the weight
    * (1 - eps) k of the epigraph offset t in  (1 + eps) sum_i y_i + (1 - eps) k t,  J_i <= y_i + t,  y >= 0.  k = M (the
    * default, and the only value its C ABI reaches) is the sum of the particle costs up to the eps-anchoring; k < M is a

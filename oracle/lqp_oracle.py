@@ -778,3 +778,94 @@ def lsoc_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, r
         mu = max(0.2 * mu, mu_final)
     X, U = split_vars(qp, z)
     return (X, U, dict(newton=newton, mu=mu)) if return_info else (X, U)
+
+
+# -------------------------------------------------------------------------------------------------
+# general conic rows over the joint variable vector (the reference's `extra_cstrs` tuples, PMPC.jl/src/main.jl:293-316 with the
+# sign conventions of cone_solver.jl:163-177: linear rows  h - G z >= 0,  second-order cones  G z - h in SOC)
+# -------------------------------------------------------------------------------------------------
+def lconic_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, u_l=None, u_u=None, x_l=None, x_u=None,
+                    lin=None, socs=(), weights=None, z0=None, mu_final=1e-13, return_info=False):
+    """The joint QP of `lqp_solve_py` (optionally with per-particle cost `weights`) plus ARBITRARY conic rows over
+    z = [U_cons; U_free; X] (lqp_utils.jl:12-15):  `lin = (G, h)`: rows  G z <= h;  `socs = [(G_k, h_k), ...]`: G_k z - h_k in the
+    second-order cone {(t, x): |x| <= t}.  Independent of the device code: primal log-barrier path following on the sparse joint
+    KKT system (boxes, rows and cones all through their barriers), Newton to a decrement below 1e-12 at every mu, mu -> mu_final.
+    `z0`: a strictly feasible start for the CONTROL part (n_controls,) (the states follow from the dynamics); default: the
+    unconstrained-in-the-cones box centre is NOT guessed — the caller passes one."""
+    f = _f64(f)
+    M, N, xdim = f.shape
+    udim = np.shape(fu)[-1]
+    nan = np.full(1, np.nan)
+    bxu = lambda z: nan if z is None else np.broadcast_to(_f64(z), (M, N, udim)).copy()
+    bxx = lambda z: nan if z is None else np.broadcast_to(_f64(z), (M, N, xdim)).copy()
+    qp = assemble_abi(xdim, udim, N, M, Nc, f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev), to_abi_mat(Q), to_abi_mat(R),
+                      _f64(X_ref), _f64(U_ref), bxx(x_l), bxx(x_u), bxu(u_l), bxu(u_u), float(reg_x), float(reg_u), nan, nan, nan,
+                      weights=weights)
+    P, q, A, b, G, l, u = effective_P(qp.P), qp.q, qp.A, qp.b, qp.G, qp.l, qp.u
+    n = P.shape[0]
+    Ncc = qp.Nc
+    ncu = Ncc * udim + M * (N - Ncc) * udim
+    ml, mh = np.isfinite(l), np.isfinite(u)
+    # stack: box sides as linear rows  Gb z <= hb
+    rows = [(-G)[ml], G[mh]]
+    rhs = [-l[ml], u[mh]]
+    if lin is not None:
+        rows.append(sp.csr_matrix(lin[0]))
+        rhs.append(_f64(lin[1]).reshape(-1))
+    GL = sp.vstack(rows).tocsr() if sum(r.shape[0] for r in rows) else sp.csr_matrix((0, n))
+    hL = np.concatenate(rhs) if GL.shape[0] else np.zeros(0)
+    socs = [(sp.csr_matrix(Gk), _f64(hk).reshape(-1)) for Gk, hk in socs]
+    z = np.zeros(n)
+    assert z0 is not None, "pass a strictly feasible control vector z0 (ncontrols,)"
+    z[:ncu] = _f64(z0).reshape(-1)
+    z[ncu:] = spla.spsolve(A[:, ncu:].tocsc(), b - A[:, :ncu] @ z[:ncu])
+
+    def barrier(z):
+        sL = hL - GL @ z
+        if np.any(sL <= 0):
+            return None
+        val = -np.sum(np.log(sL))
+        g = GL.T @ (1.0 / sL)
+        H = (GL.T @ sp.diags(1.0 / sL ** 2) @ GL).tocsc()
+        for Gk, hk in socs:
+            s = Gk @ z - hk
+            d = s[0] * s[0] - np.sum(s[1:] * s[1:])
+            if s[0] <= 0 or d <= 0:
+                return None
+            Js = np.concatenate([[s[0]], -s[1:]])
+            val -= np.log(d)
+            g = g + Gk.T @ (-2.0 * Js / d)
+            J = np.diag(np.concatenate([[1.0], -np.ones(s.size - 1)]))
+            W = 4.0 * np.outer(Js, Js) / (d * d) - 2.0 * J / d
+            H = H + (Gk.T @ sp.csr_matrix(W) @ Gk).tocsc()
+        return val, g, H.tocsc()
+
+    if barrier(z) is None:
+        raise ValueError("lconic_solve_py: z0 is not strictly feasible")
+    mu, newton = 1.0, 0
+    while True:
+        for _ in range(200):
+            val, g, H = barrier(z)
+            grad = P @ z + q + mu * g
+            dz, dy, _ = _kkt_solve((P + mu * H).tocsc(), A, sp.csc_matrix((0, n)), -grad, np.zeros(A.shape[0]), np.zeros(0))
+            dec = float(-grad @ dz)
+            if dec <= 1e-12 * max(1.0, mu):
+                break
+            t = 1.0
+            m0 = 0.5 * z @ (P @ z) + q @ z + mu * val
+            while True:
+                zt = z + t * dz
+                bt = barrier(zt)
+                if bt is not None and 0.5 * zt @ (P @ zt) + q @ zt + mu * bt[0] <= m0 - 1e-4 * t * dec:
+                    break
+                t *= 0.5
+                if t < 1e-14:
+                    raise RuntimeError("conic oracle: line search failed")
+            z = zt
+            newton += 1
+        if mu <= mu_final:
+            break
+        mu = max(0.2 * mu, mu_final)
+    X, U = split_vars(qp, z)
+    return (X, U, dict(newton=newton, mu=mu)) if return_info else (X, U)
+

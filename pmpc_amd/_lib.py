@@ -35,7 +35,9 @@ class PmpcProblem(ctypes.Structure):
         + [(k, ctypes.c_void_p) for k in ("x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref",
                                           "lx", "ux", "lu", "uu", "slew_reg", "slew_reg0", "slew_um1", "X_out", "U_out", "weights")]
         + [("barrier_mu", ctypes.c_double), ("soc_q", ctypes.c_size_t), ("soc_W", ctypes.c_void_p), ("soc_w0", ctypes.c_void_p),
-           ("soc_v", ctypes.c_void_p), ("soc_v0", ctypes.c_double), ("soc_u_interior", ctypes.c_void_p), ("cone_k", ctypes.c_longlong)]
+           ("soc_v", ctypes.c_void_p), ("soc_v0", ctypes.c_double), ("soc_u_interior", ctypes.c_void_p),
+           ("cone_count", ctypes.c_size_t), ("cone_sizes", ctypes.POINTER(ctypes.c_int)), ("cone_A", ctypes.c_void_p), ("cone_c", ctypes.c_void_p),
+           ("cone_per_stage", ctypes.c_int), ("cone_k", ctypes.c_longlong)]
     )
 
 

@@ -145,7 +145,8 @@ def _aff_solve_stage_cone(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg
     global _SOC_SOLVER
     if slew_rate or u_slew is not None or (x_l is not None and np.size(x_l)):
         raise ValueError("extra_cstrs (stage-wise second-order cone): slew penalties and state boxes are not supported on this path")
-    if u_l is None or np.size(u_l) == 0:
+    general = "cones" in soc
+    if not general and (u_l is None or np.size(u_l) == 0):
         raise ValueError("extra_cstrs (stage-wise second-order cone): control boxes are required (the method starts strictly inside them)")
     if _SOC_SOLVER is None:
         _SOC_SOLVER = DeviceSolver(0)
@@ -157,22 +158,30 @@ def _aff_solve_stage_cone(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg
     ignored = [k for k in ("smooth_alpha", "smooth_cstr", "k", "weights") if solver_settings.get(k) is not None
                and not (k == "smooth_alpha" and isinstance(solver_settings[k], float) and math.isnan(solver_settings[k]))]
     if ignored:
-        raise ValueError(f"extra_cstrs (stage-wise second-order cone): solver_settings {ignored} are not supported together with a "
-                         "stage cone (this path minimises the plain sum of the particle costs with hard boxes)")
-    u_int = solver_settings.get("soc_u_interior")
-    lo_all, hi_all = np.asarray(u_l, dtype=np.float64), np.asarray(u_u, dtype=np.float64)
-    if u_int is None:  # a point strictly inside EVERY stage's box: the centre of the intersection of the boxes
-        u_int = 0.5 * (lo_all.reshape(-1, lo_all.shape[-1]).max(0) + hi_all.reshape(-1, hi_all.shape[-1]).min(0))
-    u_int = np.asarray(u_int, dtype=np.float64).reshape(-1)
-    margin = float(np.dot(soc["v"], u_int) + soc["v0"] - np.linalg.norm(np.asarray(soc["W"]) @ u_int + soc["w0"]))
-    if not (np.all(lo_all < u_int) and np.all(u_int < hi_all) and margin > 0.0):
-        raise ValueError("extra_cstrs (stage-wise second-order cone): solver_settings['soc_u_interior'] must lie strictly inside "
-                         f"every stage's control box and the cone (cone margin {margin:.3e}); the default — the centre of the "
-                         "boxes' intersection — does not: pass one explicitly")
+        raise ValueError(f"extra_cstrs (stage cones): solver_settings {ignored} are not supported together with stage cones "
+                         "(this path minimises the plain sum of the particle costs with hard boxes)")
     Nc = solver_settings.get("Nc", -1)
-    X, U, status = s.lsoc_solve(f=t(f), fx=tm(fx), fu=tm(fu), X_prev=t(X_prev), U_prev=t(U_prev), Q=tm(Q), R=tm(R), X_ref=t(X_ref),
-                                U_ref=t(U_ref), reg_x=float(reg_x), reg_u=float(reg_u), Nc=Nc, x0=t(x0), lu=t(u_l), uu=t(u_u),
-                                soc_W=t(soc["W"]), soc_w0=t(soc["w0"]), soc_v=t(soc["v"]), soc_v0=float(soc["v0"]), soc_u_interior=t(u_int))
+    boxes = dict(lu=t(u_l), uu=t(u_u)) if u_l is not None and np.size(u_l) else {}
+    sym = bool(np.array_equal(Q, np.swapaxes(Q, -1, -2)) and np.array_equal(R, np.swapaxes(R, -1, -2)))
+    common = dict(f=t(f), fx=tm(fx), fu=tm(fu), X_prev=t(X_prev), U_prev=t(U_prev), Q=tm(Q), R=tm(R), X_ref=t(X_ref), U_ref=t(U_ref),
+                  reg_x=float(reg_x), reg_u=float(reg_u), Nc=Nc, x0=t(x0), symmetric_cost=sym, **boxes)
+    u_int = solver_settings.get("soc_u_interior")
+    if general:
+        cn = soc["cones"]
+        X, U, status = s.lsoc_solve(cones=dict(sizes=cn["sizes"], A=t(cn["A"]), c=t(cn["c"])),
+                                    soc_u_interior=None if u_int is None else t(np.asarray(u_int, dtype=np.float64).reshape(-1)), **common)
+    else:
+        lo_all, hi_all = np.asarray(u_l, dtype=np.float64), np.asarray(u_u, dtype=np.float64)
+        if u_int is None:  # a point strictly inside EVERY stage's box: the centre of the intersection of the boxes
+            u_int = 0.5 * (lo_all.reshape(-1, lo_all.shape[-1]).max(0) + hi_all.reshape(-1, hi_all.shape[-1]).min(0))
+        u_int = np.asarray(u_int, dtype=np.float64).reshape(-1)
+        margin = float(np.dot(soc["v"], u_int) + soc["v0"] - np.linalg.norm(np.asarray(soc["W"]) @ u_int + soc["w0"]))
+        if not (np.all(lo_all < u_int) and np.all(u_int < hi_all) and margin > 0.0):
+            raise ValueError("extra_cstrs (stage-wise second-order cone): solver_settings['soc_u_interior'] must lie strictly inside "
+                             f"every stage's control box and the cone (cone margin {margin:.3e}); the default — the centre of the "
+                             "boxes' intersection — does not: pass one explicitly")
+        X, U, status = s.lsoc_solve(soc_W=t(soc["W"]), soc_w0=t(soc["w0"]), soc_v=t(soc["v"]), soc_v0=float(soc["v0"]), soc_u_interior=t(u_int),
+                                    **common)
     s.sync()
     X, U = X.cpu().numpy(), U.cpu().numpy()
     if status != 0:
@@ -200,22 +209,17 @@ def aff_solve(
     # back end implements are folded in here; anything else is REFUSED, never dropped silently
     soc = None
     if solver_settings.get("extra_cstrs"):
-        from .extra_cstrs import linear_rows_to_boxes, stage_soc_from_extra_cstrs
+        from .extra_cstrs import linear_rows_to_boxes, stage_cones_from_extra_cstrs, stage_soc_from_extra_cstrs
 
         Mb, Nb, xd, ud = f.shape[0], f.shape[1], f.shape[2], fu.shape[-1]
         Ncb = solver_settings.get("Nc", -1)
+        rest = []
         for cstr in solver_settings["extra_cstrs"]:
             try:  # single-variable linear rows: boxes
                 bx = linear_rows_to_boxes(cstr, Mb, Nb, xd, ud, Ncb)
-            except ValueError as e_lin:
-                try:  # one second-order cone on the controls of every stage
-                    if soc is not None:
-                        raise ValueError("more than one stage-wise second-order cone")
-                    soc = stage_soc_from_extra_cstrs(cstr, Mb, Nb, xd, ud, Ncb)
-                    continue
-                except ValueError as e_soc:
-                    raise ValueError("extra_cstrs: supported are linear rows on single variables (boxes) and one second-order cone "
-                                     f"on the controls of every stage; this tuple is neither ({e_lin}; {e_soc})") from None
+            except ValueError:
+                rest.append(cstr)
+                continue
             merged = []
             for cur, new, is_lo, like in ((x_l, bx[0], True, X_prev), (x_u, bx[1], False, X_prev), (u_l, bx[2], True, U_prev), (u_u, bx[3], False, U_prev)):
                 if np.all(np.isinf(new)):
@@ -231,6 +235,20 @@ def aff_solve(
             if (u_l is None or u_l.size == 0) != (u_u is None or u_u.size == 0):
                 u_l = np.full(U_prev.shape, -np.inf) if u_l is None or u_l.size == 0 else u_l
                 u_u = np.full(U_prev.shape, np.inf) if u_u is None or u_u.size == 0 else u_u
+        if rest:
+            # conic rows inside one stage's controls: ONE second-order cone with the same data on every stage keeps the
+            # path-following fallback (soc); anything else stage-local goes to the general form (several cones / linear rows
+            # per stage, stage-dependent data); what is neither is REFUSED with the reason, never dropped silently
+            try:
+                if len(rest) != 1:
+                    raise ValueError("several tuples")
+                soc = stage_soc_from_extra_cstrs(rest[0], Mb, Nb, xd, ud, Ncb)
+            except ValueError as e_soc:
+                try:
+                    soc = dict(cones=stage_cones_from_extra_cstrs(rest, Mb, Nb, xd, ud, Ncb))
+                except ValueError as e_gen:
+                    raise ValueError("extra_cstrs: supported are linear rows and second-order cones on the controls of ONE stage (the same "
+                                     f"list of cones on every stage); this is not ({e_gen}; as a single uniform cone: {e_soc})") from None
     if soc is not None:
         return _aff_solve_stage_cone(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, slew_rate, u_slew, x_l, x_u, u_l, u_u,
                                      solver_settings, soc)

@@ -222,6 +222,199 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
   }
 }
 
+// General form: `ncones` cones per (particle, stage), cone k with qs[k] + 1 rows (qs[k] = 0: a linear row s >= 0, i.e. the cone R+,
+// whose projection has the interior and the polar case only), rows stacked in A (rows x UD) / c (rows); per_stage: every
+// (particle, stage) has its own (A, c).  Same arithmetic as k_cone_step, cone by cone; the Newton terms add up.
+template <int UD>
+__global__ void __launch_bounds__(256) k_cone_step_multi(ConeArgs a) {
+  if (a.done && *a.done) return;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long nrows = (long long)a.M * a.N;
+  if (idx >= nrows) return;
+  const int i = (int)(idx / a.N), j = (int)(idx - (long long)i * a.N);
+  constexpr int QM = 3, Q1M = QM + 1;
+  const int R = a.rows;
+  // shared controls carry ONE set of cones: particle 0's data on the consensus stages
+  const long long didx = a.per_stage ? ((j < a.Nc) ? (long long)j : idx) : 0;
+  const double *Ag = a.A + didx * R * UD, *cg = a.c + didx * R;
+  double u[UD], ur[UD];
+#pragma unroll
+  for (int k = 0; k < UD; k++) { u[k] = a.U[idx * UD + k]; ur[k] = a.finish ? a.Uraw[idx * UD + k] : 0.0; }
+  double tr = 0.0;
+#pragma unroll
+  for (int k = 0; k < UD; k++) tr += a.R[idx * UD * UD + k * (UD + 1)];
+  const double rho = a.rho_scale * (tr / UD + a.reg_u);
+  double H[UD][UD], g[UD];
+#pragma unroll
+  for (int p = 0; p < UD; p++) {
+    g[p] = 0.0;
+#pragma unroll
+    for (int q = 0; q < UD; q++) H[p][q] = 0.0;
+  }
+  int changed = 0, open = 0, row0 = 0;
+  bool bad = false;
+  const double rs2 = 0.70710678118654752440;
+  for (int kc = 0; kc < a.ncones; kc++) {
+    const int Q = a.qs[kc], Q1 = Q + 1;
+    double A[Q1M][UD], cc[Q1M], s[Q1M], z[Q1M];
+#pragma unroll
+    for (int r = 0; r < Q1M; r++) {
+      const bool rv = r < Q1;
+      cc[r] = rv ? cg[row0 + (rv ? r : 0)] : 0.0;
+#pragma unroll
+      for (int k = 0; k < UD; k++) A[r][k] = rv ? Ag[(row0 + (rv ? r : 0)) * UD + k] : 0.0;
+      double v = cc[r];
+#pragma unroll
+      for (int k = 0; k < UD; k++) v = fma(A[r][k], u[k], v);
+      s[r] = v;
+      z[r] = rv ? a.z[idx * R + row0 + (rv ? r : 0)] : 0.0;
+      bad |= !(v == v);
+    }
+    auto classify = [&](const double *sv, const double *zv, double *wh, double &w0, double &nb) -> int {
+      double wb[QM], n2 = 0.0;
+      w0 = sv[0] - zv[0];
+#pragma unroll
+      for (int r = 0; r < QM; r++) { wb[r] = r < Q ? sv[r + 1] - zv[r + 1] : 0.0; n2 = fma(wb[r], wb[r], n2); }
+      nb = sqrt(n2);
+      const double inv = nb > 0.0 ? 1.0 / nb : 0.0;
+#pragma unroll
+      for (int r = 0; r < QM; r++) wh[r] = wb[r] * inv;
+      return nb <= w0 ? 0 : (nb <= -w0 ? 2 : 1);
+    };
+    double *rec = a.rec + (idx * a.ncones + kc) * PMPC_CONE_REC;
+    if (a.finish) {
+      const int case_old = (int)rec[0];
+      const double rho_o = rec[1], curv = rec[2], nu_hat = rec[3];
+      double wh_o[QM], sb_o[Q1M], sr[Q1M], zn[Q1M];
+#pragma unroll
+      for (int r = 0; r < QM; r++) wh_o[r] = r < Q ? rec[4 + (r < Q ? r : 0)] : 0.0;
+#pragma unroll
+      for (int r = 0; r < Q1M; r++) {
+        sb_o[r] = r < Q1 ? rec[4 + Q + (r < Q1 ? r : 0)] : 0.0;
+        double v = cc[r];
+#pragma unroll
+        for (int k = 0; k < UD; k++) v = fma(A[r][k], ur[k], v);
+        sr[r] = v;
+      }
+      if (case_old == 1) {
+        double es = sr[0], whs = 0.0;
+#pragma unroll
+        for (int r = 0; r < QM; r++) { es = fma(-wh_o[r], sr[r + 1], es); whs = fma(wh_o[r], sr[r + 1], whs); }
+        es *= rs2;
+        const double nu = nu_hat - rho_o * es;
+        zn[0] = nu * rs2;
+#pragma unroll
+        for (int r = 0; r < QM; r++) zn[r + 1] = r < Q ? -nu * rs2 * wh_o[r] - curv * (sr[r + 1] - whs * wh_o[r]) : 0.0;
+      } else if (case_old == 2) {
+#pragma unroll
+        for (int r = 0; r < Q1M; r++) zn[r] = r < Q1 ? z[r] - rho_o * sr[r] : 0.0;
+      } else {
+#pragma unroll
+        for (int r = 0; r < Q1M; r++) zn[r] = 0.0;
+      }
+      double wh_n[QM], w0, nb;
+      const int case_new = classify(s, zn, wh_n, w0, nb);
+      if (case_new == 0) {
+#pragma unroll
+        for (int r = 0; r < Q1M; r++) zn[r] = 0.0;
+      }
+      const int ch = case_new != case_old;
+      changed += ch;
+      double ns = 0.0, nz = 0.0, ds = 0.0, dz = 0.0;
+#pragma unroll
+      for (int r = 0; r < Q1M; r++) {
+        ns = fmax(ns, fabs(s[r])); nz = fmax(nz, fabs(zn[r]));
+        ds = fmax(ds, fabs(s[r] - sb_o[r])); dz = fmax(dz, fabs(zn[r] - z[r]));
+      }
+      if (!ch && case_new == 1) {
+        const double lam = 0.5 * (w0 + nb);
+        double phi = fabs(s[0] - lam);
+#pragma unroll
+        for (int r = 0; r < QM; r++) phi = fmax(phi, r < Q ? fabs(s[r + 1] - lam * wh_n[r]) : 0.0);
+        open += (ds > a.tol_step * fmax(1.0, ns) || dz > a.tol_step * fmax(a.dual_scale, nz) || phi > a.tol_phi * fmax(1.0, ns)) ? 1 : 0;
+      } else if (!ch && case_new == 2) {
+        open += (ns > a.tol_phi || dz > a.tol_step * fmax(a.dual_scale, nz)) ? 1 : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < Q1M; r++) {
+        z[r] = zn[r];
+        bad |= !(zn[r] == zn[r]);
+        if (r < Q1) a.z[idx * R + row0 + r] = zn[r];
+      }
+    }
+    // ---- Newton terms of this cone at (u, z) -------------------------------------------------------------------------------------
+    double wh[QM], w0, nb;
+    const int cs = classify(s, z, wh, w0, nb);
+    double curv = 0.0, nu_hat = 0.0;
+    if (cs == 1) {
+      const double theta = 0.5 * (1.0 + w0 / nb);
+      curv = (1.0 - theta) / theta;
+      double am[UD], es = s[0], whs = 0.0;
+      nu_hat = z[0];
+#pragma unroll
+      for (int r = 0; r < QM; r++) { es = fma(-wh[r], s[r + 1], es); nu_hat = fma(-wh[r], z[r + 1], nu_hat); whs = fma(wh[r], s[r + 1], whs); }
+      es *= rs2; nu_hat *= rs2;
+      double T[QM][UD];
+#pragma unroll
+      for (int k = 0; k < UD; k++) {
+        double v = A[0][k], wa = 0.0;
+#pragma unroll
+        for (int r = 0; r < QM; r++) { v = fma(-wh[r], A[r + 1][k], v); wa = fma(wh[r], A[r + 1][k], wa); }
+        am[k] = v * rs2;
+#pragma unroll
+        for (int r = 0; r < QM; r++) T[r][k] = r < Q ? A[r + 1][k] - wh[r] * wa : 0.0;
+      }
+      const double gm = -nu_hat + rho * es;
+#pragma unroll
+      for (int p = 0; p < UD; p++) {
+        double gt = 0.0;
+#pragma unroll
+        for (int r = 0; r < QM; r++) gt = fma(T[r][p], s[r + 1], gt);
+        g[p] += curv * gt + gm * am[p];
+#pragma unroll
+        for (int q = 0; q < UD; q++) {
+          double tt = 0.0;
+#pragma unroll
+          for (int r = 0; r < QM; r++) tt = fma(T[r][p], T[r][q], tt);
+          H[p][q] += curv * tt + rho * am[p] * am[q];
+        }
+      }
+    } else if (cs == 2) {
+#pragma unroll
+      for (int p = 0; p < UD; p++) {
+        double gv = 0.0;
+#pragma unroll
+        for (int r = 0; r < Q1M; r++) gv = fma(A[r][p], -z[r] + rho * s[r], gv);  // (rows beyond the cone are zero)
+        g[p] += gv;
+#pragma unroll
+        for (int q = 0; q < UD; q++) {
+          double t = 0.0;
+#pragma unroll
+          for (int r = 0; r < Q1M; r++) t = fma(A[r][p], A[r][q], t);
+          H[p][q] += rho * t;
+        }
+      }
+    }
+    rec[0] = (double)cs; rec[1] = rho; rec[2] = curv; rec[3] = nu_hat;
+    for (int r = 0; r < Q; r++) rec[4 + r] = wh[r];
+    for (int r = 0; r < Q1; r++) rec[4 + Q + r] = s[r];
+    row0 += Q1;
+  }
+#pragma unroll
+  for (int q = 0; q < UD; q++)
+#pragma unroll
+    for (int p = 0; p < UD; p++) a.H[idx * UD * UD + q * UD + p] = H[p][q];
+#pragma unroll
+  for (int p = 0; p < UD; p++) a.g[idx * UD + p] = g[p];
+  const bool counts = j >= a.Nc || (i == 0 && a.owner);
+  if (a.finish && counts) {
+    if (changed) atomicAdd(&a.cnt[3 * i + 1], changed);
+    if (open) atomicAdd(&a.open[i], open);
+    if (changed || open) a.settled[i] = 0;
+    if (bad) a.cnt[3 * i + 2] = 1;
+  }
+}
+
 // a lower box side that the cone's s0 >= 0 implies (v has ONE nonzero v_k > 0 and lo_k <= -v0 / v_k: thrust >= 0 next to the
 // thrust cone) is dropped: at the apex the cone holds that control, and a box active on top of it would leave the multipliers
 // without a unique split — the active-set rule would flip between the two for ever
@@ -237,11 +430,18 @@ __global__ void k_cone_drop_lo(double *lo, const double *A, const double *c, lon
 
 }  // namespace
 
-bool cone_as_supported(int u, int q) { return u >= 2 && u <= 4 && q >= 1 && q <= 3; }
+bool cone_as_supported(int u, int q) { return u >= 2 && u <= 4 && q >= 0 && q <= 3; }
 
 void launch_cone_step(const ConeArgs &a, hipStream_t s) {
   const long long rows = (long long)a.M * a.N;
   const dim3 grd((unsigned)((rows + 255) / 256)), blk(256);
+  if (a.ncones != 1 || a.per_stage || a.qs[0] < 1) {  // the general form
+    if (a.u == 4) hipLaunchKernelGGL((k_cone_step_multi<4>), grd, blk, 0, s, a);
+    else if (a.u == 3) hipLaunchKernelGGL((k_cone_step_multi<3>), grd, blk, 0, s, a);
+    else if (a.u == 2) hipLaunchKernelGGL((k_cone_step_multi<2>), grd, blk, 0, s, a);
+    else abort();
+    return;
+  }
 #define PMPC_CONE(UD, Q) if (a.u == UD && a.q == Q) { hipLaunchKernelGGL((k_cone_step<UD, Q>), grd, blk, 0, s, a); return; }
   PMPC_CONE(4, 2) PMPC_CONE(4, 1) PMPC_CONE(4, 3) PMPC_CONE(3, 2) PMPC_CONE(3, 1) PMPC_CONE(3, 3) PMPC_CONE(2, 1) PMPC_CONE(2, 2) PMPC_CONE(2, 3)
 #undef PMPC_CONE

@@ -231,10 +231,12 @@ void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int 
 struct ConeArgs {
   int M, N, u, q, Nc, owner;
   const double *U, *Uraw;     // new base controls / each stage's raw Newton step (finish); U alone for the first preparation
-  const double *A, *c;        // cone data, device: A = [v'; W] ((q+1) x u, row-major), c = (v0, w0)
+  const double *A, *c;        // cone data, device: A = [v'; W] ((q+1) x u, row-major), c = (v0, w0) — general form: the rows of
+                              // all cones stacked (rows x u), per (particle, stage) if per_stage
+  int ncones, qs[4], rows, per_stage;  // general form: cones per stage, their sizes (0 = linear row), total rows; 1 cone, shared data, q >= 1: k_cone_step
   const double *R;            // cost blocks (penalty scale rho = rho_scale * (trace(R)/u + reg_u))
   double reg_u, rho_scale;
-  double *z, *rec;            // multipliers (M,N,q+1) and the per-stage record of the prepared round (M,N,PMPC_CONE_REC)
+  double *z, *rec;            // multipliers (M,N,rows) and the per-cone record of the prepared round (M,N,ncones,PMPC_CONE_REC)
   double *H, *g;              // outputs: Newton terms (M,N,u,u) column-major blocks, (M,N,u)
   int *cnt, *settled, *open;  // per particle: as_cnt (3 ints: case changes are added to [1]), settled flag (cleared), open cones
   const int *done;

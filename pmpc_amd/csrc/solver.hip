@@ -864,17 +864,35 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   }
   const int B = PMPC_RED_BLOCKS;
 
-  if (soc && (has_xb || p->weights || a.any_slew || p->soc_u_interior == nullptr || (p->soc_q > 0 && (!p->soc_W || !p->soc_w0 || !p->soc_v)) ||
-              u > 8 || p->soc_q > 4)) {
-    fprintf(stderr, "pmpc_hip: pmpc_lsoc_solve_device supports control boxes + one stage cone (udim <= 8, soc_q <= 4), no state boxes / "
-                    "weights / slew, and needs soc_u_interior\n");
+  // general form of the stage cones (pmpc_problem.cone_count > 0): several cones / linear rows per stage, optionally stage-dependent data
+  const int ncones = soc ? (int)p->cone_count : 0;
+  int cone_rows = 0;
+  bool cones_ok = true;
+  if (ncones > 0) {
+    cones_ok = ncones <= 4 && p->cone_sizes && p->cone_A && p->cone_c;
+    for (int k = 0; cones_ok && k < ncones; k++) {
+      cones_ok = p->cone_sizes[k] >= 0 && p->cone_sizes[k] <= 3;
+      cone_rows += p->cone_sizes[k] + 1;
+    }
+    cones_ok = cones_ok && cone_rows <= 8;
+  }
+  if (soc && (has_xb || a.any_slew || (ncones == 0 && p->soc_u_interior == nullptr) || (ncones == 0 && p->soc_q > 0 && (!p->soc_W || !p->soc_w0 || !p->soc_v)) ||
+              u > 8 || p->soc_q > 4 || !cones_ok)) {
+    fprintf(stderr, "pmpc_hip: pmpc_lsoc_solve_device supports control boxes + stage cones (udim <= 8; one cone soc_q <= 4 with soc_u_interior, or "
+                    "the general form: <= 4 cones of size <= 3, <= 8 rows), no state boxes / slew\n");
     return finish(2);
   }
   // Stage cones inside the active-set rounds (kernels_cone.hip: semismooth Newton on the cones' natural map, boxes by the
   // primal-dual active-set rule) — warm-started from the previous solve's set and multipliers, cold-started from soc_u_interior;
   // the path-following iteration below is the fallback.  PMPC_CONE_AS=0 switches it off.
   static const bool cone_as_env = !(getenv("PMPC_CONE_AS") && atoi(getenv("PMPC_CONE_AS")) == 0);
-  const bool cone_as = soc && cone_as_env && fast && p->soc_q > 0 && cone_as_supported(u, (int)p->soc_q) && cone_as_dims_supported(x, u);
+  const bool cone_as = soc && cone_as_env && fast && cone_as_dims_supported(x, u) &&
+                       (ncones > 0 ? cone_as_supported(u, 0) : (p->soc_q > 0 && cone_as_supported(u, (int)p->soc_q)));
+  if (soc && ncones > 0 && !cone_as) {
+    fprintf(stderr, "pmpc_hip: the general form of the stage cones needs the register-resident path (symmetric cost, compiled dims with udim 2..4)\n");
+    return finish(2);
+  }
+  if (ncones == 0 && soc && p->soc_q > 0) cone_rows = (int)p->soc_q + 1;
   if (soc && !has_ub && cone_as) {  // no boxes: the active-set sweeps still read them — unbounded working copies
     w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
     w.su_key = -1;
@@ -893,7 +911,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       su.lo = w.su.lo.d(); su.hi = w.su.hi.d();
     }
   }
-  if (soc && p->soc_q > 0) {  // cone data as one block A = [v'; W], c = (v0, w0) for kernels_cone.hip
+  if (soc && ncones == 0 && p->soc_q > 0) {  // cone data as one block A = [v'; W], c = (v0, w0) for kernels_cone.hip
     w.cone_A.ensure((size_t)(p->soc_q + 1) * u * D8); w.cone_c.ensure((size_t)(p->soc_q + 1) * D8);
     HIP_CHECK(hipMemcpyAsync(w.cone_A.p, p->soc_v, (size_t)u * D8, hipMemcpyDeviceToDevice, s));
     HIP_CHECK(hipMemcpyAsync(w.cone_A.d() + u, p->soc_W, (size_t)p->soc_q * u * D8, hipMemcpyDeviceToDevice, s));
@@ -1107,7 +1125,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // If the set does not settle the interior-point iteration runs (on), its state untouched.  The rounds act on the control
   // boxes (a state cannot be moved onto its bound without leaving the dynamics; state boxes that do not bind are verified at
   // acceptance, see below); not in barrier mode.  DESIGN.md section 2.4.
-  const long long as_key_pre = (((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0)) * 8 + (soc ? 1 + (long long)p->soc_q : 0);
+  const long long as_key_pre = (((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0)) * 64 + (soc ? 1 + (long long)p->soc_q + 8 * (long long)cone_rows : 0);
   static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
   static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
   static const bool as_skip_on = !(getenv("PMPC_AS_SKIP") && atoi(getenv("PMPC_AS_SKIP")) == 0);
@@ -1145,11 +1163,20 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       const int q = (int)p->soc_q;
       const size_t rows = (size_t)M * N;
       w.Hadd.ensure(nu * u * D8); w.wu_soc.ensure(nu * D8); w.cone_uraw.ensure(nu * D8); w.as_open.ensure((size_t)M * sizeof(int));
-      const bool z_new = w.cone_z.ensure(rows * (q + 1) * D8), rec_new = w.cone_rec.ensure(rows * PMPC_CONE_REC * D8);
+      const bool z_new = w.cone_z.ensure(rows * cone_rows * D8), rec_new = w.cone_rec.ensure(rows * std::max(ncones, 1) * PMPC_CONE_REC * D8);
       if (z_new || rec_new) w.as_key = -1;
       b.cone_H = w.Hadd.d(); b.cone_g = w.wu_soc.d(); b.as_uraw = w.cone_uraw.d(); b.as_open = (int *)w.as_open.p;
       ca.M = M; ca.N = N; ca.u = u; ca.q = q; ca.Nc = Nc; ca.owner = a.owner;
-      ca.A = w.cone_A.d(); ca.c = w.cone_c.d(); ca.R = p->R; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
+      ca.rows = cone_rows;
+      if (ncones > 0) {
+        ca.ncones = ncones; ca.per_stage = p->cone_per_stage ? 1 : 0;
+        for (int k = 0; k < ncones; k++) ca.qs[k] = p->cone_sizes[k];
+        ca.A = p->cone_A; ca.c = p->cone_c;
+      } else {
+        ca.ncones = 1; ca.qs[0] = q; ca.per_stage = 0;
+        ca.A = w.cone_A.d(); ca.c = w.cone_c.d();
+      }
+      ca.R = p->R; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
       ca.z = w.cone_z.d(); ca.rec = w.cone_rec.d(); ca.H = w.Hadd.d(); ca.g = w.wu_soc.d();
       ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done;
       ca.tol_step = 1e-6; ca.tol_phi = 1e-9; ca.dual_scale = dual_scale;
@@ -1166,8 +1193,9 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     if (mode == 3) {  // cold start of the cone rounds: every control at the caller's interior point, nothing held, no multipliers
       ProfScope ps(c, 5);
       HIP_CHECK(hipMemsetAsync(act, 0, nu * sizeof(int) + 8, s));
-      HIP_CHECK(hipMemsetAsync(w.cone_z.p, 0, (size_t)M * N * (p->soc_q + 1) * D8, s));
-      launch_soc_fill_u(p->U_out, p->soc_u_interior, (long long)nu, u, s);
+      HIP_CHECK(hipMemsetAsync(w.cone_z.p, 0, (size_t)M * N * cone_rows * D8, s));
+      if (p->soc_u_interior) launch_soc_fill_u(p->U_out, p->soc_u_interior, (long long)nu, u, s);
+      else HIP_CHECK(hipMemcpyAsync(p->U_out, p->U_prev, nu * D8, hipMemcpyDeviceToDevice, s));  // (any start will do for the rounds)
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     } else if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
       ProfScope ps(c, 5);
@@ -1270,8 +1298,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
       if (verbose > 1 && cone) {  // debugging aid: the active cones' records (small problems only)
         HIP_CHECK(hipStreamSynchronize(s));
-        const int q1 = (int)p->soc_q + 1;
-        std::vector<double> hz((size_t)M * N * q1), hr((size_t)M * N * PMPC_CONE_REC), hu(nu), hraw(nu), hg(nu);
+        const int q1 = cone_rows;
+        std::vector<double> hz((size_t)M * N * q1), hr((size_t)M * N * std::max(ncones, 1) * PMPC_CONE_REC), hu(nu), hraw(nu), hg(nu);
         HIP_CHECK(hipMemcpy(hz.data(), w.cone_z.p, hz.size() * D8, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(hr.data(), w.cone_rec.p, hr.size() * D8, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(hu.data(), p->U_out, nu * D8, hipMemcpyDeviceToHost));
@@ -1455,6 +1483,10 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         if (verbose) printf("pmpc_hip: cold cone rounds not settled (%d): path-following iteration\n", r);
       }
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+    }
+    if (ncones > 0) {  // the general form has no path-following fallback
+      if (verbose) printf("pmpc_hip: stage cones (general form): the rounds did not settle\n");
+      return finish(1);
     }
     return soc_interior_point();
   }

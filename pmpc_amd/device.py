@@ -90,7 +90,7 @@ class DeviceSolver:
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
                  barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, static_cons_bounds=False, prev_is_last_solution=False, soc_W=None, soc_w0=None,
-                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0):
+                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0, cones=None):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
@@ -125,6 +125,15 @@ class DeviceSolver:
             slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu),
             soc_q=0 if soc_W is None else int(soc_W.shape[0]), soc_W=_p(soc_W), soc_w0=_p(soc_w0), soc_v=_p(soc_v), soc_v0=float(soc_v0),
             soc_u_interior=_p(soc_u_interior), cone_k=int(cone_k))
+        if cones is not None:  # general form of the stage cones: dict(sizes=[q_k], A=tensor, c=tensor); per-stage data if A is (M, N, rows, udim)
+            sizes = [int(v) for v in cones["sizes"]]
+            rows = sum(sizes) + len(sizes)
+            A, cvec = cones["A"], cones["c"]
+            per_stage = A.dim() == 4
+            assert A.shape == ((M, N, rows, u) if per_stage else (rows, u)) and cvec.shape == ((M, N, rows) if per_stage else (rows,)), (A.shape, cvec.shape)
+            self._cone_sizes = (ctypes.c_int * len(sizes))(*sizes)  # (kept alive: the struct holds a bare pointer)
+            prob.cone_count, prob.cone_sizes = len(sizes), ctypes.cast(self._cone_sizes, ctypes.POINTER(ctypes.c_int))
+            prob.cone_A, prob.cone_c, prob.cone_per_stage = _p(A), _p(cvec), int(per_stage)
         return prob, X_out, U_out
 
     def lqp_solve(self, *, verbose=False, wait_current_stream=True, **kw):
@@ -155,7 +164,9 @@ class DeviceSolver:
         """`lqp_solve` plus one second-order cone ||W u + w0||_2 <= v'u + v0 on the controls of every (particle, stage) —
         `soc_W (q, udim)`, `soc_w0 (q)`, `soc_v (udim)`, `soc_v0`, and `soc_u_interior (udim)`, a control strictly inside
         the boxes and the cone (all float64 CUDA tensors).  Config E's thrust cones; the structured case of the reference's
-        pyjulia-only `extra_cstrs` (README.md:219-239)."""
+        pyjulia-only `extra_cstrs` (README.md:219-239).  General form: `cones=dict(sizes=[q_k, ...], A=..., c=...)` — several
+        cones per stage, cone k with q_k + 1 rows of `s = A u + c` (q_k = 0: a linear row s >= 0; q_k >= 1: |s[1:]| <= s[0]),
+        `A (rows, udim)` / `c (rows,)` shared by all stages or `A (M, N, rows, udim)` / `c (M, N, rows)` per stage; `weights` allowed.
         prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
         self._before(wait_current_stream)

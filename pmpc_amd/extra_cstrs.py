@@ -128,3 +128,80 @@ def linear_rows_to_boxes(cstr: Sequence[Any], M: int, N: int, xdim: int, udim: i
         else:
             lo[idx] = np.maximum(lo[idx], bound)
     return x_l, x_u, u_l, u_u
+
+
+def stage_cones_from_extra_cstrs(cstrs: Sequence[Sequence[Any]], M: int, N: int, xdim: int, udim: int, Nc: int) -> Dict[str, Any]:
+    """Several `extra_cstrs` tuples -> the device solver's general stage-cone form (`DeviceSolver.lsoc_solve(cones=...)`).
+    Accepted: linear rows (`l`, rows  G z <= h  — cone_solver.jl:163-166) and second-order cones (`q`, G z - h in SOC,
+    cone_solver.jl:167-177) whose nonzeros all lie on the controls of ONE stage block — one particle's free stage, or one shared
+    consensus stage — with the SAME list of cone sizes on every block (the data may differ from stage to stage).  Refused with
+    the reason: exponential cones, new variables, cost terms, rows on states, rows spanning stages, blocks with different
+    structures, more than 4 cones / 8 rows per stage or cones larger than 4 rows.
+    Returns dict(sizes=[q_k], A, c) with `s = A u + c`: per-stage arrays `A (M, N, rows, udim)`, `c (M, N, rows)` (a shared
+    control's block is replicated over the particles)."""
+    Ncc = N if Nc < 0 else min(int(Nc), N)
+    Nf = N - Ncc
+    ncu = Ncc * udim + M * Nf * udim
+    n = ncu + M * N * xdim
+    nblocks = ncu // udim
+    per_block = [[] for _ in range(nblocks)]  # (q, A rows (q+1, udim), c (q+1))
+    for cstr in cstrs:
+        l, q, e, G_left, G_right, h, c_left, c_right = cstr
+        q = [int(v) for v in np.atleast_1d(np.asarray(q, dtype=np.int64))] if np.size(q) else []
+        if int(e) != 0:
+            raise ValueError("exponential cones are not supported")
+        if G_right is not None and np.size(G_right) > 0 and sp.csr_matrix(G_right).shape[1] > 0:
+            raise ValueError("rows that introduce new variables (G_right) are not supported")
+        for cv in (c_left, c_right):
+            if cv is not None and np.size(cv) > 0 and np.any(np.asarray(cv, dtype=np.float64) != 0.0):
+                raise ValueError("cost augmentation (c_left / c_right) is not supported")
+        G = sp.csr_matrix(G_left, dtype=np.float64)
+        hv = np.asarray(h, dtype=np.float64).reshape(-1)
+        nr = int(l) + sum(q)
+        if G.shape[0] != nr or hv.size != nr or G.shape[1] > n:
+            raise ValueError(f"G_left must have {nr} rows over (a prefix of) z = [U_cons; U_free; X] ({n} columns), h ({nr},)")
+        if G.shape[1] > ncu and G[:, ncu:].count_nonzero() > 0:
+            raise ValueError("rows on the states are not supported (only the controls of one stage)")
+        G = G[:, :min(G.shape[1], ncu)]
+        pieces = [(0, r, r + 1) for r in range(int(l))]
+        r0 = int(l)
+        for qk in q:
+            if qk > 4 or qk < 2:
+                raise ValueError("second-order cones of 2 .. 4 rows are supported")
+            pieces.append((qk - 1, r0, r0 + qk))
+            r0 += qk
+        for qs, ra, rb in pieces:
+            rows = G[ra:rb]
+            cols = np.unique(rows.indices)
+            if cols.size == 0:
+                raise ValueError(f"rows {ra}..{rb - 1} touch no control")
+            blk = int(cols[0]) // udim
+            if np.any(cols // udim != blk):
+                raise ValueError(f"rows {ra}..{rb - 1} couple the controls of several stages")
+            Ablk = np.zeros((rb - ra, udim))
+            sub = rows[:, blk * udim:min((blk + 1) * udim, rows.shape[1])].toarray()
+            Ablk[:, :sub.shape[1]] = sub
+            if qs == 0:   # G z <= h  ->  s = h - G u >= 0
+                per_block[blk].append((0, -Ablk, hv[ra:rb].copy()))
+            else:         # G z - h in SOC  ->  s = G u - h
+                per_block[blk].append((qs, Ablk, -hv[ra:rb]))
+    sizes = [c_[0] for c_ in per_block[0]]
+    if not sizes:
+        raise ValueError("the first control block carries no constraint: every stage needs the same list of cones")
+    if len(sizes) > 4 or sum(sizes) + len(sizes) > 8:
+        raise ValueError("at most 4 cones and 8 rows per stage are supported")
+    for b, lst in enumerate(per_block):
+        if [c_[0] for c_ in lst] != sizes:
+            raise ValueError(f"control block {b} carries cones of sizes {[c_[0] for c_ in lst]}, block 0 {sizes}: every stage needs the same list")
+    rows_tot = sum(sizes) + len(sizes)
+    A = np.zeros((M, N, rows_tot, udim))
+    c = np.zeros((M, N, rows_tot))
+    for b, lst in enumerate(per_block):
+        Ab, cb = np.vstack([c_[1] for c_ in lst]), np.concatenate([c_[2] for c_ in lst])
+        if b < Ncc:
+            A[:, b], c[:, b] = Ab, cb
+        else:
+            i, j = divmod(b - Ncc, Nf)
+            A[i, Ncc + j], c[i, Ncc + j] = Ab, cb
+    return dict(sizes=sizes, A=A, c=c)
+

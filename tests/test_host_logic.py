@@ -342,7 +342,7 @@ def test_extra_cstrs_linear_rows_become_boxes_and_the_rest_is_refused(monkeypatc
     G2 = G.copy()
     G2[0, 3] = 1.0  # a row coupling two variables
     bad = (4, [], 0, G2.tocsr(), sp.csr_matrix((4, 0)), np.ones(4), np.zeros(n), np.zeros(0))
-    with pytest.raises(ValueError, match="neither"):
+    with pytest.raises(ValueError, match="this is not"):  # (rows on states that couple variables: not a box, not a stage-local cone)
         backend.aff_solve(f, fx, fu, np.zeros((M, x)), z3(x), z3(u), Q, R, z3(x), z3(u), 1.0, 0.1, 0.0, None, empty, empty, empty, empty,
                           solver_settings=dict(solver="osqp", Nc=Nc, extra_cstrs=[bad]))
 
@@ -378,3 +378,51 @@ def test_extra_cstrs_tuple_to_stage_cones():
         stage_soc_from_extra_cstrs((0, cstr[1], 0, cstr[3], cstr[4], h, cstr[6], cstr[7]), M, N, x, u, Nc)
     with pytest.raises(ValueError, match="one cone per control block"):
         stage_soc_from_extra_cstrs((0, cstr[1][:-1], 0, cstr[3][:-3], cstr[4], cstr[5][:-3], cstr[6], cstr[7]), M, N, x, u, Nc)
+
+
+def test_unsupported_extra_cstrs_tuples_are_refused_with_the_reason():
+    """pmpc_amd/extra_cstrs.py recognises stage-local linear rows and second-order cones on the controls; everything else of the
+    reference's tuple format (PMPC.jl/src/main.jl:293-316) is refused with the reason, never dropped."""
+    import scipy.sparse as sp
+
+    from pmpc_amd.extra_cstrs import stage_cones_from_extra_cstrs
+
+    M, N, x, u, Nc = 2, 4, 3, 2, 0
+    ncu, n = M * N * u, M * N * u + M * N * x
+    base = lambda G, l=1, q=(), e=0, Gr=None, cl=None, cr=None: (l, list(q), e, G, sp.csr_matrix((G.shape[0], 0)) if Gr is None else Gr, np.ones(G.shape[0]),
+                                                                 np.zeros(n) if cl is None else cl, np.zeros(0) if cr is None else cr)
+    row = lambda cols: sp.csr_matrix((np.ones(len(cols)), (np.zeros(len(cols), int), cols)), shape=(1, n))
+    with pytest.raises(ValueError, match="several stages"):
+        stage_cones_from_extra_cstrs([base(row([0, u]))], M, N, x, u, Nc)
+    with pytest.raises(ValueError, match="states"):
+        stage_cones_from_extra_cstrs([base(row([0, ncu + 1]))], M, N, x, u, Nc)
+    with pytest.raises(ValueError, match="exponential"):
+        stage_cones_from_extra_cstrs([base(sp.vstack([row([0])] * 3), l=0, e=1)], M, N, x, u, Nc)
+    with pytest.raises(ValueError, match="new variables"):
+        stage_cones_from_extra_cstrs([base(row([0]), Gr=sp.csr_matrix(np.ones((1, 1))))], M, N, x, u, Nc)
+    with pytest.raises(ValueError, match="same list"):
+        stage_cones_from_extra_cstrs([base(row([0]))], M, N, x, u, Nc)  # only block 0 carries a row
+
+
+def test_general_conic_oracle_agrees_with_the_stage_cone_oracle(oracle):
+    """Two independent restatements of the same problem: `lsoc_solve_py` (per-block cone data) and `lconic_solve_py` (arbitrary
+    sparse conic rows over the joint variable vector, here built from the reference-format tuple)."""
+    import scipy.sparse as sp
+
+    from pmpc_amd.extra_cstrs import stage_soc_to_extra_cstrs
+    from tests.support.problems import rand_problem
+
+    M, N, x, u, Nc = 3, 5, 4, 3, 1
+    args, kw = rand_problem(np.random.default_rng(3), M, N, x, u, 0.6)
+    W = np.zeros((2, 3)); W[0, 1] = W[1, 2] = 1.0
+    v, v0, w0, u_int = np.array([0.5, 0, 0]), 0.05, np.zeros(2), np.array([0.2, 0, 0])
+    Xo, Uo = oracle.lsoc_solve_py(*args, Nc=Nc, reg_x=kw["reg_x"], reg_u=kw["reg_u"], u_l=kw["u_l"], u_u=kw["u_u"], soc_W=W, soc_w0=w0, soc_v=v,
+                                  soc_v0=v0, u_interior=u_int)
+    l, q, e, G, Gr, h, cl, cr = stage_soc_to_extra_cstrs(W, w0, v, v0, M, N, x, u, Nc)
+    G = sp.csr_matrix(G)
+    socs = [(G[k * 3:(k + 1) * 3], h[k * 3:(k + 1) * 3]) for k in range(len(q))]
+    ncu = Nc * u + M * (N - Nc) * u
+    X, U = oracle.lconic_solve_py(*args, Nc=Nc, reg_x=kw["reg_x"], reg_u=kw["reg_u"], u_l=kw["u_l"], u_u=kw["u_u"], socs=socs,
+                                  z0=np.tile(u_int, ncu // u))
+    assert np.abs(X - Xo).max() < 1e-9 and np.abs(U - Uo).max() < 1e-9
+
