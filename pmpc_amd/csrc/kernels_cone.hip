@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
 #pragma unroll
   for (int r = 0; r < Q1; r++) bad |= !(s[r] == s[r]);
 
-  int changed = 0, open = 0;
+  int changed = 0, open = 0, decided = -1;
   if (a.finish) {
     // ---- finish the round just swept -----------------------------------------------------------------------------------------
     const int case_old = (int)rec[0];
@@ -100,12 +100,23 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
       for (int r = 0; r < Q1; r++) zn[r] = 0.0;
     }
     double wh_n[Q], w0, nb;
-    const int case_new = classify(s, zn, wh_n, w0, nb);
+    int case_new = classify(s, zn, wh_n, w0, nb);
+    // hysteresis against flip-flopping of a (nearly) weakly active cone — the counterpart of the widening sign tolerance of the
+    // box multipliers: a case change counts only if the new classification holds with a margin above the round's tolerance
+    if (case_new != case_old) {
+      const double m = case_new == 0 ? w0 - nb : (case_new == 2 ? -w0 - nb : fmin(nb - w0, nb + w0));
+      double ns0 = 0.0;
+#pragma unroll
+      for (int r = 0; r < Q1; r++) ns0 = fmax(ns0, fabs(s[r]));
+      if (m <= 10.0 * (a.ctl ? a.ctl->tol_l : 1e-11 * a.dual_scale) + 1e-13 * fmax(1.0, ns0)) case_new = case_old;
+    }
+    decided = case_new;
     if (case_new == 0) {
 #pragma unroll
       for (int r = 0; r < Q1; r++) zn[r] = 0.0;
     }
     changed = case_new != case_old;
+    if (changed) rec[11] += 1.0;  // case changes of this cone in the current attempt (diagnostic)
     // open: the cone's own Newton iteration has not converged (the rest of the system is linear given the cone terms)
     double ns = 0.0, nz = 0.0, ds = 0.0, dz = 0.0;
 #pragma unroll
@@ -130,7 +141,8 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
 
   // ---- prepare the next round: Newton terms at (u, z) ---------------------------------------------------------------------------
   double wh[Q], w0, nb;
-  const int cs = classify(s, z, wh, w0, nb);
+  int cs = classify(s, z, wh, w0, nb);
+  if (decided >= 0 && !(decided == 1 && !(nb > 0.0))) cs = decided;  // (the case the hysteresis kept)
   double tr = 0.0;
 #pragma unroll
   for (int k = 0; k < UD; k++) tr += a.R[idx * UD * UD + k * (UD + 1)];
@@ -145,7 +157,7 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
   double curv = 0.0, nu_hat = 0.0;
   if (cs == 1) {
     const double rs2 = 0.70710678118654752440;
-    const double theta = 0.5 * (1.0 + w0 / nb);
+    const double theta = fmin(fmax(0.5 * (1.0 + w0 / nb), 1e-12), 1.0);  // (clamped: the hysteresis may keep this case a hair outside its region)
     curv = (1.0 - theta) / theta;
     double am[UD], es = s[0], whs = 0.0;
     nu_hat = z[0];
@@ -207,6 +219,7 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
 #pragma unroll
   for (int p = 0; p < UD; p++) a.g[idx * UD + p] = g[p];
   rec[0] = (double)cs; rec[1] = rho; rec[2] = curv; rec[3] = nu_hat;
+  if (!a.finish) rec[11] = 0.0;
 #pragma unroll
   for (int r = 0; r < Q; r++) rec[4 + r] = wh[r];
 #pragma unroll
@@ -282,6 +295,7 @@ __global__ void __launch_bounds__(256) k_cone_step_multi(ConeArgs a) {
       return nb <= w0 ? 0 : (nb <= -w0 ? 2 : 1);
     };
     double *rec = a.rec + (idx * a.ncones + kc) * PMPC_CONE_REC;
+    int decided = -1;
     if (a.finish) {
       const int case_old = (int)rec[0];
       const double rho_o = rec[1], curv = rec[2], nu_hat = rec[3];
@@ -313,7 +327,15 @@ __global__ void __launch_bounds__(256) k_cone_step_multi(ConeArgs a) {
         for (int r = 0; r < Q1M; r++) zn[r] = 0.0;
       }
       double wh_n[QM], w0, nb;
-      const int case_new = classify(s, zn, wh_n, w0, nb);
+      int case_new = classify(s, zn, wh_n, w0, nb);
+      if (case_new != case_old) {  // hysteresis, see k_cone_step
+        const double m = case_new == 0 ? w0 - nb : (case_new == 2 ? -w0 - nb : fmin(nb - w0, nb + w0));
+        double ns0 = 0.0;
+#pragma unroll
+        for (int r = 0; r < Q1M; r++) ns0 = fmax(ns0, fabs(s[r]));
+        if (m <= 10.0 * (a.ctl ? a.ctl->tol_l : 1e-11 * a.dual_scale) + 1e-13 * fmax(1.0, ns0)) case_new = case_old;
+      }
+      decided = case_new;
       if (case_new == 0) {
 #pragma unroll
         for (int r = 0; r < Q1M; r++) zn[r] = 0.0;
@@ -344,10 +366,11 @@ __global__ void __launch_bounds__(256) k_cone_step_multi(ConeArgs a) {
     }
     // ---- Newton terms of this cone at (u, z) -------------------------------------------------------------------------------------
     double wh[QM], w0, nb;
-    const int cs = classify(s, z, wh, w0, nb);
+    int cs = classify(s, z, wh, w0, nb);
+    if (decided >= 0 && !(decided == 1 && !(nb > 0.0))) cs = decided;
     double curv = 0.0, nu_hat = 0.0;
     if (cs == 1) {
-      const double theta = 0.5 * (1.0 + w0 / nb);
+      const double theta = fmin(fmax(0.5 * (1.0 + w0 / nb), 1e-12), 1.0);
       curv = (1.0 - theta) / theta;
       double am[UD], es = s[0], whs = 0.0;
       nu_hat = z[0];
@@ -435,14 +458,15 @@ bool cone_as_supported(int u, int q) { return u >= 2 && u <= 4 && q >= 0 && q <=
 void launch_cone_step(const ConeArgs &a, hipStream_t s) {
   const long long rows = (long long)a.M * a.N;
   const dim3 grd((unsigned)((rows + 255) / 256)), blk(256);
-  if (a.ncones != 1 || a.per_stage || a.qs[0] < 1) {  // the general form
+  static const bool force_general = getenv("PMPC_CONE_GENERAL_KERNEL") && atoi(getenv("PMPC_CONE_GENERAL_KERNEL")) != 0;  // (tests: the general kernel on the single-cone cases)
+  if (force_general || a.ncones != 1 || a.per_stage || a.qs[0] < 1) {  // the general form
     if (a.u == 4) hipLaunchKernelGGL((k_cone_step_multi<4>), grd, blk, 0, s, a);
     else if (a.u == 3) hipLaunchKernelGGL((k_cone_step_multi<3>), grd, blk, 0, s, a);
     else if (a.u == 2) hipLaunchKernelGGL((k_cone_step_multi<2>), grd, blk, 0, s, a);
     else abort();
     return;
   }
-#define PMPC_CONE(UD, Q) if (a.u == UD && a.q == Q) { hipLaunchKernelGGL((k_cone_step<UD, Q>), grd, blk, 0, s, a); return; }
+#define PMPC_CONE(UD, Q) if (a.u == UD && a.qs[0] == Q) { hipLaunchKernelGGL((k_cone_step<UD, Q>), grd, blk, 0, s, a); return; }
   PMPC_CONE(4, 2) PMPC_CONE(4, 1) PMPC_CONE(4, 3) PMPC_CONE(3, 2) PMPC_CONE(3, 1) PMPC_CONE(3, 3) PMPC_CONE(2, 1) PMPC_CONE(2, 2) PMPC_CONE(2, 3)
 #undef PMPC_CONE
   abort();

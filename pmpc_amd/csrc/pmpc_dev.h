@@ -240,6 +240,7 @@ struct ConeArgs {
   double *H, *g;              // outputs: Newton terms (M,N,u,u) column-major blocks, (M,N,u)
   int *cnt, *settled, *open;  // per particle: as_cnt (3 ints: case changes are added to [1]), settled flag (cleared), open cones
   const int *done;
+  const AsCtl *ctl;           // round control block (tolerance of the round); null: 1e-11 dual_scale
   int finish;                 // 0: prepare only (first round of an attempt)
   double tol_step, tol_phi, dual_scale;
 };

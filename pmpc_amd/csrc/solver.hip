@@ -1178,7 +1178,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       }
       ca.R = p->R; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
       ca.z = w.cone_z.d(); ca.rec = w.cone_rec.d(); ca.H = w.Hadd.d(); ca.g = w.wu_soc.d();
-      ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done;
+      ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done; ca.ctl = ctl;
       ca.tol_step = 1e-6; ca.tol_phi = 1e-9; ca.dual_scale = dual_scale;
     }
     launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s, cone ? 8 : 2);  // control block of this attempt (+ cleared failure flag)
@@ -1195,7 +1195,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       HIP_CHECK(hipMemsetAsync(act, 0, nu * sizeof(int) + 8, s));
       HIP_CHECK(hipMemsetAsync(w.cone_z.p, 0, (size_t)M * N * cone_rows * D8, s));
       if (p->soc_u_interior) launch_soc_fill_u(p->U_out, p->soc_u_interior, (long long)nu, u, s);
-      else HIP_CHECK(hipMemcpyAsync(p->U_out, p->U_prev, nu * D8, hipMemcpyDeviceToDevice, s));  // (any start will do for the rounds)
+      else launch_init_base(p->U_out, p->U_prev, M, N, u, Nc, s);  // (any start will do for the rounds; the shared controls need ONE base value: 0)
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     } else if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
       ProfScope ps(c, 5);
@@ -1324,7 +1324,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         }
         int shown = 0;
         for (size_t k = 0; k < (size_t)M * N && shown < 6; k++) {
-          if (hr[k * PMPC_CONE_REC] == 0.0) continue;
+          if (M > 64 ? hr[k * PMPC_CONE_REC + 11] < 3.0 : hr[k * PMPC_CONE_REC] == 0.0) continue;  // (large problems: the cones that keep changing case)
+          printf("   [flips %g]", hr[k * PMPC_CONE_REC + 11]);
           shown++;
           printf("   cone (%zu,%zu) case %g rho %.3e curv %.3e nu %.6e | s_b", k / N, k % N, hr[k * PMPC_CONE_REC], hr[k * PMPC_CONE_REC + 1], hr[k * PMPC_CONE_REC + 2], hr[k * PMPC_CONE_REC + 3]);
           for (int r = 0; r < q1; r++) printf(" %.9e", hr[k * PMPC_CONE_REC + 4 + (q1 - 1) + r]);

@@ -166,7 +166,7 @@ class DeviceSolver:
         the boxes and the cone (all float64 CUDA tensors).  Config E's thrust cones; the structured case of the reference's
         pyjulia-only `extra_cstrs` (README.md:219-239).  General form: `cones=dict(sizes=[q_k, ...], A=..., c=...)` — several
         cones per stage, cone k with q_k + 1 rows of `s = A u + c` (q_k = 0: a linear row s >= 0; q_k >= 1: |s[1:]| <= s[0]),
-        `A (rows, udim)` / `c (rows,)` shared by all stages or `A (M, N, rows, udim)` / `c (M, N, rows)` per stage; `weights` allowed.
+        `A (rows, udim)` / `c (rows,)` shared by all stages or `A (M, N, rows, udim)` / `c (M, N, rows)` per stage; `weights` allowed."""
         prob, X_out, U_out = self._problem(**kw)
         info = _lib.PmpcInfo()
         self._before(wait_current_stream)
