@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="weak scaling: --M particles PER GPU instead of in total")
     ap.add_argument("--soc", action="store_true", help="quadrotor only: add the thrust cone ||(tau_x,tau_y)|| <= 0.3 T per stage "
                     "(config E's constraint set, fp64; pmpc_lsoc_solve_device)")
+    ap.add_argument("--cone", action="store_true", help="the reference's DEFAULT solver path (solver=\"ecos\" -> c_lcone_solve, pmpc/static_backend.py:242-253): "
+                    "the eps-anchored epigraph objective of PMPC.jl/src/main.jl:204-238 through pmpc_lcone_solve_device, Python-driven SCP loop")
+    ap.add_argument("--smooth-alpha", type=float, default=float("nan"), help="with --cone: log-barrier smoothing of the boxes (main.jl:246-262); NaN = hard boxes")
     ap.add_argument("--repeats", type=int, default=4, help="extra repeats of the timed window from a fresh SCP start (spread; outside `value`)")
     ap.add_argument("--thrust-min", type=float, default=0.0, help="quadrotor: lower box of the thrust as a fraction of the hover thrust "
                     "(default 0: the thrust cone's apex is feasible; > 0 keeps every cone away from its apex)")
@@ -218,6 +221,12 @@ def main():
                       soc_v=torch.tensor([0.3, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev), soc_v0=0.0,
                       soc_u_interior=torch.tensor([9.81, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev))
     solve_fn = solver.lsoc_solve if args.soc else solver.lqp_solve
+    if args.cone:
+        assert not args.soc
+        import functools
+
+        solve_fn = functools.partial(solver.lcone_solve, smooth_alpha=args.smooth_alpha)
+        args.python_loop = True  # (pmpc_scp_loop_device drives the QP / stage-cone sub-problems only)
     solve_events = []  # (start, end) HIP events on the solver's stream around the convex sub-problem (repeat windows only)
 
     def step(Xp, Up, Xo, Uo, first, time_solve=False):
@@ -365,8 +374,10 @@ def main():
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                     "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
-                                    if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 else
+                                    if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 and not args.cone and not args.soc else
                                     f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u" + (" + thrust cone per stage (config E constraints, fp64)" if args.soc else "")
+                                    + ((" through the reference's default cone path (c_lcone_solve semantics: eps-anchored epigraph objective"
+                                        + (f", log-barrier smoothing alpha = {args.smooth_alpha:g})" if args.smooth_alpha == args.smooth_alpha else ", hard boxes)")) if args.cone else "")
                                     + (f", thrust >= {args.thrust_min} x hover" if args.thrust_min > 0.0 else ""))
                                    + f"; timed window = SCP iterations {w0}..{w1} from the cold start X_prev = x0, U_prev = U_ref "
                                      "(the active-set round count falls as the SCP loop converges, so the rate depends on the window)",
@@ -374,6 +385,7 @@ def main():
                        "scp_loop": "python (one call per linearise / solve / residual)" if args.python_loop else "library (pmpc_scp_loop_device)",
                        "ipm_iters_per_step": float(np.mean(ipm_its)), "riccati_factorisations_per_step": float(np.mean(solves)),
                        "active_set_rounds_per_step": float(np.mean(as_rounds)),
+                       "weighted_qps_per_step": float(np.mean([h[1].get("outer_solves", 0) for h in timed])),
                        "fast_path": bool(timed[-1][1]["fast_path"]), "final_scp_residual": float(timed[-1][0][0].item()),
                        "aff_solve_only_cold_per_s": aff_only,
                        "ipm_warm_start": os.environ.get("PMPC_WARM_START", "1") != "0"},

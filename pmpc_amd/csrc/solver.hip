@@ -1853,6 +1853,9 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
     for (size_t i = 0; i < Ml; i++) pw[i] = user[off + i] * rankw[off + i];
     HIP_CHECK(hipMemcpyAsync(w.pw.p, pw.data(), Ml * D8, hipMemcpyHostToDevice, s));
     const int st = pmpc_lqp_solve_device(c, &q, &inf, verbose > 1);
+    // the later weighted QPs of this call start from THIS solve's set and solution (kept in the workspace), not from the
+    // caller's X_prev / U_prev: the caller's promise covers the first one only
+    q.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;
     outer++;
     solves_total += inf.structured_solves;
     ipm_total += inf.ipm_iters;

@@ -126,7 +126,7 @@ def test_weights_and_warm_start_with_general_cones(oracle):
 
     M, N, x, u, Nc = 5, 8, 6, 3, 1
     rng = np.random.default_rng(77)
-    args, kw = rand_problem(rng, M, N, x, u, 0.6)
+    args, kw = rand_problem(rng, M, N, x, u, 2.0)
     tuples, ncu = make_tuples(rng, M, N, x, u, Nc, ["lin2", "soc"])
     wts = 0.3 + rng.random(M)
     cn = stage_cones_from_extra_cstrs(tuples, M, N, x, u, Nc)
