@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cone", action="store_true", help="the reference's DEFAULT solver path (solver=\"ecos\" -> c_lcone_solve, pmpc/static_backend.py:242-253): "
                     "the eps-anchored epigraph objective of PMPC.jl/src/main.jl:204-238 through pmpc_lcone_solve_device, Python-driven SCP loop")
     ap.add_argument("--smooth-alpha", type=float, default=float("nan"), help="with --cone: log-barrier smoothing of the boxes (main.jl:246-262); NaN = hard boxes")
+    ap.add_argument("--fp32", action="store_true", help="fp32-STORAGE mode (BASELINE config E's dtype; the reference is fp64-only): fx, fu, Q, R and the "
+                    "factor records in float32 — half the HBM bytes of the dominant arrays —, arithmetic fp64 (include/pmpc_abi.h PMPC_F32_MATRICES)")
     ap.add_argument("--repeats", type=int, default=4, help="extra repeats of the timed window from a fresh SCP start (spread; outside `value`)")
     ap.add_argument("--thrust-min", type=float, default=0.0, help="quadrotor: lower box of the thrust as a fraction of the hover thrust "
                     "(default 0: the thrust cone's apex is feasible; > 0 keeps every cone away from its apex)")
@@ -208,8 +210,11 @@ def main():
     Xa, Ua = X0.clone(), U0.clone()
     Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
     f = torch.empty((M_loc, N, x), dtype=torch.float64, device=dev)
-    fx = torch.empty((M_loc, N, x, x), dtype=torch.float64, device=dev)
-    fu = torch.empty((M_loc, N, u, x), dtype=torch.float64, device=dev)
+    mdt = torch.float32 if args.fp32 else torch.float64  # storage type of the matrix stacks
+    fx = torch.empty((M_loc, N, x, x), dtype=mdt, device=dev)
+    fu = torch.empty((M_loc, N, u, x), dtype=mdt, device=dev)
+    if args.fp32:
+        d["Q"], d["R"] = d["Q"].to(torch.float32).contiguous(), d["R"].to(torch.float32).contiguous()
     hist = []
 
     soc_kw = {}
@@ -340,6 +345,8 @@ def main():
         value = args.steps / elapsed
         ms_f, n_f = prof["bwd_factor"]
         unit_bytes = ELEMS_PER_UNIT * 8 if (x, u) == (12, 4) else (2 * x * x + x * u + u * u + 3 * x + 2 * u + 2 * u + x + u) * 8
+        if args.fp32:  # the matrix stacks (2 x^2 + x u + u^2 elements of the unit) are 4-byte entries
+            unit_bytes -= 4 * (2 * x * x + x * u + u * u)
         alg_bytes = unit_bytes * M_loc * N  # per launch: every (particle, stage) of this rank's shard
         avg_s = (ms_f / max(n_f, 1)) * 1e-3
         achieved = alg_bytes / avg_s / 1e9 if n_f else 0.0
@@ -371,7 +378,8 @@ def main():
         out = {
             "metric": "SCP iterations/sec (M particles x N horizon)", "value": value, "unit": "SCP iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
+            "dtype": "f32 storage (fx, fu, Q, R, factor records) / f64 arithmetic" if args.fp32 else "f64", "data": "synthetic",
             "config": {"workload": (f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                     "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
                                     if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 and not args.cone and not args.soc else

@@ -113,6 +113,14 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                                           the base point of the stored set under the boxes this solve uses): a broken promise
                                           costs time, not correctness. */
 
+#define PMPC_F32_MATRICES 512u /* fp32-STORAGE mode (BASELINE config E's "fp32"; the reference is fp64-only, c_interface.jl:6-25): fx, fu,
+                                 Q, R point to FLOAT arrays of the same layouts (cast to const double * in the struct).  The
+                                 active-set sweeps of an SCP loop's warm-started solves (control boxes and / or stage cones,
+                                 Nc <= 1) then stream half the bytes of the dominant arrays and keep their factor records in
+                                 fp32; every value is widened on load and ALL arithmetic stays fp64, so the solve is the exact
+                                 solve of the fp32-rounded data.  Every other path (cold start, fallbacks, other dims) widens the
+                                 four arrays into workspace copies first and runs the fp64 kernels. */
+
 typedef struct pmpc_problem {
   size_t xdim, udim, N, M; /* M = particles held by THIS rank */
   long long Nc;
@@ -162,7 +170,7 @@ typedef struct pmpc_info {
   int status;          /* 0 ok, 1 not converged (outputs NaN), 2 numerical failure (outputs NaN) */
   int ipm_iters;       /* 0 = the equality-only optimum was feasible */
   int structured_solves; /* Riccati factorisations performed */
-  int fast_path;       /* 1 = MFMA register-resident kernels were used */
+  int fast_path;       /* 1 = MFMA register-resident kernels were used; 2 = those kernels on fp32-stored matrices (PMPC_F32_MATRICES) */
   double mu;           /* final complementarity */
   double slack_res;    /* final slack residual (inf-norm) */
   double max_violation;/* bound violation of the equality-only optimum */
@@ -217,6 +225,10 @@ int pmpc_comm_world(pmpc_ctx *ctx);
  * 1 = synthetic quadrotor (params (4,M)).  X_prev/U_prev/x0 and outputs in ABI layout. */
 int pmpc_linearize_device(pmpc_ctx *ctx, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu);
+
+/* the same with fx / fu written as FLOAT arrays (PMPC_F32_MATRICES) */
+int pmpc_linearize_device_f32(pmpc_ctx *ctx, int model, size_t N, size_t M, const double *x0, const double *X_prev,
+                              const double *U_prev, const double *params, double *f, float *fx, float *fu);
 
 /* SCP residual of one iteration (pmpc/scp_mpc.py:397-403): *out (device, one double) = max over particles and stages of
  * ||X - X_prev||_2 and ||U - U_prev||_2 (inf if a trajectory holds a NaN); asynchronous on pmpc_stream(). */

@@ -18,13 +18,13 @@ _lib = None
 c_dp = ctypes.POINTER(ctypes.c_double)
 
 # flags of pmpc_problem.flags (include/pmpc_abi.h)
-HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, COLD_START, STATIC_CONS_BOUNDS, PREV_IS_LAST_SOLUTION = 1, 2, 4, 8, 16, 32, 64, 128, 256
+HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, COLD_START, STATIC_CONS_BOUNDS, PREV_IS_LAST_SOLUTION, F32_MATRICES = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_lqp_solve_host", "pmpc_lcone_solve_host", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
-    "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device",
+    "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device", "pmpc_linearize_device_f32",
 ]
 
 
@@ -94,6 +94,8 @@ def load():
     lib.pmpc_comm_world.restype = ctypes.c_int
     lib.pmpc_linearize_device.argtypes = [vp, ctypes.c_int, sz, sz] + [vp] * 7
     lib.pmpc_linearize_device.restype = ctypes.c_int
+    lib.pmpc_linearize_device_f32.argtypes = [vp, ctypes.c_int, sz, sz] + [vp] * 7
+    lib.pmpc_linearize_device_f32.restype = ctypes.c_int
     lib.pmpc_scp_residual_device.argtypes = [vp, sz, sz, sz, sz] + [vp] * 5
     lib.pmpc_scp_residual_device.restype = ctypes.c_int
     lib.pmpc_profile_enable.argtypes = [vp, ctypes.c_int]

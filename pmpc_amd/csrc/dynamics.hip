@@ -149,9 +149,10 @@ struct ResArgs {  // residual of the iteration just finished, riding in the laun
 #ifndef PMPC_LIN_THREADS
 #define PMPC_LIN_THREADS 256  // the model is evaluated by the first UNITS threads; all of them stream the records out
 #endif
-template <class Model>
+// JT: storage type of the Jacobian stacks (float = the fp32-storage mode of the active-set sweeps)
+template <class Model, class JT>
 __global__ void __launch_bounds__(PMPC_LIN_THREADS) k_linearize(int N, long long tot, const double *x0, const double *X_prev, const double *U_prev,
-                                                  const double *params, double *f, double *fx, double *fu, ResArgs res) {
+                                                  const double *params, double *f, JT *fx, JT *fu, ResArgs res) {
   constexpr int X = Model::X, U = Model::U, UNITS = Model::UNITS;
   {
     const int glin = (int)gridDim.x - res.nblk;  // the last res.nblk blocks compute the residual (independent work, one launch)
@@ -174,18 +175,25 @@ __global__ void __launch_bounds__(PMPC_LIN_THREADS) k_linearize(int N, long long
   __syncthreads();
   const int n = (int)((tot - first) < UNITS ? (tot - first) : UNITS);
   for (int e = t; e < n * X; e += PMPC_LIN_THREADS) f[first * X + e] = rec[(e / X) * LD + e % X];
-  for (int e = t; e < n * X * X; e += PMPC_LIN_THREADS) fx[first * (X * X) + e] = rec[(e / (X * X)) * LD + X + e % (X * X)];
-  for (int e = t; e < n * X * U; e += PMPC_LIN_THREADS) fu[first * (X * U) + e] = rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
+  for (int e = t; e < n * X * X; e += PMPC_LIN_THREADS) fx[first * (X * X) + e] = (JT)rec[(e / (X * X)) * LD + X + e % (X * X)];
+  for (int e = t; e < n * X * U; e += PMPC_LIN_THREADS) fu[first * (X * U) + e] = (JT)rec[(e / (X * U)) * LD + X + X * X + e % (X * U)];
 }
 
 template <class Model>
 void launch_model(int N, int M, const double *x0, const double *X_prev, const double *U_prev, const double *params, double *f,
-                  double *fx, double *fu, const ResArgs &res, hipStream_t s) {
+                  double *fx, double *fu, const ResArgs &res, hipStream_t s, int jac32) {
   const long long tot = (long long)M * N;
   constexpr int REC = Model::X + Model::X * Model::X + Model::X * Model::U, LD = REC | 1;
   const unsigned grid = (unsigned)((tot + Model::UNITS - 1) / Model::UNITS);
-  hipLaunchKernelGGL((k_linearize<Model>), dim3(grid + (unsigned)res.nblk), dim3(PMPC_LIN_THREADS), Model::UNITS * LD * sizeof(double), s, N, tot, x0,
-                     X_prev, U_prev, params, f, fx, fu, res);
+  if (jac32)
+    hipLaunchKernelGGL((k_linearize<Model, float>), dim3(grid + (unsigned)res.nblk), dim3(PMPC_LIN_THREADS), Model::UNITS * LD * sizeof(double), s, N, tot, x0,
+                       X_prev, U_prev, params, f, (float *)fx, (float *)fu, res);
+  else
+    hipLaunchKernelGGL((k_linearize<Model, double>), dim3(grid + (unsigned)res.nblk), dim3(PMPC_LIN_THREADS), Model::UNITS * LD * sizeof(double), s, N, tot, x0,
+                       X_prev, U_prev, params, f, fx, fu, res);
+}
+__global__ void __launch_bounds__(256) k_widen_f32(const float *src, double *dst, long long n) {
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += (long long)gridDim.x * 256) dst[k] = (double)src[k];
 }
 
 }  // namespace
@@ -199,24 +207,29 @@ static long long residual_blocks(long long rows) {
 }
 
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
-                      const double *params, double *f, double *fx, double *fu, hipStream_t s) {
+                      const double *params, double *f, double *fx, double *fu, hipStream_t s, int jac32) {
   ResArgs none;
   memset(&none, 0, sizeof(none));
-  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, none, s);
-  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, none, s);
+  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, none, s, jac32);
+  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, none, s, jac32);
+}
+void launch_widen_f32(const float *src, double *dst, long long n, hipStream_t s) {
+  long long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(k_widen_f32, dim3((unsigned)b), dim3(256), 0, s, src, dst, n);
 }
 
 // the same with the SCP residual of (Xr, Xrp, Ur, Urp) computed by extra blocks of the launch (the SCP loop's follow-up of an
 // iteration: residual of the iteration + linearisation of the next — independent work); *res_out must be 0 on entry
 void launch_linearize_with_residual(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                                     const double *params, double *f, double *fx, double *fu, const double *Xr, const double *Xrp,
-                                    const double *Ur, const double *Urp, int x, int u, double *res_out, hipStream_t s) {
+                                    const double *Ur, const double *Urp, int x, int u, double *res_out, hipStream_t s, int jac32) {
   ResArgs r;
   r.X = Xr; r.Xp = Xrp; r.U = Ur; r.Up = Urp; r.rows = (long long)M * N; r.x = x; r.u = u;
   r.nblk = (int)residual_blocks(r.rows);
   r.out_bits = (unsigned long long *)res_out;
-  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, r, s);
-  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, r, s);
+  if (model == 0) launch_model<Unicycle>(N, M, x0, X_prev, U_prev, params, f, fx, fu, r, s, jac32);
+  else launch_model<Quadrotor>(N, M, x0, X_prev, U_prev, params, f, fx, fu, r, s, jac32);
 }
 
 // SCP residual of pmpc/scp_mpc.py:397-403: max over (particle, stage) of the 2-norms of X - X_prev and U - U_prev, in one

@@ -103,6 +103,20 @@ __device__ __forceinline__ void gsto_i(const double *base, unsigned boff, int v)
   *(int __attribute__((address_space(1))) *)((__attribute__((address_space(1))) char *)(unsigned long long)base + boff) = v;
 }
 
+// matrix stacks (fx, fu, Q, R) and the factor record in a storage type MT (double, or float: the fp32-storage mode — half the
+// HBM bytes of the dominant arrays; every value is widened on load, the arithmetic stays fp64)
+template <class MT>
+__device__ __forceinline__ double gldm(const void *p) { return (double)*(const MT __attribute__((address_space(1))) *)(unsigned long long)p; }
+template <class MT>
+__device__ __forceinline__ double ldom(const void *base, unsigned boff) {  // uniform base + 32-bit byte offset
+  return (double)*(const MT __attribute__((address_space(1))) *)((const __attribute__((address_space(1))) char *)(unsigned long long)base + boff);
+}
+template <class MT>
+__device__ __forceinline__ void gstom(const void *base, unsigned boff, double v) {
+  *(MT __attribute__((address_space(1))) *)((__attribute__((address_space(1))) char *)(unsigned long long)base + boff) = (MT)v;
+}
+__device__ __forceinline__ const void *ubase_v(const void *arr, long long off) { return (const void *)ubase((const double *)arr, off); }
+
 // unconditional load from a per-lane VALID address, zeroed by a select (no exec-mask branch);
 // `rv` guards padding rows (only when xdim is not a multiple of 4, where p[r] could leave the block)
 template <bool PADX>

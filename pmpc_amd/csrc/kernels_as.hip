@@ -56,13 +56,15 @@ namespace {
 // CONE: stage cones ride along (kernels_cone.hip prepares their Newton terms per round): a full (u x u) block cone_H added to H_uu
 // — loaded like R — and a vector cone_g added to the control gradient — it comes in with the control word (lane XP + 3 of the
 // control quad), so the sweep pays ONE more load per stage.  Consensus stages: the owner's particle 0 alone adds them.
-template <int XD, int UD, int MODE, bool SKIP, bool DEFECT, bool CONE = false>
+// MT: storage type of the matrix stacks fx, fu, Q, R and of the factor record (float = the fp32-storage mode; arithmetic stays fp64).
+template <int XD, int UD, int MODE, bool SKIP, bool DEFECT, bool CONE = false, class MT = double>
 __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_WAVES : PMPC_AS_LEAN_WAVES)) k_bwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
   constexpr bool PADX = (XD != XP);
   constexpr long long D8 = sizeof(double);
   constexpr bool DEEP = MODE != 0, SCHOL = !DEEP;
+  constexpr long long MB = sizeof(MT);  // bytes per matrix entry
   if (a.done && *a.done) return;
   const int lane = threadIdx.x;
   const int N = a.N, Nc = a.Nc, i = blockIdx.x;
@@ -91,15 +93,15 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 
   // F = [fx | fu]: per-lane pointer at stage N-1 and per-lane byte stride (0 for lanes that read the zero buffer)
   const bool fF = L.cxv || L.cu;
-  const double *pF = L.cxv ? a.fx + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0
-                           : (L.cu ? a.fu + (pbase + N - 1) * (XD * UD) + XD * L.cb + L.row0 : Z);
-  const int sF = fF ? -(int)D8 * (L.cxv ? XD * XD : XD * UD) : 0;
+  const MT *pF = L.cxv ? (const MT *)a.fx + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0
+                       : (L.cu ? (const MT *)a.fu + (pbase + N - 1) * (XD * UD) + XD * L.cb + L.row0 : (const MT *)Z);
+  const int sF = fF ? -(int)MB * (L.cxv ? XD * XD : XD * UD) : 0;
   // everything else: UNIFORM stage base (scalar registers, advanced by the scalar unit) + a per-lane constant byte offset.
   // Lanes without an entry read entry 0 of the stage block (finite data) and are masked by a zero factor or a select.
-  const unsigned lQ = (unsigned)((L.cxv ? XD * L.oc + L.row0 : 0) * D8);
+  const unsigned lQ = (unsigned)((L.cxv ? XD * L.oc + L.row0 : 0) * MB);
   const double pwt_x = L.cxv ? pwt : 0.0;  // cost weight on the state columns, zero elsewhere (masks Q)
   const bool fR = L.cu && gu;
-  const unsigned lR = (unsigned)((fR ? g + UD * L.cb : 0) * D8);
+  const unsigned lR = (unsigned)((fR ? g + UD * L.cb : 0) * MB), lRd = (unsigned)((fR ? g + UD * L.cb : 0) * D8);
   const unsigned lxr = (unsigned)(L.row0 * D8), lxc = (unsigned)((L.cxv ? L.oc : 0) * D8);
   const unsigned lug = (unsigned)((gu ? g : 0) * D8);
   const double regx_c = L.cxv ? regx : 0.0;
@@ -113,16 +115,16 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
   const double *Xb_ = ubase(Xb, px), *Xr_ = ubase(a.X_ref, px), *Xp_ = ubase(a.X_prev, px), *f_ = ubase(a.f, px);
   const double *kff_ = ubase(a.kff, pu);
-  const double *Q_ = ubase(a.Q, (long long)(pbase * (XD * XD)) * D8), *R_ = ubase(a.R, (long long)(pbase * (UD * UD)) * D8);
-  const double *K_ = ubase(a.K, (long long)(pbase * 64) * D8);
+  const void *Q_ = ubase_v(a.Q, (long long)(pbase * (XD * XD)) * MB), *R_ = ubase_v(a.R, (long long)(pbase * (UD * UD)) * MB);
+  const void *K_ = ubase_v(a.K, (long long)(pbase * 64) * MB);
   auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
   auto uoff = [&](int jj) { return (long long)(jj * (int)(UD * D8)); };
   auto ld_Q = [&](int jj, double *dst) {  // Q_jj, rows g + 4r of column c (garbage on the control columns: masked by pwt_x)
-    const double *q = ubase(Q_, (long long)(jj * (int)(XD * XD * D8)));
+    const void *q = ubase_v(Q_, (long long)(jj * (int)(XD * XD * MB)));
 #pragma unroll
     for (int r = 0; r < KS; r++) {
       const bool rv = !PADX || (L.row0 + r < XD);
-      const double v = ldo(q, rv ? lQ + r * 8u : 0u);
+      const double v = ldom<MT>(q, rv ? lQ + r * (unsigned)MB : 0u);
       dst[r] = rv ? v : 0.0;
     }
   };
@@ -155,18 +157,18 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   }
   const double regu_s = (L.cu && g < 2) ? (g == 0 ? regu : -regu) : 0.0;  // reg_u (u - u_prev): the two terms summed over the k-groups
   auto ld_R = [&](int jj) -> double {
-    const double v = ldo(ubase(R_, (long long)(jj * (int)(UD * UD * D8))), lR);
+    const double v = ldom<MT>(ubase_v(R_, (long long)(jj * (int)(UD * UD * MB))), lR);
     return fR ? v : 0.0;
   };
   const double *CH_ = CONE ? ubase(a.cone_H, (long long)(pbase * (UD * UD)) * D8) : Z;
   auto ld_CH = [&](int jj) -> double {  // cone block entry [g][cb], laid out like R
-    const double v = ldo(ubase(CH_, (long long)(jj * (int)(UD * UD * D8))), lR);
+    const double v = ldo(ubase(CH_, (long long)(jj * (int)(UD * UD * D8))), lRd);
     return fR ? v : 0.0;
   };
   const bool frec = (L.cxv || L.cu) && gu;
-  const unsigned lrec = (unsigned)(lane * D8);
-  auto st_rec = [&](int jj, double v) {  // this lane's slot of the stage's factor record: one coalesced 512-byte store
-    gsto(ubase(K_, (long long)(jj * (int)(64 * D8))), lrec, v);
+  const unsigned lrec = (unsigned)(lane * MB);
+  auto st_rec = [&](int jj, double v) {  // this lane's slot of the stage's factor record: one coalesced store (512 bytes in fp64)
+    gstom<MT>(ubase_v(K_, (long long)(jj * (int)(64 * MB))), lrec, v);
   };
 
   // prefetch register set of one stage: what it needs the moment it starts (F, R, control word, f of the stage) and — DEEP —
@@ -176,9 +178,9 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   struct Pipe : std::conditional_t<CONE, PipeCone, PipeNone> { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
   int jF = N - 1;  // stage pF / pC point at
   auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves the pointers alone)
-    if (jj < jF) { pF = badd(pF, sF); pC += sC; jF = jj; }
+    if (jj < jF) { pF = (const MT *)((const char *)pF + sF); pC += sC; jF = jj; }
 #pragma unroll
-    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || pF == Z) ? gld(pF + r) : 0.0;
+    for (int r = 0; r < KS; r++) q.F[r] = (!PADX || L.row0 + r < XD || (const void *)pF == (const void *)Z) ? gldm<MT>(pF + r) : 0.0;
     q.R = ld_R(jj);
     q.ctl = gld(pC);
     if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lxc);
@@ -432,7 +434,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // other twelve stay zero.
 // CONE: also records each stage's own Newton step u_b + du BEFORE clamping (a.as_uraw: the cone multiplier updates of
 // kernels_cone.hip are valid for that step only) — a third lane of the per-control store, no further instruction.
-template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false>
+template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false, class MT = double>
 __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
@@ -449,15 +451,16 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   // lane supplies T[rho = c][kappa = g + 4r], r = 0 .. KS (kappa < XP: state column, original index KS g + r; kappa = XP + g:
   // control column g).  State rows rho < XP read fx / fu (original row pi(rho) = L.oc), gain rows rho = XP + b read row b of
   // the factor record (record[kernel column + 16 b]); every other lane reads the zero buffer through a zero stride.
-  const double *pA = Z, *pB = Z;
+  constexpr int MB = (int)sizeof(MT);  // bytes per entry of fx, fu and the factor record (float: the fp32-storage mode)
+  const char *pA = (const char *)Z, *pB = (const char *)Z;
   int sAr = 0, sAj = 0, sBj = 0;  // byte strides: between the steps r < KS, between stages (A), between stages (B: step KS)
   if (L.cxv) {
-    pA = a.fx + pbase * (XD * XD) + (size_t)XD * (KS * g) + L.oc;
-    sAr = XD * (int)D8; sAj = XD * XD * (int)D8;
-    if (gu) { pB = a.fu + pbase * (XD * UD) + (size_t)XD * g + L.oc; sBj = XD * UD * (int)D8; }
+    pA = (const char *)((const MT *)a.fx + pbase * (XD * XD) + (size_t)XD * (KS * g) + L.oc);
+    sAr = XD * MB; sAj = XD * XD * MB;
+    if (gu) { pB = (const char *)((const MT *)a.fu + pbase * (XD * UD) + (size_t)XD * g + L.oc); sBj = XD * UD * MB; }
   } else if (L.cu) {
-    pA = a.K + pbase * 64 + 16 * L.cb + g;
-    sAr = 4 * (int)D8; sAj = 64 * (int)D8;
+    pA = (const char *)((const MT *)a.K + pbase * 64 + 16 * L.cb + g);
+    sAr = 4 * MB; sAj = 64 * MB;
   }
   bool vA[KS];  // (padding: state column KS g + r beyond xdim -> zero; the record holds zeros there already)
 #pragma unroll
@@ -495,13 +498,13 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   struct Pipe { double T[KS + 1], grp, xb, f; };
   int jF = 0;  // stage the pointers point at
   auto fetch = [&](int jj, Pipe &q) {  // called in ascending stage order (a clamped repeat of the last stage leaves the pointers alone)
-    if (jj > jF) { pA = badd(pA, sAj); pB = badd(pB, sBj); pG += sG; jF = jj; }
+    if (jj > jF) { pA += sAj; pB += sBj; pG += sG; jF = jj; }
 #pragma unroll
     for (int r = 0; r < KS; r++) {
-      const double t = gld((const char *)pA + (vA[r] ? r * sAr : 0));
+      const double t = gldm<MT>(pA + (vA[r] ? r * sAr : 0));
       q.T[r] = vA[r] ? t : 0.0;
     }
-    q.T[KS] = gld(pB);
+    q.T[KS] = gldm<MT>(pB);
     q.grp = gld(pG);
     q.xb = ldo(ubase(Xb_, xoff(jj)), lx1);
     if (DEFECT) q.f = ldo(ubase(f_, xoff(jj)), lx1);
@@ -748,6 +751,9 @@ constexpr bool cone_dims() {
                      (XD == 6 && UD == 3) || (XD == 5 && UD == 3) || (XD == 3 && UD == 3) || (XD == 8 && UD == 2) || (XD == 4 && UD == 2) ||
                      (XD == 2 && UD == 2));
 }
+// (xdim, udim) pairs with fp32-storage instantiations (class MT = float) of the two sweeps
+template <int XD, int UD>
+constexpr bool f32_dims() { return (XD == 12 && UD == 4) || (XD == 6 && UD == 3) || (XD == 4 && UD == 2); }
 template <int XD, int UD>
 void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
   // waves per SIMD this launch brings (1024 SIMDs): <= 2 deep2, <= 3 deep, else lean (see k_bwd_as)
@@ -757,6 +763,21 @@ void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
   // the DEFECT instantiation of the deep variant needs 127 registers (4 waves per SIMD without help): never the lean one
   if (a.defect && mode == 0) mode = 1;
  const dim3 grd(a.M), blk(64);
+  if (a.mat32) {  // fp32-storage mode: the deep variants, with or without stage cones
+    if constexpr (f32_dims<XD, UD>()) {
+      if (mode == 0) mode = 1;
+#define PMPC_BWD32(MD, SK, DF, CN) hipLaunchKernelGGL((k_bwd_as<XD, UD, MD, SK, DF, CN, float>), grd, blk, 0, s, a)
+#define PMPC_BWD32_C(MD, SK, DF) do { if (a.cone_H) PMPC_BWD32(MD, SK, DF, true); else PMPC_BWD32(MD, SK, DF, false); } while (0)
+      if (a.defect) { if (mode == 2) PMPC_BWD32_C(2, false, true); else PMPC_BWD32_C(1, false, true); }
+      else if (a.as_settled_in) PMPC_BWD32_C(2, true, false);
+      else { if (mode == 2) PMPC_BWD32_C(2, false, false); else PMPC_BWD32_C(1, false, false); }
+#undef PMPC_BWD32_C
+#undef PMPC_BWD32
+      return;
+    } else {
+      abort();  // (solver.hip asks f32_as_dims_supported first)
+    }
+  }
   if (a.cone_H) {  // stage cones: the deep variants only (one more register per prefetch set)
     if constexpr (cone_dims<XD, UD>()) {
       if (mode == 0) mode = 1;
@@ -794,6 +815,20 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
   //  PMPC_AS_FWD_PF2_MAXM=<M> puts larger launches back on the one-stage variant)
   static const int m2 = getenv("PMPC_AS_FWD_PF2_MAXM") ? atoi(getenv("PMPC_AS_FWD_PF2_MAXM")) : (1 << 30);
   const dim3 grd(a.M), blk(64);
+  if (a.mat32) {
+    if constexpr (f32_dims<XD, UD>()) {
+      if (a.as_uraw) {
+        if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true, float>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true, float>), grd, blk, 0, s, a);
+      } else {
+        if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, float>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, float>), grd, blk, 0, s, a);
+      }
+      return;
+    } else {
+      abort();
+    }
+  }
   if (a.as_uraw) {
     if constexpr (cone_dims<XD, UD>()) {
       if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true>), grd, blk, 0, s, a);
@@ -814,6 +849,12 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
 
 }  // namespace
 
+bool f32_as_dims_supported(int x, int u) {
+#define X(xd, ud) if (x == xd && u == ud) return f32_dims<xd, ud>();
+  PMPC_FAST_DIMS(X)
+#undef X
+  return false;
+}
 bool cone_as_dims_supported(int x, int u) {
 #define X(xd, ud) if (x == xd && u == ud) return cone_dims<xd, ud>();
   PMPC_FAST_DIMS(X)

@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
   if (decided >= 0 && !(decided == 1 && !(nb > 0.0))) cs = decided;  // (the case the hysteresis kept)
   double tr = 0.0;
 #pragma unroll
-  for (int k = 0; k < UD; k++) tr += a.R[idx * UD * UD + k * (UD + 1)];
+  for (int k = 0; k < UD; k++) tr += a.r32 ? (double)((const float *)a.R)[idx * UD * UD + k * (UD + 1)] : a.R[idx * UD * UD + k * (UD + 1)];
   const double rho = a.rho_scale * (tr / UD + a.reg_u);
   double H[UD][UD], g[UD];
 #pragma unroll
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) k_cone_step_multi(ConeArgs a) {
   for (int k = 0; k < UD; k++) { u[k] = a.U[idx * UD + k]; ur[k] = a.finish ? a.Uraw[idx * UD + k] : 0.0; }
   double tr = 0.0;
 #pragma unroll
-  for (int k = 0; k < UD; k++) tr += a.R[idx * UD * UD + k * (UD + 1)];
+  for (int k = 0; k < UD; k++) tr += a.r32 ? (double)((const float *)a.R)[idx * UD * UD + k * (UD + 1)] : a.R[idx * UD * UD + k * (UD + 1)];
   const double rho = a.rho_scale * (tr / UD + a.reg_u);
   double H[UD][UD], g[UD];
 #pragma unroll

@@ -122,6 +122,7 @@ struct LQArgs {
   const double *cone_H, *cone_g;
   double *as_uraw;
   int *as_open;    // per particle: open stage cones (zeroed by the forward sweep, counted by the cone pass)
+  int mat32;       // fx, fu, Q, R (and the factor record a.K of the active-set sweeps) are FLOAT arrays (fp32-storage mode; kernels_as.hip only)
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
   int sym_cost;    // caller guarantees Q_j = Q_j', R_j = R_j' (else OSQP's triu semantics need the generic path)
@@ -234,7 +235,8 @@ struct ConeArgs {
   const double *A, *c;        // cone data, device: A = [v'; W] ((q+1) x u, row-major), c = (v0, w0) — general form: the rows of
                               // all cones stacked (rows x u), per (particle, stage) if per_stage
   int ncones, qs[4], rows, per_stage;  // general form: cones per stage, their sizes (0 = linear row), total rows; 1 cone, shared data, q >= 1: k_cone_step
-  const double *R;            // cost blocks (penalty scale rho = rho_scale * (trace(R)/u + reg_u))
+  const double *R;            // cost blocks (penalty scale rho = rho_scale * (trace(R)/u + reg_u)); float array if r32
+  int r32;
   double reg_u, rho_scale;
   double *z, *rec;            // multipliers (M,N,rows) and the per-cone record of the prepared round (M,N,ncones,PMPC_CONE_REC)
   double *H, *g;              // outputs: Newton terms (M,N,u,u) column-major blocks, (M,N,u)
@@ -312,10 +314,13 @@ struct SlewAug {
 void launch_slew_augment(const SlewAug &g, hipStream_t s);
 void launch_slew_split(const double *Z, const double *W, double *X, double *U, long long rows, int x, int u, int N, int Nc,
                        const double *cons_lo, const double *cons_hi, hipStream_t s);
+// (jac32: fx / fu are FLOAT arrays — the fp32-storage mode)
 void launch_linearize(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
-                      const double *params, double *f, double *fx, double *fu, hipStream_t s);
+                      const double *params, double *f, double *fx, double *fu, hipStream_t s, int jac32 = 0);
 void launch_linearize_with_residual(int model, int N, int M, const double *x0, const double *X_prev, const double *U_prev,
                                     const double *params, double *f, double *fx, double *fu, const double *Xr, const double *Xrp,
-                                    const double *Ur, const double *Urp, int x, int u, double *res_out, hipStream_t s);
+                                    const double *Ur, const double *Urp, int x, int u, double *res_out, hipStream_t s, int jac32 = 0);
+void launch_widen_f32(const float *src, double *dst, long long n, hipStream_t s);  // dst[k] = (double)src[k]
+bool f32_as_dims_supported(int x, int u);  // (xdim, udim) pairs with fp32-storage instantiations of the active-set sweeps
 void launch_scp_residual(const double *X, const double *Xp, const double *U, const double *Up, long long rows, int x, int u,
                          double *out, hipStream_t s, bool zero_out = true);

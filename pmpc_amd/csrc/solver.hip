@@ -150,6 +150,7 @@ struct Workspace {
   long long soc_key = -1;
   DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift (path following) / Newton terms of the cones (active-set rounds)
   DevBuf cone_A, cone_c, cone_z, cone_rec, cone_uraw, as_open;  // stage cones inside the active-set rounds (kernels_cone.hip)
+  DevBuf m64[4];  // fp32-storage mode: fx, fu, Q, R widened for the paths that run the fp64 kernels
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
@@ -446,7 +447,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
                    &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
-                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open};
+                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -563,6 +564,19 @@ int pmpc_scp_residual_device(pmpc_ctx *c, size_t xdim, size_t udim, size_t N, si
   return 0;
 }
 
+int pmpc_linearize_device_f32(pmpc_ctx *c, int model, size_t N, size_t M, const double *x0, const double *X_prev,
+                              const double *U_prev, const double *params, double *f, float *fx, float *fu) {
+  try {
+    HIP_CHECK(hipSetDevice(c->device));
+    ProfScope ps(c, 6);
+    launch_linearize(model, (int)N, (int)M, x0, X_prev, U_prev, params, f, (double *)fx, (double *)fu, c->stream, 1);
+    HIP_CHECK(hipGetLastError());
+  } catch (const PmpcHipError &) {
+    return 2;
+  }
+  return 0;
+}
+
 int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const double *x0, const double *X_prev,
                           const double *U_prev, const double *params, double *f, double *fx, double *fu) {
   try {
@@ -578,9 +592,27 @@ int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const doub
 
 // -------------------------------------------------------------------------------------------------
 static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc);
+constexpr int PMPC_NEEDS_F64 = -7;  // solve_impl_body on an fp32-storage problem: this solve needs a path that runs the fp64 kernels
 static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
   try {
-    const int st = solve_impl_body(c, p, info, verbose, soc);
+    int st = solve_impl_body(c, p, info, verbose, soc);
+    if (st == PMPC_NEEDS_F64) {
+      // fp32-storage mode outside the warm-started active-set rounds (first solve of a loop, fallbacks, other dims / consensus
+      // horizons): widen fx, fu, Q, R into workspace copies — exact — and run the ordinary solve on them
+      Workspace &w = c->ws;
+      const long long rows = (long long)p->M * (long long)p->N, x = (long long)p->xdim, u = (long long)p->udim;
+      const long long cnt[4] = {rows * x * x, rows * x * u, rows * x * x, rows * u * u};
+      const double *src[4] = {p->fx, p->fu, p->Q, p->R};
+      for (int k = 0; k < 4; k++) {
+        w.m64[k].ensure((size_t)cnt[k] * sizeof(double));
+        launch_widen_f32((const float *)src[k], w.m64[k].d(), cnt[k], c->stream);
+      }
+      pmpc_problem q = *p;
+      q.flags &= ~(unsigned)PMPC_F32_MATRICES;
+      q.fx = w.m64[0].d(); q.fu = w.m64[1].d(); q.Q = w.m64[2].d(); q.R = w.m64[3].d();
+      if (verbose) printf("pmpc_hip: fp32-storage problem: widened for the fp64 kernels\n");
+      st = solve_impl_body(c, &q, info, verbose, soc);
+    }
     HIP_CHECK(hipGetLastError());  // a kernel launch that was refused (bad configuration, lost device) is a failed solve
     return st;
   } catch (const PmpcHipError &) {
@@ -680,6 +712,8 @@ static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
 }
 
 static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
+  const bool f32 = (p->flags & PMPC_F32_MATRICES) != 0;
+  if (f32 && (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_HAS_XBOUNDS | PMPC_FORCE_GENERIC))) return PMPC_NEEDS_F64;
   if (p->xdim > 0 && p->udim > 0 && p->N > 0 && p->M > 0 && p->Nc <= (long long)p->N && slew_increment_form_applies(p, soc))
     return solve_slew_increment_form(c, p, info, verbose);
   HIP_CHECK(hipSetDevice(c->device));
@@ -757,6 +791,17 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   a.dX = w.dX.d(); a.dU = w.dU.d(); a.fail = (int *)w.fail.p;
   a.X = w.X.d(); a.U = w.U.d();
   const bool fast = !(p->flags & PMPC_FORCE_GENERIC) && lq_fast_supported(a);
+  if (f32) {
+    // fp32-storage mode: only the warm-started active-set rounds of an SCP loop (no rollout, no equality phase) read the float
+    // arrays; everything else asks the caller (solve_impl) for widened copies
+    static const bool f32_defect_on = !(getenv("PMPC_AS_DEFECT") && atoi(getenv("PMPC_AS_DEFECT")) == 0);
+    if (!(fast && f32_as_dims_supported(x, u) && Nc <= 1 && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && !(p->flags & PMPC_COLD_START) &&
+          f32_defect_on && !(p->barrier_mu > 0.0))) {
+      w.as_key = as_prev;  // (nothing ran: the warm-start memory stands for the widened solve)
+      return PMPC_NEEDS_F64;
+    }
+    a.mat32 = 1;
+  }
   if (w.zeros.bytes == 0) {
     w.zeros.ensure(64 * D8);
     HIP_CHECK(hipMemsetAsync(w.zeros.p, 0, 64 * D8, s));
@@ -766,7 +811,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     w.xm.ensure(nx * D8); w.xd.ensure(nx * D8); w.um.ensure(nu * D8); w.ud.ensure(nu * D8);
     a.xm = w.xm.d(); a.xd = w.xd.d(); a.um = w.um.d(); a.ud = w.ud.d();
   }
-  inf.fast_path = fast ? 1 : 0;
+  inf.fast_path = fast ? (f32 ? 2 : 1) : 0;  // (2: the active-set sweeps on fp32-stored matrices — set back to 1 by the widened re-solve)
   IpmScal *sc = (IpmScal *)w.sc.p;
 
   // ---- 1. equality-only optimum: one Newton step from a dynamics-consistent base point -----------
@@ -1176,7 +1221,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         ca.ncones = 1; ca.qs[0] = q; ca.per_stage = 0;
         ca.A = w.cone_A.d(); ca.c = w.cone_c.d();
       }
-      ca.R = p->R; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
+      ca.R = p->R; ca.r32 = a.mat32; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
       ca.z = w.cone_z.d(); ca.rec = w.cone_rec.d(); ca.H = w.Hadd.d(); ca.g = w.wu_soc.d();
       ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done; ca.ctl = ctl;
       ca.tol_step = 1e-6; ca.tol_phi = 1e-9; ca.dual_scale = dual_scale;
@@ -1190,6 +1235,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     // those stages forward anyway, carries d as one more column (k_cond_fast).  Found by the config-B full-consensus test,
     // which a single accepted round without the term got wrong by 8 %)
     const bool use_defect = mode == 0 && as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
+    if (a.mat32 && !use_defect) return 1;  // (fp32 storage: no rollout kernel reads the float arrays)
     if (mode == 3) {  // cold start of the cone rounds: every control at the caller's interior point, nothing held, no multipliers
       ProfScope ps(c, 5);
       HIP_CHECK(hipMemsetAsync(act, 0, nu * sizeof(int) + 8, s));
@@ -1477,6 +1523,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         if (r == 0) return finish(0);
         if (verbose) printf("pmpc_hip: warm cone rounds not settled (%d): cold start\n", r);
       }
+      if (f32) return PMPC_NEEDS_F64;
       if (cone_cold_rounds > 0) {
         if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
         r = active_set_fast(1.0, 3, cone_cold_rounds);
@@ -1485,6 +1532,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       }
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
     }
+    if (f32) return PMPC_NEEDS_F64;
     if (ncones > 0) {  // the general form has no path-following fallback
       if (verbose) printf("pmpc_hip: stage cones (general form): the rounds did not settle\n");
       return finish(1);
@@ -1502,6 +1550,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     if (verbose) printf("pmpc_hip: warm active-set iteration not settled (%d): interior-point path\n", r);
     if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
   }
+  if (f32) return PMPC_NEEDS_F64;
   // Warm start (see below): when the previous solve of this shape ended in the interior-point phase, go there directly —
   // the equality-only solve (one factorisation + forward sweep) would only tell us that the boxes are active again; it
   // is done later if the warm attempt is rejected or fails
@@ -1686,7 +1735,8 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
   // trajectory buffers A = (X_prev, U_prev), B = (X_out, U_out); linearisation buffers 0 = (f, fx, fu), 1 = (f2, fx2, fu2)
   double *XA = const_cast<double *>(p0->X_prev), *UA = const_cast<double *>(p0->U_prev), *XB = p0->X_out, *UB = p0->U_out;
   double *F[2][3] = {{const_cast<double *>(p0->f), const_cast<double *>(p0->fx), const_cast<double *>(p0->fu)}, {f2, fx2, fu2}};
-  const bool soc = p0->soc_u_interior != nullptr;
+  const bool soc = p0->soc_u_interior != nullptr || p0->cone_count > 0;
+  const int jac32 = (p0->flags & PMPC_F32_MATRICES) ? 1 : 0;  // (f / fx / fu scratch sets: fx, fu FLOAT arrays then)
   int done = 0, cur = 0;
   bool lin_ready = false;  // the linearisation of iteration `done` is already enqueued (valid speculation of the previous one)
   try {
@@ -1696,7 +1746,7 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
       double *Xp = (done & 1) ? XB : XA, *Up = (done & 1) ? UB : UA, *Xo = (done & 1) ? XA : XB, *Uo = (done & 1) ? UA : UB;
       if (!lin_ready) {
         ProfScope ps(c, 6);
-        launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xp, Up, params, F[cur][0], F[cur][1], F[cur][2], c->stream);
+        launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xp, Up, params, F[cur][0], F[cur][1], F[cur][2], c->stream, jac32);
       }
       p.f = F[cur][0]; p.fx = F[cur][1]; p.fu = F[cur][2];
       p.X_prev = Xp; p.U_prev = Up; p.X_out = Xo; p.U_out = Uo;
@@ -1709,7 +1759,7 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
         if (next && !res_dirty && !c->multi()) {  // both in ONE launch (independent work)
           ProfScope ps(c, 6);
           launch_linearize_with_residual(model, (int)p.N, (int)p.M, p.x0, Xo, Uo, params, F[cur ^ 1][0], F[cur ^ 1][1], F[cur ^ 1][2], Xo, Xp, Uo,
-                                         Up, (int)p.xdim, (int)p.udim, res + done, c->stream);
+                                         Up, (int)p.xdim, (int)p.udim, res + done, c->stream, jac32);
           res_dirty = true;
           return;
         }
@@ -1721,7 +1771,7 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
         if (c->multi()) allreduce(c, res + done, 1, ncclFloat64, ncclMax);
         if (next) {
           ProfScope ps(c, 6);
-          launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xo, Uo, params, F[cur ^ 1][0], F[cur ^ 1][1], F[cur ^ 1][2], c->stream);
+          launch_linearize(model, (int)p.N, (int)p.M, p.x0, Xo, Uo, params, F[cur ^ 1][0], F[cur ^ 1][1], F[cur ^ 1][2], c->stream, jac32);
         }
       };
       c->spec_fired = c->spec_ok = false;

@@ -16,10 +16,10 @@ from . import _lib
 MODEL_UNICYCLE, MODEL_QUADROTOR = 0, 1
 
 
-def _p(t: Optional[torch.Tensor]):
+def _p(t: Optional[torch.Tensor], dtype=torch.float64):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+    assert t.is_cuda and t.dtype == dtype and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -118,9 +118,14 @@ class DeviceSolver:
             flags |= _lib.PREV_IS_LAST_SOLUTION
         if symmetric_cost:  # Q_j, R_j exactly symmetric (enables the register-resident MFMA path)
             flags |= _lib.SYMMETRIC_COST
+        # fp32-STORAGE mode (include/pmpc_abi.h PMPC_F32_MATRICES): fx, fu, Q, R as float32 tensors — all four or none
+        md = torch.float32 if fx.dtype == torch.float32 else torch.float64
+        assert fx.dtype == fu.dtype == Q.dtype == R.dtype == md, "fx, fu, Q, R must share one dtype (float64, or float32 for the fp32-storage mode)"
+        if md == torch.float32:
+            flags |= _lib.F32_MATRICES
         prob = _lib.PmpcProblem(
             xdim=x, udim=u, N=N, M=M, Nc=int(Nc), flags=flags, reg_x=float(reg_x), reg_u=float(reg_u),
-            x0=_p(x0), f=_p(f), fx=_p(fx), fu=_p(fu), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q), R=_p(R),
+            x0=_p(x0), f=_p(f), fx=_p(fx, md), fu=_p(fu, md), X_prev=_p(X_prev), U_prev=_p(U_prev), Q=_p(Q, md), R=_p(R, md),
             X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
             slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu),
             soc_q=0 if soc_W is None else int(soc_W.shape[0]), soc_W=_p(soc_W), soc_w0=_p(soc_w0), soc_v=_p(soc_v), soc_v0=float(soc_v0),
@@ -193,8 +198,12 @@ class DeviceSolver:
         fx = torch.empty((M, N, x, x), dtype=torch.float64, device=dev) if fx is None else fx
         fu = torch.empty((M, N, u, x), dtype=torch.float64, device=dev) if fu is None else fu
         self._before(wait_current_stream)
-        self.lib.pmpc_linearize_device(self.h, int(model), N, M, _p(x0), _p(X_prev), _p(U_prev), _p(params), _p(f), _p(fx),
-                                       _p(fu))
+        if fx.dtype == torch.float32:  # fp32-storage mode: the Jacobian stacks are written as float32
+            self.lib.pmpc_linearize_device_f32(self.h, int(model), N, M, _p(x0), _p(X_prev), _p(U_prev), _p(params), _p(f), _p(fx, torch.float32),
+                                               _p(fu, torch.float32))
+        else:
+            self.lib.pmpc_linearize_device(self.h, int(model), N, M, _p(x0), _p(X_prev), _p(U_prev), _p(params), _p(f), _p(fx),
+                                           _p(fu))
         self._after(wait_current_stream)
         return f, fx, fu
 
@@ -221,7 +230,8 @@ class DeviceSolver:
         infos = (_lib.PmpcInfo * steps)()
         last = ctypes.c_int(0)
         self._before(wait_current_stream)
-        done = self.lib.pmpc_scp_loop_device(self.h, int(model), _p(params), ctypes.byref(prob), _p(f2), _p(fx2), _p(fu2), int(steps),
+        jd = kw["fx"].dtype
+        done = self.lib.pmpc_scp_loop_device(self.h, int(model), _p(params), ctypes.byref(prob), _p(f2), _p(fx2, jd), _p(fu2, jd), int(steps),
                                              int(bool(first_cold)), _p(res), infos, ctypes.byref(last))
         self._after(wait_current_stream)
         out = [{k: getattr(infos[i], k) for k, _ in _lib.PmpcInfo._fields_} for i in range(min(done + 1, steps))]

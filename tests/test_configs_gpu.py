@@ -143,6 +143,50 @@ def test_config_E_shape_N100_cones_match_cone_oracle(solver, oracle):
     assert ex < 1e-6 and eu < 1e-6, (ex, eu)  # (the cone oracle itself stops at mu = 1e-13: ~1e-8 on trajectories)
 
 
+@pytest.mark.parametrize("M", [8, 32])
+def test_config_E_as_stated_fp32_storage_matches_the_fp64_cone_oracle(solver, oracle, M):
+    """BASELINE configs[4] AS STATED: quadrotor, N = 100, control boxes + thrust cones, **fp32** — here: fx, fu, Q, R and the factor
+    records stored in float32 (PMPC_F32_MATRICES; half the HBM bytes of the dominant arrays), every value widened on load, all
+    arithmetic fp64.  The reference is fp64-only (PMPC.jl/src/c_interface.jl:6-25), so the comparator is the fp64 cone oracle on
+    the fp64 data.  STATED TOLERANCE: 1e-6 relative on X and U (north star's bar; measured ~1e-8: the rounding of the data to
+    fp32, relative 6e-8, times the problem's conditioning).  Three SCP iterations: the first is a cold start (widened copies, fp64
+    kernels), the second and third run the warm-started active-set rounds on the float arrays (pmpc_info.fast_path == 2)."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem
+
+    N = 100
+    prob = dyn.make_quadrotor_problem(M=M, N=N)
+    d = to_device_problem(prob)
+    dev = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device="cuda")
+    soc, W = _thrust_cone(dev)
+    Q32, R32 = d["Q"].to(torch.float32).contiguous(), d["R"].to(torch.float32).contiguous()
+    fx = torch.empty((M, N, 12, 12), dtype=torch.float32, device="cuda")
+    fu = torch.empty((M, N, 4, 12), dtype=torch.float32, device="cuda")
+    f = torch.empty((M, N, 12), dtype=torch.float64, device="cuda")
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    for it in range(3):
+        solver.linearize(MODEL_QUADROTOR, d["x0"], Xa, Ua, d["params"], f, fx, fu)
+        X, U, status = solver.lsoc_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, Q=Q32, R=R32, X_ref=d["X_ref"], U_ref=d["U_ref"],
+                                         reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d["lu"], uu=d["uu"], X_out=Xb, U_out=Ub,
+                                         symmetric_cost=True, static_cons_bounds=True, prev_is_last_solution=it > 0, **soc)
+        solver.sync()
+        assert status == 0
+        if it > 0:
+            assert solver.last_info["fast_path"] == 2 and solver.last_info["ipm_iters"] == 0 and solver.last_info["active_set_rounds"] > 0
+        if it == 2:  # this sub-problem in fp64 on the CPU: linearisation of the reference-style numpy dynamics at the same point
+            Xp, Up = Xa.cpu().numpy(), Ua.cpu().numpy()
+            fn, fxn, fun = prob["f_fx_fu_fn"](np.concatenate([prob["x0"][:, None, :], Xp[:, :-1]], 1), Up)
+            Xo, Uo = oracle.lsoc_solve_py(prob["x0"], fn, fxn, fun, Xp, Up, prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], reg_x=prob["reg_x"],
+                                          reg_u=prob["reg_u"], Nc=1, u_l=prob["u_l"], u_u=prob["u_u"], soc_W=W, soc_w0=np.zeros(2),
+                                          soc_v=np.array([0.3, 0, 0, 0]), soc_v0=0.0, u_interior=np.array([9.81, 0, 0, 0]))
+            ex, eu = _rel(Xb.cpu().numpy(), Xo), _rel(Ub.cpu().numpy(), Uo)
+            assert ex < 1e-6 and eu < 1e-6, (ex, eu)
+        Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+
+
 def test_config_E_size_M4096_N100_thrust_cones_properties(solver):
     """BASELINE configs[4]'s size (quadrotor M=4096, N=100, boxes + thrust cones; fp64 — the reference has no fp32): consensus,
     box and cone feasibility with the cone active on many stages, exact linearised dynamics, optimality by feasible perturbations."""
