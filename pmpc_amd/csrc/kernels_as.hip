@@ -434,15 +434,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // other twelve stay zero.
 // CONE: also records each stage's own Newton step u_b + du BEFORE clamping (a.as_uraw: the cone multiplier updates of
 // kernels_cone.hip are valid for that step only) — a third lane of the per-control store, no further instruction.
-// SENS (one consensus stage): the sweep also carries the SENSITIVITY of the particle's closed-loop trajectory to the shared control
-// step — UD more columns of the same tile products (the MFMA tile has 16 columns, the state uses 4 of them: free arithmetic) —
-// and stores it as one more 64-double record per stage, a.as_T: [d(x_j, du_j) / d delta_k].  A SETTLED particle of a later round
-// (no status change, factors unchanged) then skips the sequential sweep: its wave handles the consensus stage as usual and
-// updates the other stages elementwise, X += T_x delta, U += T_u delta, multipliers of the held controls by the same rule, with
-// the sweep's own box / sign tests — a violation un-settles the particle (counted as a change: the round is not accepted, the
-// next one sweeps it normally), so nothing about the exactness of an accepted set changes.
-template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false, class MT = double, bool SENS = false>
-__global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs a) {  // (SENS + DEFECT: 128 registers would spill)
+template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false, class MT = double>
+__global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
   constexpr bool PADX = (XD != LT::XP);
@@ -522,7 +515,6 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
   for (int r = 0; r < KS; r++) V[r] = 0.0;
   int nrel = 0, nadd = 0, nbad = 0;
   double vworst = 0.0;
-  double dcap = 0.0;  // SENS: the consensus step as applied (lane c = 0 of k-group g: control g of stage 0)
   // consensus step of k-group g when this wave solves the consensus system itself (a.cons_G block partials; Nc == 1): lane e
   // sums entry e of [H | g] in block order — the same operations in every wave, so every particle applies the same step —,
   // then a Cholesky solve on lane-uniform values (arithmetic of k_cons_small's single-thread solve)
@@ -631,7 +623,6 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
       vworst = fmax(vworst, cnt_here ? fmax(pv, dv) : 0.0);
     }
     const double du_q = dpp_d<0x00>(dug);  // the decision of lane 0, in the four lanes of the k-group whose columns are kept
-    if (SENS && !MAIN && j < Nc) dcap = dug;
     // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
     // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
     const double knew = actc ? -draw : 0.0;
@@ -649,22 +640,7 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
     if (store_u) gsto_i(ubase(act_, uoff(j) >> 1), lug >> 1, anew);
     // second pass: + B du.  The C layout of the result IS the B layout of the next stage's state: nothing moves.
     D[KS] = 0.0;
-    double bop = (c < 4 && gu) ? du_q : 0.0;
-    if (SENS) {  // sensitivity columns c = 4 .. 4 + UD - 1: unit steps of the shared controls on the consensus stage, the feedback law elsewhere
-      const bool sc = c >= 4 && c < 4 + UD && gu;
-      const double bs = (!MAIN && j < Nc) ? ((g == c - 4) ? 1.0 : 0.0) : -raw;
-      bop = sc ? bs : bop;
-    }
-    D = mfma(cur.T[KS], bop, D);
-    if (SENS) {  // the stage's sensitivity record: lane (4 + k, g) owns slots 4 g .. 4 g + 3 of column k (KS state rows, then control g)
-      if (c >= 4 && c < 4 + UD) {
-        double *t = a.as_T + ((pbase + j) * 64 + (size_t)(c - 4) * 16 + 4 * g);
-        typedef double v2dd __attribute__((ext_vector_type(2)));
-        v2dd lo2 = {D[0], KS > 1 ? D[KS > 1 ? 1 : 0] : 0.0}, hi2 = {KS > 2 ? D[KS > 2 ? 2 : 0] : 0.0, gu ? bop : 0.0};
-        *(v2dd __attribute__((address_space(1))) *)(unsigned long long)t = lo2;
-        *(v2dd __attribute__((address_space(1))) *)(unsigned long long)(t + 2) = hi2;
-      }
-    }
+    D = mfma(cur.T[KS], (c < 4 && gu) ? du_q : 0.0, D);
     if (DEFECT) {  // the defect r = f - x_prev of row KS g + r sits in lane c = r of the k-group: quad broadcasts
       const double dfo = own_x ? cur.f - cur.xb : 0.0;
       D[0] += dpp_d<0x00>(dfo);
@@ -678,65 +654,7 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
       gsto(ubase(Xo_, xoff(j)), lx1, cur.xb + mine);
     }
 #pragma unroll
-    for (int r = 0; r < KS; r++) V[r] = (c < (SENS ? 4 + UD : 4)) ? D[r] : 0.0;  // (the other columns of the tile carry nothing: kept at zero)
-  };
-  // SENS: a settled particle's stages behind the consensus stage, elementwise (see the kernel's header comment)
-  bool swept = true;
-  int nrel_e = 0, nadd_e = 0, nbad_e = 0;
-  auto settled_update = [&](int j0) {
-    double dl[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) dl[k] = k < UD ? readlane_d(dcap, 16 * k) : 0.0;
-    const double dmine = pick4(dl[0], dl[1], dl[2], dl[3], g);
-    const int s16 = lane & 15, gs = s16 >> 2, rs = s16 & 3;  // slot of this lane: k-group gs, register rs
-    const bool grp0 = lane < 16;
-    const bool is_x = grp0 && rs < KS && KS * gs + rs < XD, is_u = grp0 && rs == 3 && gs < UD;
-    const size_t xo = (size_t)(KS * gs + rs), uo = (size_t)gs;
-    // four stages per trip, every load of the trip issued before anything is stored (the stages are independent: what bounds this
-    // path is memory latency, not arithmetic)
-    constexpr int SB = 4;
-    for (int j4 = j0; j4 < N; j4 += SB) {
-      double t[SB], xv[SB], ub[SB], kf[SB], lo[SB], hi[SB];
-      int act[SB];
-#pragma unroll
-      for (int q = 0; q < SB; q++) {
-        const int jj = j4 + q < N ? j4 + q : N - 1;  // (clamped: the tail re-reads the last stage, its results are dropped)
-        t[q] = gld(a.as_T + (pbase + jj) * 64 + lane);
-        xv[q] = is_x ? gld(Xb + (pbase + jj) * XD + xo) : 0.0;
-        const size_t e = (pbase + jj) * UD + uo;
-        ub[q] = is_u ? gld(Ub + e) : 0.0;
-        kf[q] = is_u ? gld(a.kff + e) : 0.0;
-        lo[q] = is_u ? gld(a.as_lo + e) : 0.0;
-        hi[q] = is_u ? gld(a.as_hi + e) : 0.0;
-        act[q] = is_u ? a.as_act[e] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < SB; q++) {
-        const int jj = j4 + q;
-        const bool live = jj < N;
-        const double dv = grp_allsum(t[q] * dmine);  // change of slot s16 (every k-group gets the sum over the shared controls)
-        if (is_x && live) gst(a.Xo + (pbase + jj) * XD + xo, xv[q] + dv);
-        if (is_u && live) {
-          const size_t e = (pbase + jj) * UD + uo;
-          if (act[q] == 0) {
-            const double zt = ub[q] + dv;
-            const bool vlo = zt < lo[q] - a.as_tol_p * fmax(1.0, fabs(lo[q])), vhi = !vlo && zt > hi[q] + a.as_tol_p * fmax(1.0, fabs(hi[q]));
-            nadd_e += (vlo || vhi) ? 1 : 0;  // (left outside its box and free: the next round sweeps this particle and clamps it)
-            nbad_e |= !(zt == zt) ? 1 : 0;
-            gst(a.Uo + e, zt);
-          } else {
-            const double kn = kf[q] - dv;                    // kff holds -du_b of the held control: its multiplier is -/+ big du_b
-            const double lam = act[q] == 1 ? a.as_big * kn : -a.as_big * kn;
-            const bool release = lam < -tol_l;
-            nrel_e += release ? 1 : 0;
-            nbad_e |= !(kn == kn) ? 1 : 0;
-            gst(a.kff + e, kn);
-            if (release) a.as_act[e] = 0;
-            if (a.Uo != Ub) gst(a.Uo + e, ub[q]);
-          }
-        }
-      }
-    }
+    for (int r = 0; r < KS; r++) V[r] = (c < 4) ? D[r] : 0.0;  // (the other columns of the tile carry nothing: kept at zero)
   };
 
   const int jmin = Nc > 1 ? Nc : 1;  // MAIN covers the free stages jmin .. N-1
@@ -756,7 +674,6 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
       P0 = P1;
       P1 = P2;
     }
-    if (SENS && a.as_settled_in && a.as_settled_in[i]) { settled_update(j); swept = false; j = N; }
     for (; j + 2 < N; j += 3) {
       fetch(clampN(j + 2), P2);
       stage(std::true_type{}, j, P0);
@@ -775,7 +692,6 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
       stage(std::false_type{}, j, A);
       A = B;
     }
-    if (SENS && a.as_settled_in && a.as_settled_in[i]) { settled_update(j); swept = false; j = N; }
     for (; j < N; j++) {
       fetch(clampN(j + 1), B);
       stage(std::true_type{}, j, A);
@@ -783,10 +699,7 @@ __global__ void __launch_bounds__(64, (SENS && DEFECT) ? 3 : 4) k_fwd_as(LQArgs 
     }
   }
   // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
-  double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
-  if (SENS && !swept) {  // the elementwise path counted in the control lanes of k-group 0: row sums reach lane 0
-    r += row_allsum((double)nrel_e); d += row_allsum((double)nadd_e); b += row_allsum((double)nbad_e);
-  }
+  const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
   if (a.as_viol) {  // max over the k-groups (the counting lanes are c == 0)
     double p01, p23, q0, q1;
     swap32_d(vworst, p01, p23);
@@ -902,15 +815,11 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
   //  PMPC_AS_FWD_PF2_MAXM=<M> puts larger launches back on the one-stage variant)
   static const int m2 = getenv("PMPC_AS_FWD_PF2_MAXM") ? atoi(getenv("PMPC_AS_FWD_PF2_MAXM")) : (1 << 30);
   const dim3 grd(a.M), blk(64);
-  const bool sens = a.as_T != nullptr && a.Nc == 1 && !a.as_uraw;  // (solver.hip allocates the records for one consensus stage only)
   if (a.mat32) {
     if constexpr (f32_dims<XD, UD>()) {
       if (a.as_uraw) {
         if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true, float>), grd, blk, 0, s, a);
         else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true, float>), grd, blk, 0, s, a);
-      } else if (sens) {
-        if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, float, true>), grd, blk, 0, s, a);
-        else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, float, true>), grd, blk, 0, s, a);
       } else {
         if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, float>), grd, blk, 0, s, a);
         else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, float>), grd, blk, 0, s, a);
@@ -928,11 +837,6 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
     } else {
       abort();
     }
-  }
-  if (sens) {
-    if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, double, true>), grd, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, double, true>), grd, blk, 0, s, a);
-    return;
   }
   if (a.M <= m2) {
     if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true>), grd, blk, 0, s, a);

@@ -122,7 +122,6 @@ struct LQArgs {
   const double *cone_H, *cone_g;
   double *as_uraw;
   int *as_open;    // per particle: open stage cones (zeroed by the forward sweep, counted by the cone pass)
-  double *as_T;    // forward sweep, one consensus stage: sensitivity records [M][N][64] (null: off) — see k_fwd_as<SENS>
   int mat32;       // fx, fu, Q, R (and the factor record a.K of the active-set sweeps) are FLOAT arrays (fp32-storage mode; kernels_as.hip only)
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present

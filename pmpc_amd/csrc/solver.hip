@@ -150,7 +150,6 @@ struct Workspace {
   long long soc_key = -1;
   DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift (path following) / Newton terms of the cones (active-set rounds)
   DevBuf cone_A, cone_c, cone_z, cone_rec, cone_uraw, as_open;  // stage cones inside the active-set rounds (kernels_cone.hip)
-  DevBuf as_T;    // forward sweep's sensitivity records (one consensus stage: settled particles are updated elementwise)
   DevBuf m64[4];  // fp32-storage mode: fx, fu, Q, R widened for the paths that run the fp64 kernels
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
@@ -448,7 +447,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
                    &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
-                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3], &w.as_T};
+                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -1199,13 +1198,6 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     b.as_settled_out = (int *)w.as_settled.p; b.as_delta = w.as_delta.d(); b.as_ctl = ctl; b.done = &ctl->done;
     w.as_viol.ensure((size_t)M * D8);
     b.as_viol = w.as_viol.d();
-    // one consensus stage: the forward sweep also records each stage's sensitivity to the shared control step, and settled
-    // particles of the later rounds are updated elementwise from it instead of being swept again (k_fwd_as<SENS>)
-    static const bool as_sens_on = !(getenv("PMPC_AS_SENS") && atoi(getenv("PMPC_AS_SENS")) == 0);
-    if (as_sens_on && as_skip_on && Nc == 1 && !(cone_as && (mode == 0 || mode == 3))) {
-      w.as_T.ensure((size_t)M * N * 64 * D8);
-      b.as_T = w.as_T.d();
-    }
     b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
     w.as_key = -1;
     // stage cones (mode 0 warm / 3 cold): Newton terms per round from kernels_cone.hip, see the header there
