@@ -57,8 +57,11 @@ namespace {
 // — loaded like R — and a vector cone_g added to the control gradient — it comes in with the control word (lane XP + 3 of the
 // control quad), so the sweep pays ONE more load per stage.  Consensus stages: the owner's particle 0 alone adds them.
 // MT: storage type of the matrix stacks fx, fu, Q, R and of the factor record (float = the fp32-storage mode; arithmetic stays fp64).
-template <int XD, int UD, int MODE, bool SKIP, bool DEFECT, bool CONE = false, class MT = double>
+// EX = 2, XBOX: state boxes ride along (kernels_xbox.hip prepares their terms per round): a penalty xb_D on the diagonal of the state
+// cost of the stage below and xb_g in its gradient — two more loads per stage, on the state columns, next to the base state's.
+template <int XD, int UD, int MODE, bool SKIP, bool DEFECT, int EX = 0, class MT = double>
 __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_WAVES : PMPC_AS_LEAN_WAVES)) k_bwd_as(LQArgs a) {
+  constexpr bool CONE = EX == 1, XBOX = EX == 2;
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS, XP = LT::XP;
   constexpr bool PADX = (XD != XP);
@@ -174,8 +177,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   // prefetch register set of one stage: what it needs the moment it starts (F, R, control word, f of the stage) and — DEEP —
   // its mid / late data (Q and the base point of the stage BELOW it) as well
   struct PipeCone { double ch; };
+  struct PipeXbox { double xd, xg; };
   struct PipeNone {};
-  struct Pipe : std::conditional_t<CONE, PipeCone, PipeNone> { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
+  struct Pipe : std::conditional_t<CONE, PipeCone, std::conditional_t<XBOX, PipeXbox, PipeNone>> { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
+  const double *XD_ = XBOX ? ubase(a.xb_D, px) : Z, *XG_ = XBOX ? ubase(a.xb_g, px) : Z;
   int jF = N - 1;  // stage pF / pC point at
   auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves the pointers alone)
     if (jj < jF) { pF = (const MT *)((const char *)pF + sF); pC += sC; jF = jj; }
@@ -193,6 +198,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     q.xb = ldo(ubase(Xb_, xoff(jbelow)), lxc);
     q.xr = ldo(ubase(Xr_, xoff(jbelow)), lxc);
     if (!DEFECT) q.xp = ldo(ubase(Xp_, xoff(jbelow)), lxc);
+    if constexpr (XBOX) {
+      q.xd = ldo(ubase(XD_, xoff(jbelow)), lxc);
+      q.xg = ldo(ubase(XG_, xoff(jbelow)), lxc);
+    }
   };
 
   double S[KS], s_row[KS], s_col;
@@ -208,6 +217,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
       S[r] = fma(pwt_x, Q0[r], dmask[r] ? regx : 0.0);
     }
     part = grp_allsum(part);
+    if constexpr (XBOX) {
+      const double d0 = ldo(ubase(XD_, xoff(N - 1)), lxc);
+      part += ldo(ubase(XG_, xoff(N - 1)), lxc);
+#pragma unroll
+      for (int r = 0; r < KS; r++) S[r] += dmask[r] ? d0 : 0.0;
+    }
     s_col = L.cxv ? part + ld_gx(N - 1) : 0.0;
     col_to_row<KS>(s_col, g, s_row);
   }
@@ -239,6 +254,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     const double df_c = (DEFECT && L.cxv) ? cur.f - xb_carry : 0.0;     // dynamics defect of the base point on the state columns
     if (DEFECT) xb_carry = cur.xb;
     gx_c = DEFECT ? 0.0 : regx_c * (cur.xb - cur.xp);
+    if constexpr (XBOX) gx_c += cur.xg;
     col_to_row<KS>(pwt_x * (cur.xb - cur.xr), g, xm_row);
 #pragma unroll
     for (int r = 0; r < KS; r++) Qc[r] = cur.Q[r];
@@ -268,7 +284,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     if (below) {
 #pragma unroll
       for (int r = 0; r < KS; r++) {
-        H[r] = fma(pwt_x, Qc[r], dmask[r] ? regx : 0.0);
+        if constexpr (XBOX) H[r] = fma(pwt_x, Qc[r], dmask[r] ? regx + cur.xd : 0.0);
+        else H[r] = fma(pwt_x, Qc[r], dmask[r] ? regx : 0.0);
         p2q = fma(Qc[r], xm_row[r], p2q);
       }
     }
@@ -754,6 +771,9 @@ constexpr bool cone_dims() {
 // (xdim, udim) pairs with fp32-storage instantiations (class MT = float) of the two sweeps
 template <int XD, int UD>
 constexpr bool f32_dims() { return (XD == 12 && UD == 4) || (XD == 6 && UD == 3) || (XD == 4 && UD == 2); }
+// XBOX instantiations of the factor sweep: every compiled (xdim, udim) pair (five more kernels each)
+template <int XD, int UD>
+constexpr bool xbox_dims() { return true; }
 template <int XD, int UD>
 void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
   // waves per SIMD this launch brings (1024 SIMDs): <= 2 deep2, <= 3 deep, else lean (see k_bwd_as)
@@ -793,6 +813,23 @@ void launch_bwd_as_t(const LQArgs &a, hipStream_t s) {
       return;
     } else {
       abort();  // (solver.hip asks cone_as_dims_supported first)
+    }
+  }
+  if (a.xb_D) {  // state boxes: the deep variants only
+    if constexpr (xbox_dims<XD, UD>()) {
+      if (mode == 0) mode = 1;
+      if (a.defect) {
+        if (mode == 2) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, false, true, 2>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_as<XD, UD, 1, false, true, 2>), grd, blk, 0, s, a);
+      } else if (a.as_settled_in) {
+        hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, true, false, 2>), grd, blk, 0, s, a);
+      } else {
+        if (mode == 2) hipLaunchKernelGGL((k_bwd_as<XD, UD, 2, false, false, 2>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_as<XD, UD, 1, false, false, 2>), grd, blk, 0, s, a);
+      }
+      return;
+    } else {
+      abort();  // (solver.hip asks xbox_as_dims_supported first)
     }
   }
 #define PMPC_BWD_AS(SK, DF)                                                                      \
@@ -851,6 +888,12 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
 
 bool f32_as_dims_supported(int x, int u) {
 #define X(xd, ud) if (x == xd && u == ud) return f32_dims<xd, ud>();
+  PMPC_FAST_DIMS(X)
+#undef X
+  return false;
+}
+bool xbox_as_dims_supported(int x, int u) {
+#define X(xd, ud) if (x == xd && u == ud) return xbox_dims<xd, ud>();
   PMPC_FAST_DIMS(X)
 #undef X
   return false;

@@ -122,6 +122,9 @@ struct LQArgs {
   const double *cone_H, *cone_g;
   double *as_uraw;
   int *as_open;    // per particle: open stage cones (zeroed by the forward sweep, counted by the cone pass)
+  // state boxes on the active-set sweeps (kernels_xbox.hip prepares them per round): a penalty on the diagonal of the stage's state
+  // cost and a gradient term, per state entry (M,N,x).  Null = none (the XBOX instantiations are not launched).
+  const double *xb_D, *xb_g;
   int mat32;       // fx, fu, Q, R (and the factor record a.K of the active-set sweeps) are FLOAT arrays (fp32-storage mode; kernels_as.hip only)
   int owner;       // this rank holds global particle 0 (whose bounds the consensus controls use)
   int any_slew;    // slew_reg or slew_reg0 present
@@ -251,6 +254,30 @@ bool cone_as_supported(int u, int q);
 bool cone_as_dims_supported(int x, int u);  // kernels_as.hip: (xdim, udim) pairs with CONE instantiations of the sweeps
 void launch_cone_step(const ConeArgs &a, hipStream_t s);
 void launch_cone_drop_redundant_lo(double *lo, const double *A, const double *c, int q, long long rows, int u, hipStream_t s);
+
+// ---- kernels_xbox.hip: state boxes inside the active-set rounds -----------------------------------------------------
+// One pass per round behind the forward sweep (multipliers, statuses and counters of the round that just ran, then the next round's
+// terms xb_D, xb_g).  A state cannot be put ON its bound the way a control can (the dynamics decide it), so a binding state box is
+// a row of the semismooth Newton iteration on the natural map  s - max(0, s - z) = 0,  s = x - lo  (or hi - x):  inactive while
+// s - z >= 0; else held by penalty + multiplier estimate, rho/2 (s_b + dx)^2 - z dx, z+ = z - rho s_new.
+struct XboxArgs {
+  int M, N, x;
+  const double *X;           // new base states (finish) / first base point
+  const double *lo, *hi;     // (M,N,x)
+  const double *Q, *pw;      // cost blocks and particle weights (or null): penalty rho_i = rho_scale pw_i (max_j,r |Q_ijrr| + reg_x)
+  double reg_x, rho_scale;
+  double *z;                 // multipliers (M,N,x), >= 0, of the side named by st
+  int *st;                   // 0 free, 1 lower side held, 2 upper side held
+  double *D, *g;             // outputs (M,N,x)
+  int *cnt, *settled, *open; // per particle: as_cnt (status changes are added to [1]), settled flag (cleared), rows not yet on their bound
+  const int *done;
+  const AsCtl *ctl;
+  int finish;                // 0: prepare only (first round of an attempt)
+  double tol, dual_scale;
+};
+bool xbox_as_dims_supported(int x, int u);  // kernels_as.hip: (xdim, udim) pairs with XBOX instantiations of the factor sweep
+void launch_xbox_step(const XboxArgs &a, hipStream_t s);
+void launch_xbox_from_ipm(const struct Slab &sx, int *st, double *z, hipStream_t s);  // statuses / multipliers from an interior-point iterate
 
 // ---- kernels_ipm.hip ----------------------------------------------------------------------------
 void launch_block_transpose(const double *in, double *out, int rows, int cols, long long n, hipStream_t s);

@@ -150,6 +150,7 @@ struct Workspace {
   long long soc_key = -1;
   DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift (path following) / Newton terms of the cones (active-set rounds)
   DevBuf cone_A, cone_c, cone_z, cone_rec, cone_uraw, as_open;  // stage cones inside the active-set rounds (kernels_cone.hip)
+  DevBuf xb_z, xb_st, xb_D, xb_g;  // state boxes inside the active-set rounds (kernels_xbox.hip)
   DevBuf m64[4];  // fp32-storage mode: fx, fu, Q, R widened for the paths that run the fp64 kernels
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
@@ -447,7 +448,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
                    &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
-                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
+                   &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.xb_z, &w.xb_st, &w.xb_D, &w.xb_g, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
   for (DevBuf *b : all) b->release();
   for (SlabBufs *sb : {&w.sx, &w.su})
     for (DevBuf *b : {&sb->lo, &sb->hi, &sb->tl, &sb->tu, &sb->ll, &sb->lu, &sb->cl, &sb->cu, &sb->D, &sb->w}) b->release();
@@ -633,12 +634,18 @@ static bool slew_increment_form_applies(const pmpc_problem *p, bool soc) {
   if (soc || !(p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0)) || (p->flags & PMPC_FORCE_GENERIC) || !(p->flags & PMPC_SYMMETRIC_COST))
     return false;
   if (p->N < 2) return false;  // N = 1: the reference's diagonal rule is not the plain penalty (lqp_utils.jl:31-39)
-  // With boxes the control boxes become STATE boxes of the restated problem: interior-point iteration only (no active-set
-  // rounds, no warm start from the previous set).  Measured (tools/debug/slew_paths.py): 1.8x - 2.6x
-  // slower cold and ~10x slower warm than the generic kernels' active-set rounds, and 1e-7 instead of 1e-10 from the oracle —
-  // so boxed slew problems stay on the generic kernels.  PMPC_SLEW_INCREMENT_BOXES=1 forces the restated form (measurements).
-  static const bool with_boxes = [] { const char *e = getenv("PMPC_SLEW_INCREMENT_BOXES"); return e && atoi(e) != 0; }();
-  if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && !with_boxes) return false;
+  // With boxes the control boxes become STATE boxes of the restated problem.  Until r03 those met the interior-point iteration only
+  // (1.8x - 2.6x slower cold and ~10x slower warm than the generic kernels' active-set rounds), so boxed slew problems stayed on the
+  // generic kernels; with the state-box rounds of kernels_xbox.hip the restated form is 2.1x - 5.4x FASTER than the generic kernels,
+  // cold and warm, and agrees with them to 1e-15 (tools/debug/slew_paths.py).  It needs the XBOX instantiation of the
+  // factor sweep for (x + u, u); PMPC_SLEW_INCREMENT_BOXES=0 / PMPC_XBOX_AS=0 put boxed slew problems back on the generic kernels.
+  static const bool with_boxes = [] {
+    const char *e = getenv("PMPC_SLEW_INCREMENT_BOXES"), *xe = getenv("PMPC_XBOX_AS");
+    return !(e && atoi(e) == 0) && !(xe && atoi(xe) == 0);
+  }();
+  if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && !(with_boxes && xbox_as_dims_supported((int)(p->xdim + p->udim), (int)p->udim))) return false;
+  // (barrier mode: the shared controls' boxes carry ONE barrier term — particle 0's — which M state boxes on the u-part would count M times)
+  if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && p->barrier_mu > 0.0) return false;
   LQArgs t;
   memset(&t, 0, sizeof(t));
   t.x = (int)(p->xdim + p->udim); t.u = (int)p->udim; t.N = (int)p->N; t.M = (int)p->M; t.sym_cost = 1;
@@ -938,7 +945,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     return finish(2);
   }
   if (ncones == 0 && soc && p->soc_q > 0) cone_rows = (int)p->soc_q + 1;
-  if (soc && !has_ub && cone_as) {  // no boxes: the active-set sweeps still read them — unbounded working copies
+  // State boxes inside the active-set rounds (kernels_xbox.hip); PMPC_XBOX_AS=0 switches them off (then a binding state box sends
+  // the solve to the interior-point iteration, as before r03).
+  static const bool xbox_as_env = !(getenv("PMPC_XBOX_AS") && atoi(getenv("PMPC_XBOX_AS")) == 0);
+  const bool xbox_as = !soc && has_xb && xbox_as_env && fast && !f32 && xbox_as_dims_supported(x, u);
+  if ((soc && !has_ub && cone_as) || (xbox_as && !has_ub)) {  // no control boxes: the active-set sweeps still read them — unbounded working copies
     w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
     w.su_key = -1;
     launch_fill(w.su.lo.d(), -std::numeric_limits<double>::infinity(), (long long)nu, s);
@@ -1178,7 +1189,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // State boxes: a state cannot be held on its bound this way, but boxes that are there and INACTIVE at the optimum (loose
   // limits, e.g. x in +-20 of the reference's tests/pmpcjl_test.py:164-219) change nothing: the accepted point only has to
   // be checked against them.  A violated state box sends the solve (and later solves of this shape) to the interior-point path.
-  const bool polish_on = polish_mu > 0.0 && has_ub && mu_target == 0.0 && !(has_xb && w.xb_block_key == as_key_pre);
+  const bool polish_on = polish_mu > 0.0 && (has_ub || xbox_as) && mu_target == 0.0 && !(has_xb && !xbox_as && w.xb_block_key == as_key_pre);
   const long long as_key = as_key_pre;
   // mode 1: guess from the interior-point iterate in (w.U, slacks, multipliers); mode 0: the stored set, base point = w.U
   // (the previous solution).  Returns 0 accepted (w.X, w.U hold the optimum), 1 not settled, 2 numerical failure.
@@ -1186,7 +1197,10 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // solve of this shape took before it reads anything back, every kernel of a round that is no longer needed returns at once.
   // The base point lives in the caller's output buffers (the forward sweep writes base + step there), so an accepted round
   // leaves nothing to copy.  Returns 0 accepted, 1 not settled, 2 numerical failure.
-  auto active_set_fast = [&](double dual_scale, int mode, int max_rounds) -> int {
+  // xb (problems with state boxes on the XBOX sweeps): 1 state rows on, from the stored statuses / multipliers (mode 0), the
+  // interior-point iterate (mode 1) or nothing (mode 2); 0 state boxes IGNORED (first phase of a cold start, see below); 2 on, nothing
+  // stored.  mode 4: continue from the point an accepted attempt left in the output buffers (second phase of that cold start).
+  auto active_set_fast = [&](double dual_scale, int mode, int max_rounds, int xb = 1) -> int {
     const double big = 1e30, tol_p = 1e-13;
     w.as_act.ensure(nu * sizeof(int) + 8); w.as_cntp.ensure((size_t)M * 3 * sizeof(int)); w.as_settled.ensure((size_t)M * sizeof(int));
     w.as_ctl.ensure(sizeof(AsCtl)); w.as_delta.ensure((size_t)std::max(nc, 1) * D8);
@@ -1226,7 +1240,28 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done; ca.ctl = ctl;
       ca.tol_step = 1e-6; ca.tol_phi = 1e-9; ca.dual_scale = dual_scale;
     }
-    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s, cone ? 8 : 2);  // control block of this attempt (+ cleared failure flag)
+    // state boxes: penalty + multiplier terms per round from kernels_xbox.hip, see the header there
+    const bool xbox = xbox_as && xb != 0;
+    XboxArgs xa;
+    memset(&xa, 0, sizeof(xa));
+    if (xbox) {
+      w.as_open.ensure((size_t)M * sizeof(int)); w.xb_D.ensure(nx * D8); w.xb_g.ensure(nx * D8);
+      const bool z_new = w.xb_z.ensure(nx * D8), st_new = w.xb_st.ensure(nx * sizeof(int));
+      if ((z_new || st_new) && mode == 0) return 1;
+      if (mode == 2 || xb == 2) {  // cold: nothing held, no multipliers — the first pass holds what the base point violates
+        HIP_CHECK(hipMemsetAsync(w.xb_z.p, 0, nx * D8, s));
+        HIP_CHECK(hipMemsetAsync(w.xb_st.p, 0, nx * sizeof(int), s));
+      } else if (mode == 1) {
+        launch_xbox_from_ipm(sx, (int *)w.xb_st.p, w.xb_z.d(), s);
+      }
+      b.xb_D = w.xb_D.d(); b.xb_g = w.xb_g.d();
+      xa.M = M; xa.N = N; xa.x = x; xa.lo = p->lx; xa.hi = p->ux; xa.Q = p->Q; xa.pw = p->weights; xa.reg_x = p->reg_x; xa.rho_scale = 1e7;
+      xa.z = w.xb_z.d(); xa.st = (int *)w.xb_st.p; xa.D = w.xb_D.d(); xa.g = w.xb_g.d();
+      xa.cnt = (int *)w.as_cntp.p; xa.settled = (int *)w.as_settled.p; xa.open = (int *)w.as_open.p; xa.done = &ctl->done; xa.ctl = ctl;
+      xa.tol = 1e-9; xa.dual_scale = dual_scale;
+    }
+    // (a cold start that does not contract is not worth its rounds: the interior-point iteration takes over and names a better first set)
+    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s, cone ? 8 : (xbox ? (mode == 0 ? 6 : 3) : 2));  // control block of this attempt (+ cleared failure flag)
     // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
     // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout, nothing
     // written before the sweep.  The forward sweep verifies that U_prev IS the base point of the stored set.
@@ -1243,6 +1278,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (p->soc_u_interior) launch_soc_fill_u(p->U_out, p->soc_u_interior, (long long)nu, u, s);
       else launch_init_base(p->U_out, p->U_prev, M, N, u, Nc, s);  // (any start will do for the rounds; the shared controls need ONE base value: 0)
       launch_rollout_fast(b, p->U_out, p->X_out, s);
+    } else if (mode == 4) {
+      // the base point is what the attempt that just ended left in the outputs: its controls on their bounds, its states rolled out
     } else if (!use_defect) {  // first base point: controls snapped into their boxes / onto their bounds, states by rollout
       ProfScope ps(c, 5);
       Slab st = su;
@@ -1258,7 +1295,13 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
                                  !(getenv("PMPC_AS_WAVE_CONS") && atoi(getenv("PMPC_AS_WAVE_CONS")) == 0);
     const bool fuse_ctl = fuse_env && !c->multi() && Nc == 1;
     c->as_pend.ctl = nullptr;
-    const int *open_part = cone ? (const int *)w.as_open.p : nullptr;
+    const int *open_part = (cone || xbox) ? (const int *)w.as_open.p : nullptr;
+    if (xbox) {  // terms of the first round, from the first base point and the stored statuses / multipliers
+      ProfScope ps(c, 5);
+      xa.finish = 0;
+      xa.X = use_defect ? p->X_prev : p->X_out;
+      launch_xbox_step(xa, s);
+    }
     if (cone) {  // Newton terms of the first round, from the first base point and the stored multipliers
       ProfScope ps(c, 5);
       ca.finish = 0;
@@ -1291,6 +1334,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           ca.finish = 1;
           ca.U = p->U_out; ca.Uraw = w.cone_uraw.d();
           launch_cone_step(ca, s);
+        }
+        if (xbox) {
+          xa.finish = 1;
+          xa.X = p->X_out;
+          launch_xbox_step(xa, s);
         }
         if (merge) {
           if (last) {
@@ -1340,7 +1388,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (verbose)
         for (int r = round; r < h.round && r < 16; r++)
           printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest violation behind a change %.2e)\n",
-                 mode >= 2 ? "cold" : (mode ? "finish" : "warm"), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
+                 mode == 4 ? "state rows" : (mode >= 2 ? "cold" : (mode ? "finish" : "warm")), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
       if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
       if (verbose > 1 && cone) {  // debugging aid: the active cones' records (small problems only)
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1408,7 +1456,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     if (verbose && (h.cnt[2] || h.cnt[3])) printf("pmpc_hip: active set: numerical failure / broken promise (bad %d, fail %d)\n", h.cnt[2], h.cnt[3]);
     if (!h.done) return 1;
     if (h.status != 0) return h.status;
-    if (has_xb) {  // the candidate's states against their boxes
+    if (has_xb && !xbox_as) {  // the candidate's states against their boxes
       reset_scalars();
       HIP_CHECK(hipMemsetAsync(w.part_max.p, 0, 2 * PMPC_RED_BLOCKS * D8, s));
       Slab sc2 = sx;
@@ -1432,11 +1480,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     w.as_key = as_key;  // the stored set (+ w.U) start the next solve of this shape
     w.as_scale = dual_scale;
     if (mode == 0) w.as_pred_rounds = round;
-    c->spec_ok = n_batches_at_hook == 1 && !has_xb;  // what was enqueued behind the first batch saw the final outputs
+    c->spec_ok = n_batches_at_hook == 1 && !(has_xb && !xbox);  // (with state boxes ignored, a second phase follows)  // what was enqueued behind the first batch saw the final outputs
     return 0;
   };
-  auto active_set_solve = [&](double dual_scale, int mode, int max_rounds) -> int {
-    if (fast) return active_set_fast(dual_scale, mode, max_rounds);
+  auto active_set_solve = [&](double dual_scale, int mode, int max_rounds, int xb = 1) -> int {
+    if (fast) return active_set_fast(dual_scale, mode, max_rounds, xb);
     reset_scalars();
     // generic kernels: a check pass + rollout per round, decisions on the host.  `big` never meets a normal-sized term in a sum (the penalty's target is a ZERO step), so it only has to dwarf every
     // H_uu entry: gains, H_uu^-1 and the step of a held control come out ~1e-30 relative and -big du_b is its multiplier
@@ -1545,7 +1593,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   const bool as_prev_is_base = fast && !c->multi() && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
   if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || as_can_defect || as_prev_is_base)) {
     a.Dx = a.wx = nullptr;
-    const int r = active_set_solve(w.as_scale, 0, 8);
+    const int r = active_set_solve(w.as_scale, 0, xbox_as ? 14 : 8);
     if (r == 0) return finish(0);
     if (verbose) printf("pmpc_hip: warm active-set iteration not settled (%d): interior-point path\n", r);
     if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
@@ -1563,8 +1611,15 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     // cold start of the active-set iteration: the boxes the equality-only optimum violates are the first guess (the classical
     // start of the primal-dual active-set method); the interior-point iteration below only runs if that does not settle
     static const int cold_as_rounds = getenv("PMPC_AS_COLD") ? atoi(getenv("PMPC_AS_COLD")) : 10;
-    if (polish_on && cold_as_rounds > 0 && !(has_xb && w.xb_block_key == as_key)) {
-      const int q = active_set_solve(1.0, 2, cold_as_rounds);
+    if (polish_on && cold_as_rounds > 0) {
+      // with state boxes, in two phases: the control boxes alone first (the primal-dual active-set rule is at home there, whatever
+      // the start), then the state rows from that optimum — which violates about the rows that bind, where the equality-only optimum
+      // clipped into its control boxes violates many more (a start the state rows' Newton iteration does not recover from)
+      int q = active_set_solve(1.0, 2, cold_as_rounds, xbox_as ? 0 : 1);
+      if (q == 0 && xbox_as) {
+        q = active_set_fast(1.0, 4, 14, 2);
+        if (q != 0) outputs_written = false;  // (the first phase's point is not the answer)
+      }
       if (q == 0) return finish(0);
       if (q == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
       // (w.U still holds the equality-only optimum: the rounds work in their own buffers)
@@ -1631,7 +1686,9 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     int status = 1;
     double mu_peak = 1.0;  // dual scale: on badly scaled problems mu first GROWS by orders of magnitude; the
                            // complementarity tolerance is relative to that peak (1e-12 absolute is then below round-off)
-    double polish_next = polish_mu;  // try the active-set finish once mu <= polish_next * mu_peak (relative, like `tol`)
+    // try the active-set finish once mu <= polish_next * mu_peak (relative, like `tol`).  With state rows the iterate has to name the
+    // set more sharply (measured, tools/debug/xbox_check.py: attempts at 1e-3 fail two times in three, at 1e-6 .. 1e-8 they settle)
+    double polish_next = xbox_as ? 1e-3 * polish_mu : polish_mu;
     bool advanced = false;  // this iteration's elementwise pass is already in flight (launched behind the last exchange)
     for (int it = 1; it <= max_iter; it++) {
       // previous corrector step (it > 1), predictor preparation and gradient pre-pass in ONE pass
@@ -1669,14 +1726,14 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       if (it == max_iter) break;
-      if (polish_on && it > 1 && h.mu <= polish_next * mu_peak && !(has_xb && w.xb_block_key == as_key)) {
+      if (polish_on && it > 1 && h.mu <= polish_next * mu_peak && !(has_xb && !xbox_as && w.xb_block_key == as_key)) {
         const double mu_now = h.mu;  // (h aliases the host snapshot)
-        const int r = active_set_solve(std::max(1.0, mu_peak), 1, 6);
+        const int r = active_set_solve(std::max(1.0, mu_peak), 1, xbox_as ? 10 : 6);
         if (r == 0) { inf.mu = 0.0; status = 0; break; }
         // not settled: the interior-point state (U, X, slacks, multipliers) is untouched; rebuild what the attempt
         // overwrote (D, w, gradient pre-pass arrays) and go on; try again two orders of magnitude further down
         if (verbose) printf("pmpc_hip: active-set finish not settled (%d): continuing the interior-point iteration\n", r);
-        polish_next = mu_now / mu_peak * 1e-2;
+        polish_next = mu_now / mu_peak * (xbox_as ? 1e-4 : 1e-2);  // (a failed attempt with state rows costs up to ten rounds)
         if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
         launch_ipm_advance(ex, eu, 0, sc, w.part_sum.d(), w.part_cnt.d(), w.part_max.d(), s);
       }

@@ -30,6 +30,21 @@ def rand_problem(rng, M, N, x, u, bounds_u=None, bounds_x=None, slew=None, slew0
     return (x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref), kw
 
 
+def xbox_problem(rng, oracle, M, N, x, u, Nc, bounds_u=None, slew=None, slew0=None, pull=0.5, margin=0.02):
+    """A problem whose state boxes BIND and are feasible by construction: X_f is a dynamics-, box- and consensus-consistent
+    trajectory (the oracle's optimum for another reference), X* the optimum without state boxes; the boxes are the entrywise
+    interval hull of X_f and the point `pull` of the way from X_f to X*, widened by `margin` — so X_f is strictly inside and X* is
+    outside wherever it differs from X_f by more than margin / (1 - pull)."""
+    args, kw = rand_problem(rng, M, N, x, u, bounds_u, None, slew, slew0)
+    Xs, _ = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    other = list(args)
+    other[8] = rng.standard_normal((M, N, x))
+    Xf, _ = oracle.lqp_solve_py(*other, Nc=Nc, **kw)
+    P = Xf + pull * (Xs - Xf)
+    kw["x_l"], kw["x_u"] = np.minimum(Xf, P) - margin, np.maximum(Xf, P) + margin
+    return args, kw
+
+
 # (M, N, x, u, Nc, u-bound, x-bound, slew, slew0) — covers every structural branch of lqp_utils.jl
 CASES = [
     (1, 5, 2, 1, 0, None, None, None, None),

@@ -117,7 +117,7 @@ def test_weighted_lqp_and_particle_costs(dims, oracle):
         common.update(slew_reg=dev(kw["slew_reg"]), slew_reg0=dev(kw["slew_reg0"]), slew_um1=dev(kw["slew_um1"]))
     X, U, status = s.lqp_solve(weights=dev(wts), **common)
     s.sync()
-    assert status == 0 and s.last_info["fast_path"] == (0 if slew else 1)
+    assert status == 0 and s.last_info["fast_path"] == 1  # (boxed slew: the increment form with state-box rounds since r03)
     assert _rel(X.cpu().numpy(), Xo) < TOL and _rel(U.cpu().numpy(), Uo) < TOL
     J = s.particle_costs(X, U, **common).cpu().numpy()
     Jo = oracle.particle_costs_py(X.cpu().numpy(), U.cpu().numpy(), X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=kw["reg_x"],
