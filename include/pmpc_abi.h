@@ -184,6 +184,25 @@ typedef struct pmpc_ctx pmpc_ctx;
 
 int pmpc_create(pmpc_ctx **ctx, int device);          /* 0 on success */
 void pmpc_destroy(pmpc_ctx *ctx);
+/* Per-context algorithm switches (0 on success, -1 unknown key).  Every key has an environment variable of the same meaning that
+ * sets its DEFAULT when a context is created (so a process-wide override still works): key / variable / default —
+ *   as_warm PMPC_AS_WARM 1             warm start of the active-set rounds from the previous solve's set
+ *   as_skip PMPC_AS_SKIP 1             settled particles skip the factor sweep of the later rounds
+ *   as_defect PMPC_AS_DEFECT 1         no-rollout warm start under PMPC_PREV_IS_LAST_SOLUTION
+ *   as_cold_rounds PMPC_AS_COLD 10     rounds of the cold start (0: interior-point iteration at once)
+ *   polish_mu PMPC_POLISH_MU 1e-3      relative complementarity at which the interior-point iteration tries the rounds (0: rounds off altogether)
+ *   warm_start PMPC_WARM_START 1       interior-point warm start from the remembered early iterate
+ *   cone_as PMPC_CONE_AS 1             stage cones inside the rounds (0: path-following iteration)
+ *   cone_cold_rounds PMPC_CONE_AS_COLD 16
+ *   xbox_as PMPC_XBOX_AS 1             state boxes inside the rounds (0: a binding one sends the solve to the interior-point iteration)
+ *   slew_increment_boxes PMPC_SLEW_INCREMENT_BOXES 1   boxed slew problems in increment form on the MFMA path (needs xbox_as)
+ *   as_fuse_ctl PMPC_AS_FUSE_CTL 1, as_wave_cons PMPC_AS_WAVE_CONS 1   launch fusions of the rounds (measurement legs)
+ *   host_reuse PMPC_HOST_REUSE 1       host ABI: unchanged 8 MB chunks are not uploaded again
+ *   warn_slow_path PMPC_WARN_SLOW_PATH 1   one line on stderr when a context first leaves the register-resident path
+ * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
+ * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
+int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);
+int pmpc_get_option(pmpc_ctx *ctx, const char *key, double *value);
 void *pmpc_stream(pmpc_ctx *ctx);                     /* hipStream_t the solver launches on */
 void pmpc_sync(pmpc_ctx *ctx);                        /* hipStreamSynchronize(pmpc_stream) */
 

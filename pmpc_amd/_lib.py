@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
     "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device", "pmpc_linearize_device_f32",
+    "pmpc_set_option", "pmpc_get_option",
 ]
 
 
@@ -70,6 +71,10 @@ def load():
     lib.pmpc_create.restype = ctypes.c_int
     lib.pmpc_destroy.argtypes = [vp]
     lib.pmpc_destroy.restype = None
+    lib.pmpc_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_double]
+    lib.pmpc_set_option.restype = ctypes.c_int
+    lib.pmpc_get_option.argtypes = [vp, ctypes.c_char_p, c_dp]
+    lib.pmpc_get_option.restype = ctypes.c_int
     lib.pmpc_stream.argtypes = [vp]
     lib.pmpc_stream.restype = vp
     lib.pmpc_sync.argtypes = [vp]

@@ -179,7 +179,33 @@ struct ProfCat {
   long long n = 0;
 };
 
+// Per-context algorithm switches (pmpc_set_option / pmpc_get_option, include/pmpc_abi.h).  Each has an environment variable that
+// sets its DEFAULT when a context is created — so a process-wide override still works, and two contexts of one process (or a test
+// that flips a switch) no longer depend on what the first solve of the process happened to read.
+enum PmpcOpt {
+  OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_COUNT
+};
+static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COUNT] = {
+    {"as_warm", "PMPC_AS_WARM", 1},                // warm start of the active-set rounds from the previous solve's set
+    {"as_skip", "PMPC_AS_SKIP", 1},                // settled particles skip the factor sweep of the later rounds
+    {"as_defect", "PMPC_AS_DEFECT", 1},            // no-rollout warm start under PMPC_PREV_IS_LAST_SOLUTION
+    {"as_cold_rounds", "PMPC_AS_COLD", 10},        // rounds of the cold start (0: straight to the interior-point iteration)
+    {"polish_mu", "PMPC_POLISH_MU", 1e-3},         // relative complementarity at which the interior-point iteration tries the rounds (0: never; also switches the warm / cold starts off)
+    {"warm_start", "PMPC_WARM_START", 1},          // interior-point warm start from the remembered early iterate
+    {"cone_as", "PMPC_CONE_AS", 1},                // stage cones inside the rounds (0: path-following iteration)
+    {"cone_cold_rounds", "PMPC_CONE_AS_COLD", 16}, // rounds of the cone cold start
+    {"xbox_as", "PMPC_XBOX_AS", 1},                // state boxes inside the rounds (0: interior-point iteration when one binds)
+    {"slew_increment_boxes", "PMPC_SLEW_INCREMENT_BOXES", 1},  // boxed slew problems in increment form on the MFMA path (needs xbox_as)
+    {"as_fuse_ctl", "PMPC_AS_FUSE_CTL", 1},        // round control rides in the next round's consensus-partials launch
+    {"as_wave_cons", "PMPC_AS_WAVE_CONS", 1},      // consensus system solved by every wave of the forward sweep
+    {"host_reuse", "PMPC_HOST_REUSE", 1},          // host ABI: unchanged 8 MB chunks are not uploaded again
+    {"warn_slow_path", "PMPC_WARN_SLOW_PATH", 1},  // one line on stderr when a context first leaves the register-resident path
+};
+
 struct pmpc_ctx {
+  double opt[OPT_COUNT];
+  bool warned_slow_path = false;
   AsCtlCall as_pend{};  // round control of the previous active-set round, to ride in the next consensus-partials launch (structured_solve)
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
   double partial_ms = 0.0;  // class 4 of the last pmpc_profile_read
@@ -336,7 +362,7 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
       if (a.as_merge == 2)
         launch_as_ctl(const_cast<AsCtl *>(a.as_ctl), nullptr, a.M, (const int *)w.fail.p, 0, 1, 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s, tl);
     };
-    static const bool wave_solve = [] { const char *e = getenv("PMPC_AS_WAVE_CONS"); return !e || atoi(e) != 0; }();
+    const bool wave_solve = c->opt[OPT_AS_WAVE_CONS] != 0.0;
     a.cons_G = 0;
     if (fast && a.as_act && factor && !c->multi() && a.Nc == 1 && wave_solve) {
       // active-set round on one rank with one consensus stage: block partials only — every wave of the forward sweep sums
@@ -417,6 +443,10 @@ int pmpc_create(pmpc_ctx **out, int device) {
   }
   pmpc_ctx *c = new pmpc_ctx();
   c->device = device;
+  for (int k = 0; k < OPT_COUNT; k++) {
+    const char *e = getenv(kPmpcOptions[k].env);
+    c->opt[k] = (e && *e) ? atof(e) : kPmpcOptions[k].dflt;
+  }
   try {
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -433,6 +463,26 @@ int pmpc_create(pmpc_ctx **out, int device) {
   }
   *out = c;
   return 0;
+}
+
+int pmpc_set_option(pmpc_ctx *c, const char *key, double value) {
+  if (!c || !key) return -1;
+  for (int k = 0; k < OPT_COUNT; k++)
+    if (!strcmp(key, kPmpcOptions[k].key)) {
+      c->opt[k] = value;
+      c->ws.as_key = c->ws.warm_key = -1;  // (a remembered set / iterate was found under the old switches)
+      return 0;
+    }
+  return -1;
+}
+int pmpc_get_option(pmpc_ctx *c, const char *key, double *value) {
+  if (!c || !key || !value) return -1;
+  for (int k = 0; k < OPT_COUNT; k++)
+    if (!strcmp(key, kPmpcOptions[k].key)) {
+      *value = c->opt[k];
+      return 0;
+    }
+  return -1;
 }
 
 void pmpc_destroy(pmpc_ctx *c) {
@@ -630,7 +680,7 @@ int pmpc_lsoc_solve_device(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
 
 // Slew penalties on the MFMA path: restate the problem in control increments (kernels_slew.hip: state [x; u], control
 // u_j - u_{j-1}, control boxes -> boxes on the state), solve that plain problem, split the state back into (X, U).
-static bool slew_increment_form_applies(const pmpc_problem *p, bool soc) {
+static bool slew_increment_form_applies(const pmpc_ctx *c, const pmpc_problem *p, bool soc) {
   if (soc || !(p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0)) || (p->flags & PMPC_FORCE_GENERIC) || !(p->flags & PMPC_SYMMETRIC_COST))
     return false;
   if (p->N < 2) return false;  // N = 1: the reference's diagonal rule is not the plain penalty (lqp_utils.jl:31-39)
@@ -638,11 +688,8 @@ static bool slew_increment_form_applies(const pmpc_problem *p, bool soc) {
   // (1.8x - 2.6x slower cold and ~10x slower warm than the generic kernels' active-set rounds), so boxed slew problems stayed on the
   // generic kernels; with the state-box rounds of kernels_xbox.hip the restated form is 2.1x - 5.4x FASTER than the generic kernels,
   // cold and warm, and agrees with them to 1e-15 (tools/debug/slew_paths.py).  It needs the XBOX instantiation of the
-  // factor sweep for (x + u, u); PMPC_SLEW_INCREMENT_BOXES=0 / PMPC_XBOX_AS=0 put boxed slew problems back on the generic kernels.
-  static const bool with_boxes = [] {
-    const char *e = getenv("PMPC_SLEW_INCREMENT_BOXES"), *xe = getenv("PMPC_XBOX_AS");
-    return !(e && atoi(e) == 0) && !(xe && atoi(xe) == 0);
-  }();
+  // factor sweep for (x + u, u); the options slew_increment_boxes = 0 / xbox_as = 0 put boxed slew problems back on the generic kernels.
+  const bool with_boxes = c->opt[OPT_SLEW_INCREMENT_BOXES] != 0.0 && c->opt[OPT_XBOX_AS] != 0.0;
   if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && !(with_boxes && xbox_as_dims_supported((int)(p->xdim + p->udim), (int)p->udim))) return false;
   // (barrier mode: the shared controls' boxes carry ONE barrier term — particle 0's — which M state boxes on the u-part would count M times)
   if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && p->barrier_mu > 0.0) return false;
@@ -721,7 +768,7 @@ static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
 static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
   const bool f32 = (p->flags & PMPC_F32_MATRICES) != 0;
   if (f32 && (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_HAS_XBOUNDS | PMPC_FORCE_GENERIC))) return PMPC_NEEDS_F64;
-  if (p->xdim > 0 && p->udim > 0 && p->N > 0 && p->M > 0 && p->Nc <= (long long)p->N && slew_increment_form_applies(p, soc))
+  if (p->xdim > 0 && p->udim > 0 && p->N > 0 && p->M > 0 && p->Nc <= (long long)p->N && slew_increment_form_applies(c, p, soc))
     return solve_slew_increment_form(c, p, info, verbose);
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
@@ -798,10 +845,21 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   a.dX = w.dX.d(); a.dU = w.dU.d(); a.fail = (int *)w.fail.p;
   a.X = w.X.d(); a.U = w.U.d();
   const bool fast = !(p->flags & PMPC_FORCE_GENERIC) && lq_fast_supported(a);
+  if (!fast && !(p->flags & PMPC_FORCE_GENERIC) && c->opt[OPT_WARN_SLOW_PATH] != 0.0 && !c->warned_slow_path) {
+    // a caller who forgets symmetric_cost = True (or picks dimensions nothing is compiled for) would get a several times slower solver
+    // silently: say so once per context
+    c->warned_slow_path = true;
+    const char *why = !a.sym_cost ? "Q, R are not declared symmetric (flag PMPC_SYMMETRIC_COST / DeviceSolver(symmetric_cost=True))"
+                      : a.any_slew ? "slew penalties whose increment form (xdim + udim, udim) is not a compiled pair (or N = 1)"
+                      : ((size_t)M * N * (size_t)std::max(x, u) * D8 >= (1ull << 31)) ? "the problem exceeds the 2 GiB per-array addressing of the register-resident kernels"
+                                                                                       : "(xdim, udim) is not a compiled pair (fast_common.h, PMPC_FAST_DIMS)";
+    fprintf(stderr, "pmpc_hip: note: this problem (xdim %d, udim %d) runs on the generic kernels, several times slower than the register-resident MFMA path: %s. "
+                    "Said once per context; pmpc_set_option(ctx, \"warn_slow_path\", 0) or PMPC_WARN_SLOW_PATH=0 silences it.\n", x, u, why);
+  }
   if (f32) {
     // fp32-storage mode: only the warm-started active-set rounds of an SCP loop (no rollout, no equality phase) read the float
     // arrays; everything else asks the caller (solve_impl) for widened copies
-    static const bool f32_defect_on = !(getenv("PMPC_AS_DEFECT") && atoi(getenv("PMPC_AS_DEFECT")) == 0);
+    const bool f32_defect_on = c->opt[OPT_AS_DEFECT] != 0.0;
     if (!(fast && f32_as_dims_supported(x, u) && Nc <= 1 && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && !(p->flags & PMPC_COLD_START) &&
           f32_defect_on && !(p->barrier_mu > 0.0))) {
       w.as_key = as_prev;  // (nothing ran: the warm-start memory stands for the widened solve)
@@ -937,7 +995,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // Stage cones inside the active-set rounds (kernels_cone.hip: semismooth Newton on the cones' natural map, boxes by the
   // primal-dual active-set rule) — warm-started from the previous solve's set and multipliers, cold-started from soc_u_interior;
   // the path-following iteration below is the fallback.  PMPC_CONE_AS=0 switches it off.
-  static const bool cone_as_env = !(getenv("PMPC_CONE_AS") && atoi(getenv("PMPC_CONE_AS")) == 0);
+  const bool cone_as_env = c->opt[OPT_CONE_AS] != 0.0;
   const bool cone_as = soc && cone_as_env && fast && cone_as_dims_supported(x, u) &&
                        (ncones > 0 ? cone_as_supported(u, 0) : (p->soc_q > 0 && cone_as_supported(u, (int)p->soc_q)));
   if (soc && ncones > 0 && !cone_as) {
@@ -947,7 +1005,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   if (ncones == 0 && soc && p->soc_q > 0) cone_rows = (int)p->soc_q + 1;
   // State boxes inside the active-set rounds (kernels_xbox.hip); PMPC_XBOX_AS=0 switches them off (then a binding state box sends
   // the solve to the interior-point iteration, as before r03).
-  static const bool xbox_as_env = !(getenv("PMPC_XBOX_AS") && atoi(getenv("PMPC_XBOX_AS")) == 0);
+  const bool xbox_as_env = c->opt[OPT_XBOX_AS] != 0.0;
   const bool xbox_as = !soc && has_xb && xbox_as_env && fast && !f32 && xbox_as_dims_supported(x, u);
   if ((soc && !has_ub && cone_as) || (xbox_as && !has_ub)) {  // no control boxes: the active-set sweeps still read them — unbounded working copies
     w.su.lo.ensure(nu * D8); w.su.hi.ensure(nu * D8);
@@ -1037,7 +1095,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     int status = 1, newton = 0;
     // warm start as on the box path: the early iterate (mu <= 0.5) of the previous solve of this
     // shape — controls and duals; the slacks are recomputed from the new data — if it is strictly feasible for them
-    static const bool soc_warm_off = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
+    const bool soc_warm_off = c->opt[OPT_WARM_START] == 0.0;
     const long long skey = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 8 + q) * 2 + (has_ub ? 1 : 0);
     bool warm = !soc_warm_off && !(p->flags & PMPC_COLD_START) && w.soc_key == skey, remembered = false;
     int nblk, fl;
@@ -1182,10 +1240,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // boxes (a state cannot be moved onto its bound without leaving the dynamics; state boxes that do not bind are verified at
   // acceptance, see below); not in barrier mode.  DESIGN.md section 2.4.
   const long long as_key_pre = (((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 2 + (fast ? 1 : 0)) * 2 + (has_xb ? 1 : 0)) * 64 + (soc ? 1 + (long long)p->soc_q + 8 * (long long)cone_rows : 0);
-  static const double polish_mu = getenv("PMPC_POLISH_MU") ? atof(getenv("PMPC_POLISH_MU")) : 1e-3;  // 0 switches both uses off
-  static const bool as_warm_on = !(getenv("PMPC_AS_WARM") && atoi(getenv("PMPC_AS_WARM")) == 0);
-  static const bool as_skip_on = !(getenv("PMPC_AS_SKIP") && atoi(getenv("PMPC_AS_SKIP")) == 0);
-  static const bool as_defect_on = !(getenv("PMPC_AS_DEFECT") && atoi(getenv("PMPC_AS_DEFECT")) == 0);
+  const double polish_mu = c->opt[OPT_POLISH_MU];  // 0 switches both uses off
+  const bool as_warm_on = c->opt[OPT_AS_WARM] != 0.0, as_skip_on = c->opt[OPT_AS_SKIP] != 0.0, as_defect_on = c->opt[OPT_AS_DEFECT] != 0.0;
   // State boxes: a state cannot be held on its bound this way, but boxes that are there and INACTIVE at the optimum (loose
   // limits, e.g. x in +-20 of the reference's tests/pmpcjl_test.py:164-219) change nothing: the accepted point only has to
   // be checked against them.  A violated state box sends the solve (and later solves of this shape) to the interior-point path.
@@ -1291,8 +1347,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     }
     // (same conditions as the in-wave consensus solve of structured_solve: one rank, one consensus stage)
-    static const bool fuse_env = !(getenv("PMPC_AS_FUSE_CTL") && atoi(getenv("PMPC_AS_FUSE_CTL")) == 0) &&
-                                 !(getenv("PMPC_AS_WAVE_CONS") && atoi(getenv("PMPC_AS_WAVE_CONS")) == 0);
+    const bool fuse_env = c->opt[OPT_AS_FUSE_CTL] != 0.0 && c->opt[OPT_AS_WAVE_CONS] != 0.0;
     const bool fuse_ctl = fuse_env && !c->multi() && Nc == 1;
     c->as_pend.ctl = nullptr;
     const int *open_part = (cone || xbox) ? (const int *)w.as_open.p : nullptr;
@@ -1562,7 +1617,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   };
   if (soc) {
     if (cone_as) {
-      static const int cone_cold_rounds = getenv("PMPC_CONE_AS_COLD") ? atoi(getenv("PMPC_CONE_AS_COLD")) : 16;
+      const int cone_cold_rounds = (int)c->opt[OPT_CONE_COLD_ROUNDS];
       const bool can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
       const bool prev_is_base = !c->multi() && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
       int r = 1;
@@ -1602,7 +1657,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // Warm start (see below): when the previous solve of this shape ended in the interior-point phase, go there directly —
   // the equality-only solve (one factorisation + forward sweep) would only tell us that the boxes are active again; it
   // is done later if the warm attempt is rejected or fails
-  static const bool warm_disabled = getenv("PMPC_WARM_START") && atoi(getenv("PMPC_WARM_START")) == 0;
+  const bool warm_disabled = c->opt[OPT_WARM_START] == 0.0;
   const long long key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
   const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && mu_target == 0.0 && (has_xb || has_ub) && w.warm_key == key;
   if (!try_warm) {
@@ -1610,7 +1665,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     if (r != 1) return finish(r);
     // cold start of the active-set iteration: the boxes the equality-only optimum violates are the first guess (the classical
     // start of the primal-dual active-set method); the interior-point iteration below only runs if that does not settle
-    static const int cold_as_rounds = getenv("PMPC_AS_COLD") ? atoi(getenv("PMPC_AS_COLD")) : 10;
+    const int cold_as_rounds = (int)c->opt[OPT_AS_COLD_ROUNDS];
     if (polish_on && cold_as_rounds > 0) {
       // with state boxes, in two phases: the control boxes alone first (the primal-dual active-set rule is at home there, whatever
       // the start), then the state rows from that optimum — which violates about the rows that bind, where the equality-only optimum
@@ -2102,7 +2157,7 @@ static void upload_all(pmpc_ctx *c, const std::vector<UploadItem> &items) {
     HIP_CHECK(hipHostMalloc(&c->pinned, total, hipHostMallocDefault));
     c->pinned_bytes = total;
   }
-  static const bool reuse_on = !(getenv("PMPC_HOST_REUSE") && atoi(getenv("PMPC_HOST_REUSE")) == 0);
+  const bool reuse_on = c->opt[OPT_HOST_REUSE] != 0.0;
   const std::vector<pmpc_ctx::StagedChunk> &prev = c->staged;
   unsigned nthreads = std::thread::hardware_concurrency();
   nthreads = std::max(1u, std::min(nthreads ? nthreads : 4u, 16u));

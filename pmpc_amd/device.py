@@ -40,6 +40,17 @@ class DeviceSolver:
         self.rank, self.world = 0, 1
         self.last_info: Dict[str, float] = {}
 
+    def set_option(self, key: str, value: float) -> None:
+        """Per-context algorithm switch (include/pmpc_abi.h, pmpc_set_option): e.g. ``set_option("xbox_as", 0)``."""
+        if self.lib.pmpc_set_option(self.h, key.encode(), float(value)) != 0:
+            raise KeyError(f"pmpc_set_option: unknown option {key!r}")
+
+    def get_option(self, key: str) -> float:
+        v = ctypes.c_double()
+        if self.lib.pmpc_get_option(self.h, key.encode(), ctypes.byref(v)) != 0:
+            raise KeyError(f"pmpc_get_option: unknown option {key!r}")
+        return v.value
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.pmpc_destroy(self.h)

@@ -412,3 +412,38 @@ def test_bench_line_keeps_the_driver_contract():
     assert rp["windows"] == 5 and len(rp["values"]) == 5 and rp["min"] <= rp["median"] <= rp["max"] and abs(rp["values"][0] - d["value"]) < 1e-9 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and "julia" in cb
+
+
+def test_a_context_says_once_when_it_leaves_the_register_resident_path(capfd):
+    """a caller who forgets symmetric_cost=True gets a several times slower solver — said once per context on
+    stderr (and in info["fast_path"]), silenced by the option warn_slow_path."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+    from tests.support.problems import rand_problem
+
+    M, N, x, u = 4, 6, 4, 2
+    args, kw = rand_problem(np.random.default_rng(3), M, N, x, u, 0.4)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    opt = dict(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref), U_ref=dev(U_ref),
+               reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=1, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]))
+    s = DeviceSolver(0)
+    capfd.readouterr()
+    for rep in range(2):
+        _, _, status = s.lqp_solve(**opt)  # symmetric_cost not declared
+        s.sync()
+        assert status == 0 and s.last_info["fast_path"] == 0
+    err = capfd.readouterr().err
+    assert err.count("runs on the generic kernels") == 1 and "PMPC_SYMMETRIC_COST" in err, err
+    _, _, status = s.lqp_solve(symmetric_cost=True, **opt)
+    s.sync()
+    assert status == 0 and s.last_info["fast_path"] == 1
+    s.close()
+    quiet = DeviceSolver(0)
+    quiet.set_option("warn_slow_path", 0)
+    quiet.lqp_solve(**opt)
+    quiet.sync()
+    assert "generic kernels" not in capfd.readouterr().err
+    quiet.close()

@@ -104,40 +104,25 @@ def test_slew_with_weights_and_an_scp_like_sequence(oracle):
     s.close()
 
 
-_BOXED_SCRIPT = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, os.getcwd())
-from oracle import lqp_oracle as orc
-from pmpc_amd.device import DeviceSolver
-from tests.support.problems import rand_problem
-from tests.test_slew_gpu import _solve, _rel
-s = DeviceSolver(0)
-for k, (M, N, x, u, Nc, bu, bx) in enumerate([(16, 20, 4, 2, 1, 0.3, None), (12, 15, 2, 1, 0, 0.4, None), (6, 10, 4, 2, 2, 0.3, 8.0), (3, 6, 3, 2, 2, 0.3, 5.0)]):
-    args, kw = rand_problem(np.random.default_rng(300 + k), M, N, x, u, bu, bx, 0.8, 0.5)
-    Xo, Uo = orc.lqp_solve_py(*args, Nc=Nc, **kw)
+@pytest.mark.parametrize("case", [(16, 20, 4, 2, 1, 0.3, None), (12, 15, 2, 1, 0, 0.4, None), (6, 10, 4, 2, 2, 0.3, 8.0), (3, 6, 3, 2, 2, 0.3, 5.0)],
+                         ids=lambda c: str(c))
+def test_boxed_slew_problems_on_the_generic_kernels_when_switched_back(case, oracle):
+    """Option slew_increment_boxes = 0 (PMPC_SLEW_INCREMENT_BOXES=0 process-wide): boxed slew problems stay on the generic
+    kernels — the r02 default and the comparison leg of tools/debug/slew_paths.py."""
+    from pmpc_amd.device import DeviceSolver
+
+    M, N, x, u, Nc, bu, bx = case
+    args, kw = rand_problem(np.random.default_rng(300 + M), M, N, x, u, bu, bx, 0.8, 0.5)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    s = DeviceSolver(0)
+    s.set_option("slew_increment_boxes", 0)
+    s.set_option("warn_slow_path", 0)
     X, U, status, info = _solve(s, args, kw, Nc)
-    print((M, N, x, u, Nc), info["fast_path"], info["ipm_iters"], _rel(X, Xo), _rel(U, Uo), flush=True)
-    assert status == 0 and info["fast_path"] == 0
-    assert _rel(X, Xo) <= 1e-7 and _rel(U, Uo) <= 1e-7
+    assert status == 0 and info["fast_path"] == 0, info
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL
     if Nc > 0:
         assert np.all(U[:, :Nc] == U[0:1, :Nc])
-print("BOXED_GENERIC_OK")
-"""
-
-
-def test_boxed_slew_problems_on_the_generic_kernels_when_switched_back():
-    """PMPC_SLEW_INCREMENT_BOXES=0: boxed slew problems stay on the generic kernels (the r02 default; the comparison leg of
-    tools/debug/slew_paths.py).  Own process: the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-
-    env = dict(os.environ, PMPC_SLEW_INCREMENT_BOXES="0")
-    r = subprocess.run([sys.executable, "-c", _BOXED_SCRIPT], cwd=str(Path(__file__).resolve().parents[1]), env=env,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "BOXED_GENERIC_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    s.close()
 
 
 def test_boxed_slew_warm_start_takes_one_round(oracle):

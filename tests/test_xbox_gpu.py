@@ -81,34 +81,23 @@ def test_state_rows_cold_warm_and_next_problem(pull, cold_in_rounds, oracle):
     s.close()
 
 
-_OFF_SCRIPT = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, os.getcwd())
-from oracle import lqp_oracle as orc
-from pmpc_amd.device import DeviceSolver
-from tests.support.problems import xbox_problem
-from tests.test_slew_gpu import _solve, _rel
-args, kw = xbox_problem(np.random.default_rng(11), orc, 16, 20, 4, 2, 1, 0.5, pull=0.95, margin=0.05)
-Xo, Uo = orc.lqp_solve_py(*args, Nc=1, **kw)
-s = DeviceSolver(0)
-X, U, status, info = _solve(s, args, kw, 1)
-print(info, _rel(X, Xo), _rel(U, Uo), flush=True)
-assert status == 0 and info["ipm_iters"] > 0
-assert _rel(X, Xo) <= 1e-5 and _rel(U, Uo) <= 1e-5  # (the interior-point iteration ALONE on ~10 % binding state rows: the accuracy the rounds repair)
-print("XBOX_OFF_OK")
-"""
+def test_state_box_rounds_can_be_switched_off_per_context(oracle):
+    """Option xbox_as = 0 (pmpc_set_option; PMPC_XBOX_AS=0 sets the same default process-wide): the r02 behaviour — a binding state
+    box sends the solve to the interior-point iteration — stays reachable, on one context while another keeps the rounds."""
+    from pmpc_amd.device import DeviceSolver
 
-
-def test_state_box_rounds_can_be_switched_off():
-    """PMPC_XBOX_AS=0: the r02 behaviour (a binding state box sends the solve to the interior-point iteration) stays reachable —
-    the comparison leg of tools/debug/xbox_check.py.  Own process: the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-
-    env = dict(os.environ, PMPC_XBOX_AS="0")
-    r = subprocess.run([sys.executable, "-c", _OFF_SCRIPT], cwd=str(Path(__file__).resolve().parents[1]), env=env,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "XBOX_OFF_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    args, kw = xbox_problem(np.random.default_rng(11), oracle, 16, 20, 4, 2, 1, 0.5, pull=0.97, margin=0.05)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=1, **kw)
+    off, on = DeviceSolver(0), DeviceSolver(0)
+    assert off.get_option("xbox_as") == 1.0
+    off.set_option("xbox_as", 0)
+    with pytest.raises(KeyError):
+        off.set_option("no_such_option", 1)
+    X, U, status, info = _solve(off, args, kw, 1)
+    assert status == 0 and info["ipm_iters"] > 0, info
+    assert _rel(X, Xo) <= 1e-6 and _rel(U, Uo) <= 1e-6  # (the interior-point iteration alone: the north-star tolerance)
+    X, U, status, info = _solve(on, args, kw, 1)
+    assert status == 0 and info["ipm_iters"] == 0, info
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL
+    off.close()
+    on.close()
