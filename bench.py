@@ -356,15 +356,22 @@ def main():
             avg_c = ms_c / n_c * 1e-3
             plain = {"avg_launch_ms": 1e3 * avg_c, "achieved": alg_bytes / avg_c / 1e9, "frac": alg_bytes / avg_c / 1e9 / HBM_PEAK_GBS,
                      "launches": int(n_c)}
-        traffic = None
+        # PMC traffic of the timed kernel: measured once per round by tools/profile_gpu.sh + tools/summarize_profile.py (separate
+        # --pmc passes, corrections as the MI355X guide prescribes) AT CONFIG D, fp64 — attached only to that workload
+        traffic = traffic_kernel = traffic_profile = None
         tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists():
+        at_config_d = args.model == "quadrotor" and M_loc == 4096 and N == 50 and not (args.fp32 or args.soc or args.cone or args.force_generic)
+        if tf.exists() and at_config_d:
             try:
                 tj = json.loads(tf.read_text())
                 # timed region = DEFECT instantiation once the SCP loop runs (second step on); plain instantiation otherwise
-                traffic = tj.get("bwd_factor_defect_bytes_per_launch", tj.get("bwd_factor_bytes_per_launch"))
+                key = "bwd_factor_defect" if "bwd_factor_defect_bytes_per_launch" in tj else "bwd_factor"
+                traffic = tj.get(f"{key}_bytes_per_launch")
+                traffic_kernel = tj.get(key, {}).get("kernels")
+                traffic_profile = tj.get("profile")
                 if plain is not None:
-                    plain["traffic"] = tj.get("bwd_factor_bytes_per_launch")
+                    plain["traffic"] = tj.get("bwd_factor_as_plain_bytes_per_launch", tj.get("bwd_factor_bytes_per_launch"))
+                    plain["traffic_kernel"] = tj.get("bwd_factor_as_plain" if "bwd_factor_as_plain" in tj else "bwd_factor", {}).get("kernels")
             except Exception:
                 traffic = None
         per_solve = None
@@ -402,6 +409,7 @@ def main():
                         "note": "`value` is the FIRST window (the contract's W + K steps); the others repeat it from a fresh SCP start in the same process"},
             "roofline": {"bound": "hbm", "kernel": "backward Riccati factor sweep", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_kernel": traffic_kernel, "traffic_profile": traffic_profile,
                          "note": "full factor sweeps of the timed region only (every particle x stage): later active-set rounds skip the "
                                  "settled particles and are timed in a class of their own (bwd_factor_partial). Inside the "
                                  "SCP loop the full sweep is the DEFECT instantiation (it also carries the base point's dynamics defect, "

@@ -20,3 +20,19 @@ grep -h '^{' $out/bench_C.log $out/bench_B.log | cut -c1-200
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --M 256 --N 30 --model unicycle --Nc -1 > $out/bench_B_NcN.log 2>&1
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --M 4096 --Nc -1 > $out/bench_D_NcN.log 2>&1
 grep -h '^{' $out/bench_B_NcN.log $out/bench_D_NcN.log | cut -c1-200
+# r03: config E's constraints (thrust cone per stage, N = 100) in fp64 and in fp32-storage mode, config D in fp32-storage mode, the
+# reference's DEFAULT solver path (c_lcone_solve) on D and B, and the kernel split of the cone rounds
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --soc --N 100 > $out/bench_E_soc.log 2>&1
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --soc --N 100 --fp32 > $out/bench_E_soc_fp32.log 2>&1
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --fp32 > $out/bench_D_fp32.log 2>&1
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --cone > $out/bench_D_cone.log 2>&1
+python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --cone --M 256 --N 30 --model unicycle > $out/bench_B_cone.log 2>&1
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --cone --smooth-alpha 10 --M 256 --N 30 --model unicycle > $out/bench_B_cone_smooth.log 2>&1
+grep -h '^{' $out/bench_E_soc.log $out/bench_E_soc_fp32.log $out/bench_D_fp32.log $out/bench_D_cone.log $out/bench_B_cone.log $out/bench_B_cone_smooth.log | cut -c1-160
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_E_soc -- python3 bench.py --steps 5 --warmup 2 --repeats 0 --no-cpu-baseline --soc --N 100 > $out/bench_stats_E_soc.log 2>&1
+# r03: boxed slew problems (increment form + state-box rounds against the generic kernels) and binding state boxes (rounds on / off)
+python3 tools/debug/slew_paths.py > $out/slew_paths.txt 2>&1
+V=1 python3 tools/debug/xbox_check.py > $out/xbox_on.log 2>&1
+PMPC_XBOX_AS=0 V=1 python3 tools/debug/xbox_check.py > $out/xbox_off.log 2>&1
+for f in on off; do echo "state-box rounds $f: solves, interior-point iterations, factorisations"; grep "status " $out/xbox_$f.log | awk '{n++; it+=$6; ss+=$9} END {print n, it, ss}'; done > $out/xbox_summary.txt
+cat $out/xbox_summary.txt

@@ -34,10 +34,12 @@ ax_read_true = 2 * 8 * (nx + nu) / 2  # y and x streams; k_axpy runs once on X (
 ax_fetch = sum(fetch[ax]) / len(fetch[ax]) * 1024
 read_factor = ax_read_true / ax_fetch
 ax_write = sum(write[key(write, "k_axpy(")]) / len(write[key(write, "k_axpy(")]) * 1024
-out = {"calibration": {"kernel": "k_axpy", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
+out = {"profile": f"profiles/{tag}_kernel_stats.csv / rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes of tools/profile_gpu.sh {tag}",
+       "calibration": {"kernel": "k_axpy", "true_read_bytes": ax_read_true, "FETCH_SIZE_bytes": ax_fetch,
                        "read_factor": read_factor, "true_write_bytes": 8 * (nx + nu) / 2, "WRITE_SIZE_bytes": ax_write}}
 # kernels_as.hip: k_bwd_as<x, u, MODE, SKIP, DEFECT> (MODE 0 lean / 1 deep / 2 deep2; SKIP launches process a subset of the particles:
 # never part of the roofline figure), k_fwd_as<x, u, DEFECT, PF2>; kernels_fast.hip: k_bwd_fast<x, u, FACTOR, HXB, HUB, DEEP>
+# (since r03 the names end in the EX / storage-type arguments: <.., 0, double> = no cone / state-box terms, fp64 storage)
 # The instantiations bench.py's timed region runs at config D: the first round's factor sweep is k_bwd_as<12, 4, 1, false, true>
 # (deep, DEFECT) — `bwd_factor_defect`, the kernel `roofline.achieved` is measured on —, the forward sweeps k_fwd_as<12, 4, *, true>
 # (PF2).  Every match of a prefix is pooled (the MODE / PF2 arguments depend on the particle count).
@@ -54,11 +56,11 @@ def pooled(d, prefixes):
 
 
 for prefixes, label in ((("k_bwd_fast<12, 4, true, false, true, false>",), "bwd_factor"),
-                        (("k_bwd_as<12, 4, 1, false, true>", "k_bwd_as<12, 4, 0, false, true>"), "bwd_factor_defect"),
-                        (("k_bwd_as<12, 4, 1, false, false>", "k_bwd_as<12, 4, 0, false, false>"), "bwd_factor_as_plain"),
+                        (("k_bwd_as<12, 4, 1, false, true, 0, double>", "k_bwd_as<12, 4, 0, false, true, 0, double>"), "bwd_factor_defect"),
+                        (("k_bwd_as<12, 4, 1, false, false, 0, double>", "k_bwd_as<12, 4, 0, false, false, 0, double>"), "bwd_factor_as_plain"),
                         (("k_bwd_fast<12, 4, false",), "bwd_vec"), (("k_fwd_fast<12, 4, false>",), "fwd"),
-                        (("k_fwd_as<12, 4, false, true>", "k_fwd_as<12, 4, false, false>"), "fwd_active_set"),
-                        (("k_fwd_as<12, 4, true, true>", "k_fwd_as<12, 4, true, false>"), "fwd_active_set_defect")):
+                        (("k_fwd_as<12, 4, false, true, false, double>", "k_fwd_as<12, 4, false, false, false, double>"), "fwd_active_set"),
+                        (("k_fwd_as<12, 4, true, true, false, double>", "k_fwd_as<12, 4, true, false, false, double>"), "fwd_active_set_defect")):
     try:
         fv, fnames = pooled(fetch, prefixes)
         wv, _ = pooled(write, prefixes)
@@ -78,9 +80,19 @@ stats = glob.glob(str(src / "stats" / "*" / "*kernel_stats.csv"))[0]
 for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f"{tag}_bench_under_rocprof.json"),
                   ("bench_C.log", f"{tag}_bench_C.json"), ("bench_B.log", f"{tag}_bench_B.json"),
                   ("bench_B_NcN.log", f"{tag}_bench_B_NcN.json"), ("bench_D_NcN.log", f"{tag}_bench_D_NcN.json"),
-                  ("bench_shard_512.log", f"{tag}_bench_shard_512.json"), ("bench_shard_2048.log", f"{tag}_bench_shard_2048.json")):
+                  ("bench_shard_512.log", f"{tag}_bench_shard_512.json"), ("bench_shard_2048.log", f"{tag}_bench_shard_2048.json"),
+                  ("bench_E_soc.log", f"{tag}_bench_E_soc.json"), ("bench_E_soc_fp32.log", f"{tag}_bench_E_soc_fp32.json"),
+                  ("bench_D_fp32.log", f"{tag}_bench_D_fp32.json"), ("bench_D_cone.log", f"{tag}_bench_D_cone.json"),
+                  ("bench_B_cone.log", f"{tag}_bench_B_cone.json"), ("bench_B_cone_smooth.log", f"{tag}_bench_B_cone_smooth.json")):
     if not (src / log).exists():
         continue
     lines = [l for l in open(src / log) if l.startswith("{")]
     if lines:
         (dst / name).write_text(lines[-1])
+
+for extra in ("slew_paths.txt", "xbox_summary.txt"):
+    if (src / extra).exists():
+        (dst / f"{tag}_{extra}").write_text(open(src / extra).read())
+soc_stats = glob.glob(str(src / "stats_E_soc" / "*" / "*kernel_stats.csv"))
+if soc_stats:
+    (dst / f"{tag}_kernel_stats_E_soc.csv").write_text(open(soc_stats[0]).read())
