@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=4, help="extra repeats of the timed window from a fresh SCP start (spread; outside `value`)")
     ap.add_argument("--thrust-min", type=float, default=0.0, help="quadrotor: lower box of the thrust as a fraction of the hover thrust "
                     "(default 0: the thrust cone's apex is feasible; > 0 keeps every cone away from its apex)")
+    ap.add_argument("--vmax", type=float, default=0.0, help="quadrotor: state boxes |v| <= VMAX m/s on the three velocity components "
+                    "(the other states unbounded); 0 = no state boxes (BASELINE config D).  With a limit that binds the sub-problems "
+                    "exercise the state rows of the active-set rounds (kernels_xbox.hip; PMPC_XBOX_AS=0: the interior-point iteration)")
     ap.add_argument("--trace-steps", action="store_true", help="print (interior-point iterations, active-set rounds, factorisations) of every "
                     "SCP iteration of the first window to stderr")
     ap.add_argument("--python-loop", action="store_true", help="drive the SCP loop from Python (one linearise / solve / residual call per "
@@ -225,6 +228,12 @@ def main():
         soc_kw = dict(soc_W=Wc, soc_w0=torch.zeros(2, dtype=torch.float64, device=dev),
                       soc_v=torch.tensor([0.3, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev), soc_v0=0.0,
                       soc_u_interior=torch.tensor([9.81, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev))
+    xb_kw = {}
+    if args.vmax > 0.0:
+        assert args.model == "quadrotor" and not args.soc
+        lx = torch.full((M_loc, N, x), -float("inf"), dtype=torch.float64, device=dev)
+        lx[..., 3:6] = -args.vmax
+        xb_kw = dict(lx=lx, ux=-lx)
     solve_fn = solver.lsoc_solve if args.soc else solver.lqp_solve
     if args.cone:
         assert not args.soc
@@ -239,7 +248,7 @@ def main():
         if time_solve:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(solver.stream)
-        _, _, status = solve_fn(**soc_kw, f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
+        _, _, status = solve_fn(**soc_kw, **xb_kw, f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"],
                                         U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
                                         lu=d.get("lu"), uu=d.get("uu"), X_out=Xo, U_out=Uo, verbose=args.verbose,
                                         force_generic=args.force_generic, symmetric_cost=True, wait_current_stream=False,
@@ -268,7 +277,7 @@ def main():
             return
         # the SCP loop inside the library (pmpc_scp_loop_device): same kernels, same sequence, no host work between iterations
         res, infos, last_in_out, done = solver.scp_loop(
-            model, d["params"], k, f2=f2, fx2=fx2, fu2=fu2, first_cold=len(hist) == 0, **soc_kw, f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua,
+            model, d["params"], k, f2=f2, fx2=fx2, fu2=fu2, first_cold=len(hist) == 0, **soc_kw, **xb_kw, f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua,
             Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
             lu=d.get("lu"), uu=d.get("uu"), X_out=Xb, U_out=Ub, force_generic=args.force_generic, symmetric_cost=True,
             wait_current_stream=False)
@@ -360,7 +369,7 @@ def main():
         # --pmc passes, corrections as the MI355X guide prescribes) AT CONFIG D, fp64 — attached only to that workload
         traffic = traffic_kernel = traffic_profile = None
         tf = ROOT / "profiles" / "traffic.json"
-        at_config_d = args.model == "quadrotor" and M_loc == 4096 and N == 50 and not (args.fp32 or args.soc or args.cone or args.force_generic)
+        at_config_d = args.model == "quadrotor" and M_loc == 4096 and N == 50 and not (args.fp32 or args.soc or args.cone or args.force_generic or args.vmax > 0.0)
         if tf.exists() and at_config_d:
             try:
                 tj = json.loads(tf.read_text())
@@ -389,11 +398,12 @@ def main():
             "dtype": "f32 storage (fx, fu, Q, R, factor records) / f64 arithmetic" if args.fp32 else "f64", "data": "synthetic",
             "config": {"workload": (f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u, full SCP iteration "
                                     "(on-device linearise + c_lqp_solve-equivalent + residual), BASELINE config D"
-                                    if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 and not args.cone and not args.soc else
+                                    if args.model == "quadrotor" and M_total == 4096 and N == 50 and Nc == 1 and not args.cone and not args.soc and not args.vmax > 0.0 else
                                     f"{args.model} x{x} u{u} M={M_total} N={N} Nc={Nc} box-u" + (" + thrust cone per stage (config E constraints, fp64)" if args.soc else "")
                                     + ((" through the reference's default cone path (c_lcone_solve semantics: eps-anchored epigraph objective"
                                         + (f", log-barrier smoothing alpha = {args.smooth_alpha:g})" if args.smooth_alpha == args.smooth_alpha else ", hard boxes)")) if args.cone else "")
-                                    + (f", thrust >= {args.thrust_min} x hover" if args.thrust_min > 0.0 else ""))
+                                    + (f", thrust >= {args.thrust_min} x hover" if args.thrust_min > 0.0 else "")
+                                    + (f", state boxes |v| <= {args.vmax} m/s" if args.vmax > 0.0 else ""))
                                    + f"; timed window = SCP iterations {w0}..{w1} from the cold start X_prev = x0, U_prev = U_ref "
                                      "(the active-set round count falls as the SCP loop converges, so the rate depends on the window)",
                        "particles_per_gpu": M_loc, "parallelism": f"particle-shard x{world}",

@@ -34,7 +34,26 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
   if (!(rho > 0.0)) rho = a.rho_scale * pw;
   const double margin0 = 10.0 * (a.ctl ? a.ctl->tol_l : 1e-11 * a.dual_scale);
   int changed = 0, open = 0;
-  const bool clamped = a.finish && a.cnt[3 * i + 1] > 0;  // (read by every thread before thread 0 adds to it, two barriers further down)
+  const bool clamped = a.keep_on_clamp && a.finish && a.cnt[3 * i + 1] > 0;  // (read by every thread before thread 0 adds to it, two barriers further down)
+  // pass 1: the largest violation among the rows that would be newly held (a round holds only those within act_frac of it: holding
+  // every violated row of a window at once over-constrains the stage — the rows behind the first usually clear once it is held)
+  double vmax = 0.0;
+  if (a.act_frac > 0.0) {
+    for (int k = t; k < n; k += 256) {
+      const size_t idx = (size_t)i * n + k;
+      const double xv = a.X[idx];
+      if (a.st[idx] == 0 && k % xd < a.ctrl_from) vmax = fmax(vmax, fmax(a.lo[idx] - xv, xv - a.hi[idx]));
+    }
+    __syncthreads();
+    redd[t] = vmax;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) redd[t] = fmax(redd[t], redd[t + w]);
+      __syncthreads();
+    }
+    vmax = redd[0];
+  }
+  const double vthr = a.act_frac * vmax;
   for (int k = t; k < n; k += 256) {
     const size_t idx = (size_t)i * n + k;
     const double xv = a.X[idx], lo = a.lo[idx], hi = a.hi[idx];
@@ -53,9 +72,11 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
     int nst = 0;
     if (wl < (st == 1 ? mg : -mg)) nst = 1;
     else if (wh < (st == 2 ? mg : -mg)) nst = 2;
+    bool deferred = false;
+    if (st == 0 && nst != 0 && k % xd < a.ctrl_from && fmax(-sl, -sh) < vthr) { nst = 0; deferred = true; }  // violated, but not among the worst: next round
     const double zo = (nst != 0 && nst == st) ? zn : 0.0;  // (a newly held side starts without an estimate)
     if (a.finish) {
-      if (nst != st) changed++;
+      if (nst != st || deferred) changed++;
       else if (nst != 0) {
         const double sv = nst == 1 ? sl : sh, bd = nst == 1 ? lo : hi;
         if (fabs(sv) > a.tol * fmax(1.0, fabs(bd)) || fabs(zo - z) > 1e-6 * fmax(a.dual_scale, fabs(zo))) open++;

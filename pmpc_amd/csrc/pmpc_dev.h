@@ -274,6 +274,9 @@ struct XboxArgs {
   const AsCtl *ctl;
   int finish;                // 0: prepare only (first round of an attempt)
   double tol, dual_scale;
+  int keep_on_clamp;         // a sweep whose forward pass clamped a control of the particle keeps the old multipliers
+  double act_frac;           // a round holds only the violated rows within this fraction of the particle's largest violation (0: all)
+  int ctrl_from;             // state entries r >= ctrl_from are controls in disguise (slew increment form): always held when violated
 };
 bool xbox_as_dims_supported(int x, int u);  // kernels_as.hip: (xdim, udim) pairs with XBOX instantiations of the factor sweep
 void launch_xbox_step(const XboxArgs &a, hipStream_t s);

@@ -164,6 +164,7 @@ struct Workspace {
   DevBuf cons_lo, cons_hi;  // sharded runs: the consensus controls' bounds as last broadcast (PMPC_STATIC_CONS_BOUNDS)
   long long cons_key = -1;
   long long xb_block_key = -1;  // shape whose state boxes were found active: no active-set attempts for it
+  int xb_warm_backoff = 0, xb_warm_fails = 0;  // state rows: solves left for which the warm start is not tried / its failures in a row
   long long as_key = -1;  // shape whose accepted active set (as_act) and solution (U) can start the next solve
   double as_scale = 1.0;
   DevBuf part_dev;  // barrier mode: block partials of the centrality deviation
@@ -206,6 +207,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
 struct pmpc_ctx {
   double opt[OPT_COUNT];
   bool warned_slow_path = false;
+  int xb_ctrl_from = -1;  // set around the inner solve of the slew increment form: state entries from this index on are the controls (their boxes the control boxes)
   AsCtlCall as_pend{};  // round control of the previous active-set round, to ride in the next consensus-partials launch (structured_solve)
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
   double partial_ms = 0.0;  // class 4 of the last pmpc_profile_read
@@ -758,7 +760,15 @@ static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
   q.X_out = w.sa_Xo.d(); q.U_out = w.sa_Uo.d();
   pmpc_info inf;
   memset(&inf, 0, sizeof(inf));
-  const int st = solve_impl_body(c, &q, &inf, verbose, false);
+  c->xb_ctrl_from = x;
+  int st;
+  try {
+    st = solve_impl_body(c, &q, &inf, verbose, false);
+  } catch (...) {
+    c->xb_ctrl_from = -1;
+    throw;
+  }
+  c->xb_ctrl_from = -1;
   if (st == 0) launch_slew_split(w.sa_Xo.d(), w.sa_Uo.d(), p->X_out, p->U_out, (long long)rows, x, u, N, (M > 1 || c->multi()) ? Nc : 0, g.cons_lo, g.cons_hi, s);
   else fill_nan_outputs(c, p);
   if (info) *info = inf;
@@ -1311,13 +1321,21 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         launch_xbox_from_ipm(sx, (int *)w.xb_st.p, w.xb_z.d(), s);
       }
       b.xb_D = w.xb_D.d(); b.xb_g = w.xb_g.d();
-      xa.M = M; xa.N = N; xa.x = x; xa.lo = p->lx; xa.hi = p->ux; xa.Q = p->Q; xa.pw = p->weights; xa.reg_x = p->reg_x; xa.rho_scale = 1e7;
+      xa.M = M; xa.N = N; xa.x = x; xa.lo = p->lx; xa.hi = p->ux; xa.Q = p->Q; xa.pw = p->weights; xa.reg_x = p->reg_x; xa.rho_scale = 1e7;  // (measured, bench.py --vmax: 1e5 .. 1e2 only add rounds)
       xa.z = w.xb_z.d(); xa.st = (int *)w.xb_st.p; xa.D = w.xb_D.d(); xa.g = w.xb_g.d();
       xa.cnt = (int *)w.as_cntp.p; xa.settled = (int *)w.as_settled.p; xa.open = (int *)w.as_open.p; xa.done = &ctl->done; xa.ctl = ctl;
       xa.tol = 1e-9; xa.dual_scale = dual_scale;
+      // (measured on bench.py --vmax 2: 302 it/s with both, 175 without the first, 302 -> 396 and no interior-point iteration at all with the second)
+      // — for genuine state rows (a velocity limit violated over a window of stages).  In the increment form of a slew problem the boxes on
+      // the u-part of the state are the control boxes, each moved by its own increment: there the plain rule (hold everything violated) settles in 7-11 rounds
+      // and partial activation only delays it (tools/debug/slew_paths.py: cold start back on the interior-point iteration)
+      xa.keep_on_clamp = 1;
+      xa.act_frac = 0.5;
+      xa.ctrl_from = c->xb_ctrl_from >= 0 ? c->xb_ctrl_from : x;
     }
-    // (a cold start that does not contract is not worth its rounds: the interior-point iteration takes over and names a better first set)
-    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s, cone ? 8 : (xbox ? (mode == 0 ? 6 : 3) : 2));  // control block of this attempt (+ cleared failure flag)
+    // (a cold start on genuine state rows that does not contract is not worth its rounds: the interior-point iteration takes over and
+    //  names a better first set; the control boxes of a slew problem in increment form do settle, in 7-11 rounds that need not contract one by one)
+    launch_as_begin(ctl, (int *)w.fail.p, max_rounds, dual_scale, s, cone ? 8 : (xbox ? (c->xb_ctrl_from >= 0 ? 8 : (mode == 0 ? 6 : 3)) : 2));  // control block of this attempt (+ cleared failure flag)
     // warm start inside an SCP loop (PMPC_PREV_IS_LAST_SOLUTION): the base point is the linearisation point itself, whose
     // dynamics defect f - X_prev is elementwise and rides through the first round's sweeps — no sequential rollout, nothing
     // written before the sweep.  The forward sweep verifies that U_prev IS the base point of the stored set.
@@ -1646,10 +1664,21 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // (the caller's U_prev is the stored set's solution; one rank only: the shared controls' base must be the same on every rank,
   //  which only this context's own copy guarantees when a caller breaks its promise)
   const bool as_prev_is_base = fast && !c->multi() && (p->flags & PMPC_PREV_IS_LAST_SOLUTION);
-  if (polish_on && as_warm_on && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || as_can_defect || as_prev_is_base)) {
+  // (state rows: a warm start that did not settle — hundreds of rows changing at once, see kernels_xbox.hip — would not settle for the
+  //  next, similar problem either: the next 1, 2, 4 solves of the shape skip it, by the number of failures in a row)
+  const bool xb_backoff = xbox_as && w.xb_warm_backoff > 0;
+  if (xb_backoff) w.xb_warm_backoff--;
+  if (polish_on && as_warm_on && !xb_backoff && !(p->flags & PMPC_COLD_START) && as_prev == as_key && (w.as_U_valid || as_can_defect || as_prev_is_base)) {
     a.Dx = a.wx = nullptr;
     const int r = active_set_solve(w.as_scale, 0, xbox_as ? 14 : 8);
-    if (r == 0) return finish(0);
+    if (r == 0) {
+      w.xb_warm_fails = 0;
+      return finish(0);
+    }
+    if (xbox_as) {
+      w.xb_warm_fails = std::min(w.xb_warm_fails + 1, 3);
+      w.xb_warm_backoff = 1 << (w.xb_warm_fails - 1);
+    }
     if (verbose) printf("pmpc_hip: warm active-set iteration not settled (%d): interior-point path\n", r);
     if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
   }

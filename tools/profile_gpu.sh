@@ -36,3 +36,7 @@ V=1 python3 tools/debug/xbox_check.py > $out/xbox_on.log 2>&1
 PMPC_XBOX_AS=0 V=1 python3 tools/debug/xbox_check.py > $out/xbox_off.log 2>&1
 for f in on off; do echo "state-box rounds $f: solves, interior-point iterations, factorisations"; grep "status " $out/xbox_$f.log | awk '{n++; it+=$6; ss+=$9} END {print n, it, ss}'; done > $out/xbox_summary.txt
 cat $out/xbox_summary.txt
+# r03: config D with a velocity limit that binds (state rows of the active-set rounds; PMPC_XBOX_AS=0 = interior-point iteration, the r02 path)
+for v in 3.0 2.0; do python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --repeats 1 --vmax $v > $out/bench_D_vmax$v.log 2>&1; done
+PMPC_XBOX_AS=0 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --repeats 1 --vmax 3.0 > $out/bench_D_vmax3.0_ipm.log 2>&1
+grep -h '^{' $out/bench_D_vmax3.0.log $out/bench_D_vmax2.0.log $out/bench_D_vmax3.0_ipm.log | cut -c1-160

@@ -83,7 +83,9 @@ for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f
                   ("bench_shard_512.log", f"{tag}_bench_shard_512.json"), ("bench_shard_2048.log", f"{tag}_bench_shard_2048.json"),
                   ("bench_E_soc.log", f"{tag}_bench_E_soc.json"), ("bench_E_soc_fp32.log", f"{tag}_bench_E_soc_fp32.json"),
                   ("bench_D_fp32.log", f"{tag}_bench_D_fp32.json"), ("bench_D_cone.log", f"{tag}_bench_D_cone.json"),
-                  ("bench_B_cone.log", f"{tag}_bench_B_cone.json"), ("bench_B_cone_smooth.log", f"{tag}_bench_B_cone_smooth.json")):
+                  ("bench_B_cone.log", f"{tag}_bench_B_cone.json"), ("bench_B_cone_smooth.log", f"{tag}_bench_B_cone_smooth.json"),
+                  ("bench_D_vmax3.0.log", f"{tag}_bench_D_vmax3.json"), ("bench_D_vmax2.0.log", f"{tag}_bench_D_vmax2.json"),
+                  ("bench_D_vmax3.0_ipm.log", f"{tag}_bench_D_vmax3_ipm.json")):
     if not (src / log).exists():
         continue
     lines = [l for l in open(src / log) if l.startswith("{")]
