@@ -60,7 +60,7 @@ def parse():
                     "iteration) instead of pmpc_scp_loop_device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-generic", action="store_true")
-    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--verbose", nargs="?", const=1, default=0, type=int)
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every launch class, not only the dominant kernel")
     ap.add_argument("--ignore-status", action="store_true", help="timing experiments with deliberately wrong kernels")
     return ap.parse_args()

@@ -1382,6 +1382,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       launch_cone_step(ca, s);
     }
     int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
+    if (verbose > 1 && xbox) depth = 1;  // (the debugging dump below wants every round)
     int n_batches_at_hook = -1000;  // batches waited for since the speculation hook fired (in THIS attempt)
     AsCtl h;
     memset(&h, 0, sizeof(h));
@@ -1463,6 +1464,41 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest violation behind a change %.2e)\n",
                  mode == 4 ? "state rows" : (mode >= 2 ? "cold" : (mode ? "finish" : "warm")), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
       if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
+      if (verbose > 1 && xbox) {  // debugging aid: the state rows after this batch — held rows, largest multiplier, largest |x|, per worst particle
+        HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<double> hz(nx), hX(nx), hU(nu);
+        std::vector<int> hs(nx), hact(nu);
+        HIP_CHECK(hipMemcpy(hz.data(), w.xb_z.p, nx * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hs.data(), w.xb_st.p, nx * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hX.data(), p->X_out, nx * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hU.data(), p->U_out, nu * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hact.data(), w.as_act.p, nu * sizeof(int), hipMemcpyDeviceToHost));
+        int held = 0, uheld = 0, wi = 0;
+        double zmax = 0.0, xmax = 0.0;
+        for (size_t k = 0; k < nx; k++) {
+          held += hs[k] != 0;
+          if (hz[k] > zmax) { zmax = hz[k]; wi = (int)(k / ((size_t)N * x)); }
+          xmax = std::max(xmax, std::fabs(hX[k]));
+        }
+        for (size_t k = 0; k < nu; k++) uheld += hact[k] != 0;
+        printf("   state rows after round %d: %d held, %d controls held, largest multiplier %.3e (particle %d), largest |x| %.3e\n", h.round, held, uheld, zmax, wi, xmax);
+        if (getenv("PMPC_XB_DUMP")) {
+          const int pi = atoi(getenv("PMPC_XB_DUMP"));
+          for (int j = 0; j < N; j++) {
+            printf("     p%d j%2d st", pi, j);
+            for (int r = 0; r < x; r++) printf(" %d", hs[((size_t)pi * N + j) * x + r]);
+            printf(" | act");
+            for (int r = 0; r < u; r++) printf(" %d", hact[((size_t)pi * N + j) * u + r]);
+            printf(" | v");
+            for (int r = 3; r < 6 && r < x; r++) printf(" %+.4f", hX[((size_t)pi * N + j) * x + r]);
+            printf(" | z");
+            for (int r = 3; r < 6 && r < x; r++) printf(" %.3e", hz[((size_t)pi * N + j) * x + r]);
+            printf(" | u");
+            for (int r = 0; r < u; r++) printf(" %+.4f", hU[((size_t)pi * N + j) * u + r]);
+            printf("\n");
+          }
+        }
+      }
       if (verbose > 1 && cone) {  // debugging aid: the active cones' records (small problems only)
         HIP_CHECK(hipStreamSynchronize(s));
         const int q1 = cone_rows;
