@@ -361,7 +361,7 @@ def ipm_solve(p: Problem, allreduce=None, allreduce_min=None, allreduce_max=None
     return X, U, info
 
 
-def active_set_solve(p: Problem, allreduce=None, act0=None, U0=None, max_rounds=25, verbose=False):
+def active_set_solve(p: Problem, allreduce=None, act0=None, U0=None, max_rounds=25, verbose=False, ignore_xb=False):
     """numpy model of the device's primal-dual active-set iteration on the control boxes (solver.hip `active_set_solve`,
     check-pass variant of the generic kernels): per round ONE structured solve from a dynamics-consistent base point whose
     held controls sit ON their bounds, the held controls penalised by `big` on their step (-/+ big du is their multiplier),
@@ -370,7 +370,7 @@ def active_set_solve(p: Problem, allreduce=None, act0=None, U0=None, max_rounds=
     equality-only optimum, set = its violated boxes.  Returns X, U, info(rounds, act)."""
     ar = allreduce or (lambda a: a)
     M, N, u, Nc = p.M, p.N, p.u, p.Nc
-    assert p.has_ub and not p.has_xb
+    assert (p.has_ub or ignore_xb) and (ignore_xb or not p.has_xb)
     lq = StructuredLQ(p, allreduce=ar)
     _, _, lu, uu = _bounds(p)
     if Nc > 0:
@@ -416,3 +416,85 @@ def active_set_solve(p: Problem, allreduce=None, act0=None, U0=None, max_rounds=
         act = np.where(rel, 0, np.where(add_l, 1, np.where(add_u, 2, act)))
         Ufree = np.where(act > 0, Ub, zt)  # (held controls are replaced by their bounds above)
     raise RuntimeError("active set did not settle")
+
+
+def active_set_solve_xb(p: Problem, allreduce=None, max_rounds=30, verbose=False, rho_scale=1e7, act_frac=0.5, tol=1e-9):
+    """numpy model of the STATE ROWS of the device's active-set rounds (pmpc_amd/csrc/kernels_xbox.hip, solver.hip mode 4): the cold
+    start in two phases — control boxes alone (`active_set_solve(ignore_xb=True)`), then rounds in which a binding state box is a
+    row of a semismooth Newton iteration on  s - max(0, s - z) = 0  (s = x - lo or hi - x): held by the penalty rho on the
+    diagonal of the stage's state cost and  +-(rho s_b - z)  in its gradient, multiplier z+ = z - rho s_new afterwards (not in a
+    particle whose sweep clamped a control), status changes with a hysteresis margin, and per round only the violated rows within
+    `act_frac` of the particle's largest violation are newly held.  Accepted when no status (control or state) changed and no held
+    row is further than `tol` off its bound.  Cross-shard reductions: the [Hc | gc] sums inside StructuredLQ and ONE sum of
+    {changes, open rows} per round — what the GPU path all-reduces.  Returns X, U, info(rounds, phase1_rounds, held)."""
+    ar = allreduce or (lambda a: a)
+    M, N, x, u, Nc = p.M, p.N, p.x, p.u, p.Nc
+    assert p.has_xb
+    X, U, info1 = active_set_solve(p, allreduce=ar, ignore_xb=True, verbose=verbose)
+    act = info1["act"]
+    lq = StructuredLQ(p, allreduce=ar)
+    lx, ux, lu, uu = _bounds(p)
+    if Nc > 0:
+        lu[:, :Nc], uu[:, :Nc] = lu[0:1, :Nc], uu[0:1, :Nc]
+    owner = getattr(p, "owns_consensus", True)
+    big, tol_p, tol_l = 1e30, 1e-13, 1e-11
+    rho = rho_scale * (np.abs(np.einsum("mjrr->mjr", p.Q)).reshape(M, -1).max(1) + p.reg_x)[:, None, None]  # per particle
+    st, z = np.zeros((M, N, x), int), np.zeros((M, N, x))
+
+    def classify(Xb, st, zn, finish):
+        sl, sh = Xb - lx, ux - Xb
+        mg = (10.0 * tol_l + 1e-13 * np.maximum(1.0, np.abs(Xb))) if finish else 0.0
+        wl, wh = sl - np.where(st == 1, zn, 0.0), sh - np.where(st == 2, zn, 0.0)
+        nst = np.where(wl < np.where(st == 1, mg, -mg), 1, np.where(wh < np.where(st == 2, mg, -mg), 2, 0))
+        viol = np.maximum(-sl, -sh)
+        vmax = np.where(st == 0, viol, 0.0).reshape(M, -1).max(1)[:, None, None]
+        deferred = (st == 0) & (nst != 0) & (viol < act_frac * vmax)
+        nst = np.where(deferred, 0, nst)
+        zo = np.where((nst != 0) & (nst == st), zn, 0.0)
+        return nst, zo, deferred
+
+    def newton(Xb, Ub, Du, st, z):
+        gx, gu, gc0 = p.gradient(Xb, Ub)
+        sl, sh = Xb - lx, ux - Xb
+        Dx = np.where(st != 0, rho, 0.0)
+        gx = gx + np.where(st == 1, rho * sl - z, 0.0) - np.where(st == 2, rho * sh - z, 0.0)
+        gce = np.zeros(Nc * u)
+        Dc = None
+        if Nc > 0:
+            gce[:u] = ar(gc0.sum(0))
+            Dc = ar(Du[0, :Nc].reshape(-1) if owner else np.zeros(Nc * u))
+        lq.factor(Dx, Du, Dc)
+        return lq.solve(gx, gu, gce if Nc > 0 else None)
+
+    Ub, Xb = U, X  # the first phase's optimum: controls on their bounds where held, states rolled out
+    st, z, _ = classify(Xb, st, z, False)
+    for r in range(max_rounds):
+        dX, dU = newton(Xb, Ub, np.where(act > 0, big, 0.0), st, z)
+        lam = np.where(act == 1, -big * dU, big * dU)
+        zt = Ub + dU
+        rel = (act > 0) & (lam < -tol_l)
+        add_l = (act == 0) & (zt < lu - tol_p * np.maximum(1.0, np.abs(lu)))
+        add_u = (act == 0) & (zt > uu + tol_p * np.maximum(1.0, np.abs(uu)))
+        act = np.where(rel, 0, np.where(add_l, 1, np.where(add_u, 2, act)))
+        Ub = np.where(act == 1, lu, np.where(act == 2, uu, np.clip(zt, lu, uu)))
+        if Nc > 0:  # (the shared controls' clamping is decided on the summed system: identical on every shard)
+            Ub[:, :Nc] = Ub[0:1, :Nc]
+        Xb = p.rollout(Ub)  # the forward sweep's states are those of the clamped controls
+        clamped = (add_l | add_u).reshape(M, -1).any(1)[:, None, None]
+        sl, sh = Xb - lx, ux - Xb
+        zn = np.where(clamped, z, np.where(st == 1, z - rho * sl, np.where(st == 2, z - rho * sh, 0.0)))
+        zn = np.where(st == 0, 0.0, zn)
+        nst, zo, deferred = classify(Xb, st, zn, True)
+        sv, bd = np.where(nst == 1, sl, sh), np.where(nst == 1, lx, ux)
+        still = (nst == st) & (nst != 0)
+        with np.errstate(invalid="ignore"):
+            open_rows = still & ((np.abs(sv) > tol * np.maximum(1.0, np.abs(bd))) | (np.abs(zo - z) > 1e-6 * np.maximum(1.0, np.abs(zo))))
+        n_ctl = float(rel.sum() + add_l.sum() + add_u.sum())
+        n_row = float(((nst != st) | deferred).sum())
+        tot = ar(np.array([n_ctl + n_row, float(open_rows.sum())]))
+        st, z = nst, zo
+        if verbose:
+            print(f"state rows round {r + 1}: {int(n_ctl)} control changes, {int(n_row)} row changes, {int(open_rows.sum())} open")
+        if tot[0] == 0 and tot[1] == 0:
+            return Xb, Ub, dict(rounds=r + 1, phase1_rounds=info1["rounds"], held=int((st != 0).sum()))
+    raise RuntimeError("state rows did not settle")
