@@ -688,8 +688,8 @@ static bool slew_increment_form_applies(const pmpc_ctx *c, const pmpc_problem *p
   if (p->N < 2) return false;  // N = 1: the reference's diagonal rule is not the plain penalty (lqp_utils.jl:31-39)
   // With boxes the control boxes become STATE boxes of the restated problem.  Until r03 those met the interior-point iteration only
   // (1.8x - 2.6x slower cold and ~10x slower warm than the generic kernels' active-set rounds), so boxed slew problems stayed on the
-  // generic kernels; with the state-box rounds of kernels_xbox.hip the restated form is 2.1x - 5.4x FASTER than the generic kernels,
-  // cold and warm, and agrees with them to 1e-15 (tools/debug/slew_paths.py).  It needs the XBOX instantiation of the
+  // generic kernels; with the state-box rounds of kernels_xbox.hip the restated form is 1.9x - 4.4x FASTER than the generic kernels cold, 1.5x - 2x warm,
+  // and agrees with them to 1e-15 (tools/debug/slew_paths.py, profiles/r03_d_slew_paths.txt, CHANGELOG.md 3.3).  It needs the XBOX instantiation of the
   // factor sweep for (x + u, u); the options slew_increment_boxes = 0 / xbox_as = 0 put boxed slew problems back on the generic kernels.
   const bool with_boxes = c->opt[OPT_SLEW_INCREMENT_BOXES] != 0.0 && c->opt[OPT_XBOX_AS] != 0.0;
   if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && !(with_boxes && xbox_as_dims_supported((int)(p->xdim + p->udim), (int)p->udim))) return false;
@@ -1735,8 +1735,10 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       // with state boxes, in two phases: the control boxes alone first (the primal-dual active-set rule is at home there, whatever
       // the start), then the state rows from that optimum — which violates about the rows that bind, where the equality-only optimum
       // clipped into its control boxes violates many more (a start the state rows' Newton iteration does not recover from)
-      int q = active_set_solve(1.0, 2, cold_as_rounds, xbox_as ? 0 : 1);
-      if (q == 0 && xbox_as) {
+      // (no control boxes — e.g. a boxed slew problem in increment form —: the first phase would be the equality-only optimum again)
+      const bool two_phase = xbox_as && has_ub;
+      int q = active_set_solve(1.0, 2, (xbox_as && !two_phase) ? std::max(cold_as_rounds, 14) : cold_as_rounds, two_phase ? 0 : 1);
+      if (q == 0 && two_phase) {
         q = active_set_fast(1.0, 4, 14, 2);
         if (q != 0) outputs_written = false;  // (the first phase's point is not the answer)
       }
