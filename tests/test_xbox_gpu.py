@@ -101,3 +101,52 @@ def test_state_box_rounds_can_be_switched_off_per_context(oracle):
     assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL
     off.close()
     on.close()
+
+
+def test_library_scp_loop_with_a_binding_velocity_limit():
+    """What `bench.py --vmax` times: the quadrotor SCP loop with |v| <= 2.5 m/s inside the library (pmpc_scp_loop_device: warm starts
+    from the previous iteration's set and multipliers, the first round carries the linearisation point's dynamics defect, follow-up
+    work speculated behind the first batch of rounds — and redone when a second phase follows).  The same iterates as a
+    Python-driven loop of single calls, every iterate inside the limit, the limit touched."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, DeviceSolver, to_device_problem
+
+    M, N, Nc, vmax, steps = 32, 30, 1, 2.5, 6
+    prob = dyn.make_quadrotor_problem(M=M, N=N, Nc=Nc)
+    d = to_device_problem(prob)
+    lx = torch.full((M, N, 12), -float("inf"), dtype=torch.float64, device="cuda")
+    lx[..., 3:6] = -vmax
+    common = dict(Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"], lu=d["lu"],
+                  uu=d["uu"], lx=lx, ux=-lx, symmetric_cost=True)
+    s1, s2 = DeviceSolver(0), DeviceSolver(0)
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    res_py, rounds = [], 0
+    for it in range(steps):
+        f, fx, fu = s1.linearize(MODEL_QUADROTOR, d["x0"], Xa, Ua, d["params"])
+        _, _, st = s1.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, static_cons_bounds=True, prev_is_last_solution=it > 0,
+                                cold_start=it == 0, **common)
+        assert st == 0 and s1.last_info["fast_path"] == 1
+        rounds += s1.last_info["active_set_rounds"]
+        res_py.append(float(s1.scp_residual(Xb, Xa, Ub, Ua)[0].item()))
+        Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+        v = Xa[..., 3:6].abs().max().item()
+        assert v <= vmax + 1e-8, (it, v)
+    X_py, U_py = Xa.clone(), Ua.clone()
+    assert rounds > 0 and (X_py[..., 3:6].abs() > vmax - 1e-9).sum().item() > 0  # (the limit binds)
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device="cuda")
+    bufs = [mk(M, N, 12), mk(M, N, 12, 12), mk(M, N, 4, 12), mk(M, N, 12), mk(M, N, 12, 12), mk(M, N, 4, 12)]
+    res, infos, last_in_out, done = s2.scp_loop(MODEL_QUADROTOR, d["params"], steps, f=bufs[0], fx=bufs[1], fu=bufs[2], f2=bufs[3], fx2=bufs[4],
+                                                fu2=bufs[5], X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, first_cold=True, **common)
+    s2.sync()
+    assert done == steps and all(i["status"] == 0 for i in infos)
+    X_lib, U_lib = (Xb, Ub) if last_in_out else (Xa, Ua)
+    rel = lambda a, b: (a - b).norm().item() / max(b.norm().item(), 1.0)
+    assert rel(X_lib, X_py) <= 1e-9 and rel(U_lib, U_py) <= 1e-9, (rel(X_lib, X_py), rel(U_lib, U_py))
+    np.testing.assert_allclose(res.cpu().numpy(), np.array(res_py), rtol=1e-7, atol=1e-12)
+    s1.close()
+    s2.close()
