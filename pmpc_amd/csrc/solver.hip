@@ -1848,11 +1848,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
       } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) {
         status = 0;
-        // converged on its own (every finish attempt on the way failed, or none was due): with state rows one more attempt from the
+        // converged on its own (every finish attempt on the way failed, or none was due): one more attempt from the
         // converged iterate — it names the set as sharply as it ever will; a settled attempt takes the answer from ~1e-7 to round-off and
         // leaves the set and multipliers for the next solve's warm start; a failed one changes nothing (the rounds work in the outputs)
-        if (polish_on && xbox_as) {
-          const int r = active_set_solve(std::max(1.0, mu_peak), 1, 10);
+        if (polish_on && !(has_xb && !xbox_as && w.xb_block_key == as_key)) {
+          const int r = active_set_solve(std::max(1.0, mu_peak), 1, xbox_as ? 10 : 6);
           if (r == 0) inf.mu = 0.0;
           else if (r == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
         }
