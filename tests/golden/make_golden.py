@@ -240,5 +240,10 @@ if __name__ == "__main__":
     args, kw = random_spd(np.random.default_rng(2021))
     save("qp_random_spd_ubox.npz", **solve_and_pack(args, kw, -1))
     save("qp_random_spd.npz", **solve_and_pack(args, dict(reg_x=0.0, reg_u=0.0), -1))
+    # state boxes that BIND (no reference test or notebook uses binding state boxes: pinned by the oracle's KKT certificate only)
+    from tests.support.problems import xbox_problem
+
+    args, kw = xbox_problem(np.random.default_rng(2022), orc, 5, 9, 4, 2, 1, 0.4, pull=0.9, margin=0.02)
+    save("qp_xbox_binding.npz", **solve_and_pack(args, kw, 1))
     save("scp_unicycle_simple.npz", **scp_reference_run(25, None, None, 40))
     save("scp_unicycle_remote.npz", **scp_reference_run(30, 1.0, 1.0, 40))
