@@ -199,6 +199,7 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *   as_fuse_ctl PMPC_AS_FUSE_CTL 1, as_wave_cons PMPC_AS_WAVE_CONS 1   launch fusions of the rounds (measurement legs)
  *   host_reuse PMPC_HOST_REUSE 1       host ABI: unchanged 8 MB chunks are not uploaded again
  *   warn_slow_path PMPC_WARN_SLOW_PATH 1   one line on stderr when a context first leaves the register-resident path
+ *   cone_rank_memory PMPC_CONE_RANK_MEMORY 1   cone objective: the weight assignment the previous solve of the shape settled on is tried first
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);

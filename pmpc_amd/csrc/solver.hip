@@ -185,7 +185,7 @@ struct ProfCat {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_COUNT
 };
 static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COUNT] = {
     {"as_warm", "PMPC_AS_WARM", 1},                // warm start of the active-set rounds from the previous solve's set
@@ -202,11 +202,14 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"as_wave_cons", "PMPC_AS_WAVE_CONS", 1},      // consensus system solved by every wave of the forward sweep
     {"host_reuse", "PMPC_HOST_REUSE", 1},          // host ABI: unchanged 8 MB chunks are not uploaded again
     {"warn_slow_path", "PMPC_WARN_SLOW_PATH", 1},  // one line on stderr when a context first leaves the register-resident path
+    {"cone_rank_memory", "PMPC_CONE_RANK_MEMORY", 1},  // cone objective: the weight assignment the previous solve of the shape settled on is tried first
 };
 
 struct pmpc_ctx {
   double opt[OPT_COUNT];
   bool warned_slow_path = false;
+  std::vector<double> cone_rw;  // cone objective: the weight assignment (by cost rank) the last solve settled on, and what it belongs to
+  long long cone_rw_key = -1;
   int xb_ctrl_from = -1;  // set around the inner solve of the slew increment form: state entries from this index on are the controls (their boxes the control boxes)
   AsCtlCall as_pend{};  // round control of the previous active-set round, to ride in the next consensus-partials launch (structured_solve)
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
@@ -404,6 +407,9 @@ int fail_after_error(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info) {
   Workspace &w = c->ws;
   w.as_key = w.warm_key = w.soc_key = w.cons_key = w.xb_block_key = w.su_key = -1;
   w.as_U_valid = false;
+  w.xb_warm_backoff = w.xb_warm_fails = 0;
+  c->cone_rw_key = -1;
+  c->xb_ctrl_from = -1;
   c->as_pend.ctl = nullptr;
   c->staged.clear();
   (void)hipGetLastError();
@@ -472,7 +478,7 @@ int pmpc_set_option(pmpc_ctx *c, const char *key, double value) {
   for (int k = 0; k < OPT_COUNT; k++)
     if (!strcmp(key, kPmpcOptions[k].key)) {
       c->opt[k] = value;
-      c->ws.as_key = c->ws.warm_key = -1;  // (a remembered set / iterate was found under the old switches)
+      c->ws.as_key = c->ws.warm_key = c->cone_rw_key = -1;  // (a remembered set / iterate / weight assignment was found under the old switches)
       return 0;
     }
   return -1;
@@ -2134,13 +2140,24 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
     rw[0] = 1.0 - eps;
     return finish(solve_with(rw));
   }
-  int st = solve_with(rw);  // uniform weights: the QP optimum ranks the particles
-  if (st != 0) return finish(st);
-  // fixed-point iteration on the WEIGHT assignment the ranking implies (the order inside the floor-weight group is irrelevant)
+  // Inside an SCP loop the ranking of the particle costs rarely changes between iterations: the assignment the previous solve of this
+  // shape settled on is tried FIRST — if the ranking at its optimum reproduces it, that is the fixed point (the same consistency test
+  // as below: weights = multipliers of the epigraph rows, KKT of the reference's problem) after ONE weighted QP instead of two.
+  const long long rwkey = ((((((long long)M * 1000003 + (long long)p->N) * 131 + (long long)p->xdim) * 131 + (long long)p->udim) * 131 + p->Nc + 2) * 1000003 + (long long)kk) * 64 + c->world;
+  int st = 0;
   std::vector<size_t> low;
   std::vector<double> rw1(M), rw2(M), rw_prev;
-  cheapest(low);
-  rank_weights(low, rw1);
+  if (c->opt[OPT_CONE_RANK_MEMORY] != 0.0 && !(p->flags & PMPC_COLD_START) && c->cone_rw_key == rwkey && c->cone_rw.size() == M) {
+    rw1 = c->cone_rw;
+    low.assign(1, 0);  // (only its last entry is read before the first ranking, for the verbose line)
+  } else {
+    st = solve_with(rw);  // uniform weights: the QP optimum ranks the particles
+    if (st != 0) return finish(st);
+    cheapest(low);
+    rank_weights(low, rw1);
+  }
+  c->cone_rw_key = -1;
+  // fixed-point iteration on the WEIGHT assignment the ranking implies (the order inside the floor-weight group is irrelevant)
   bool settled = false;
   for (int it = 0; it < 12 && !settled; it++) {
     rw = rw1;
@@ -2150,7 +2167,12 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
     cheapest(low);
     rank_weights(low, rw2);
     if (verbose) printf("pmpc_hip: cone outer %d  threshold particle %zu -> %zu  J_thr %.9e\n", it + 1, thr_old, low.back(), J[low.back()]);
-    if (rw2 == rw1) { settled = true; break; }
+    if (rw2 == rw1) {
+      settled = true;
+      c->cone_rw = rw1;  // (a kink's interpolated weights are not remembered: they are no assignment by rank)
+      c->cone_rw_key = rwkey;
+      break;
+    }
     if (!rw_prev.empty() && rw2 == rw_prev) {
       // 2-cycle between two rankings: the optimum sits on a kink J_a = J_b between the particles a, b whose weights differ
       // most between the two assignments; on the segment rw(theta) = theta rw1 + (1 - theta) rw2 the gap J_a - J_b is

@@ -245,3 +245,43 @@ def test_host_loop_takes_the_stage_cone_as_an_extra_cstrs_tuple(oracle):
                                 np.zeros((0, 0, 0)), kw["u_l"], kw["u_u"], solver_settings=dict(solver="osqp", Nc=Nc, extra_cstrs=[cstr],
                                                                                               soc_u_interior=np.zeros(3)))
     assert _rel(X[:, 1:], Xo) < TOL and _rel(U, Uo) < TOL, (_rel(X[:, 1:], Xo), _rel(U, Uo))
+
+
+def test_the_settled_weight_assignment_starts_the_next_cone_solve(oracle):
+    """Option cone_rank_memory (default on): the assignment of weights by cost rank that the previous solve of a shape settled on
+    is tried first — accepted after ONE weighted QP when the ranking at its optimum reproduces it (the same consistency test, i.e.
+    the KKT conditions of the reference's epigraph problem, PMPC.jl/src/main.jl:204-227), otherwise the iteration goes on from
+    there.  Same answers as a context without the memory, on a sequence of related problems, and the oracle's."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    M, N, x, u, Nc = 40, 8, 4, 2, 1
+    rng = np.random.default_rng(321)
+    args, kw = rand_problem(rng, M, N, x, u, 0.5)
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    mem, plain = DeviceSolver(0), DeviceSolver(0)
+    plain.set_option("cone_rank_memory", 0)
+    outer = []
+    for t in range(4):
+        if t:
+            x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+            args = (x0, f + (0.5 if t == 3 else 0.01) * rng.standard_normal(f.shape), fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref)  # t = 3: the ranking changes
+        x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+        Xo, Uo = oracle.lcone_solve_py(*args, Nc=Nc, **kw)
+        opt = dict(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref), U_ref=dev(U_ref),
+                   reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]), symmetric_cost=True)
+        res = []
+        for s in (mem, plain):
+            X, U, status = s.lcone_solve(**opt)
+            s.sync()
+            assert status == 0
+            assert _rel(X.cpu().numpy(), Xo) < TOL and _rel(U.cpu().numpy(), Uo) < TOL, (t, s is mem)
+            res.append((X.clone(), U.clone(), s.last_info["outer_solves"]))
+        assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-9 and (res[0][1] - res[1][1]).abs().max().item() <= 1e-9
+        outer.append((res[0][2], res[1][2]))
+    assert outer[0][0] == outer[0][1] >= 2  # nothing remembered yet
+    assert outer[1][0] == 1 and outer[2][0] == 1 and outer[1][1] >= 2  # the remembered assignment is consistent: one weighted QP
+    mem.close()
+    plain.close()
