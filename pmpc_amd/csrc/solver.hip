@@ -155,6 +155,7 @@ struct Workspace {
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
   DevBuf warmU, warm_llu, warm_luu, warm_llx, warm_lux;
   long long warm_key = -1;
+  double warm_mu = 0.0;  // barrier parameter the remembered iterate belongs to (0: the early iterate of a hard-constrained solve)
   DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta, as_viol;  // active-set iteration: status per bounded control (int), counters,
                                                                  // per-particle counters, settled flags, control block, applied consensus step
   long long su_key = -1;  // shape / source arrays the working copy of the control boxes (w.su.lo, w.su.hi) was made for
@@ -1730,7 +1731,9 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // is done later if the warm attempt is rejected or fails
   const bool warm_disabled = c->opt[OPT_WARM_START] == 0.0;
   const long long key = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
-  const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && mu_target == 0.0 && (has_xb || has_ub) && w.warm_key == key;
+  // (barrier mode, r03: the previous solve's FINAL iterate — centred at the same mu for a nearby problem — is the start: a few Newton
+  //  iterations instead of ~10 from the clipped equality-only optimum)
+  const bool try_warm = !warm_disabled && !(p->flags & PMPC_COLD_START) && (has_xb || has_ub) && w.warm_key == key && w.warm_mu == mu_target;
   if (!try_warm) {
     const int r = equality_phase();
     if (r != 1) return finish(r);
@@ -1832,7 +1835,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
                h.nu, h.alpha, h.sigma, h.dev_max);
       inf.mu = h.mu; inf.slack_res = h.res_max; inf.ipm_iters = it - 1;
       if (*c->fail_host || !(h.mu == h.mu)) { status = 2; break; }
-      if (!remembered && !warm_disabled && mu_target == 0.0 && it > 1 && h.mu <= 0.5) {
+      const bool barrier_done = mu_target > 0.0 && h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8;
+      if (!warm_disabled && ((!remembered && mu_target == 0.0 && it > 1 && h.mu <= 0.5) || barrier_done)) {
         // (the step that produced this iterate is already applied: the pass behind the last exchange is in flight)
         w.warmU.ensure(nu * D8);
         HIP_CHECK(hipMemcpyAsync(w.warmU.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
@@ -1847,11 +1851,12 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           HIP_CHECK(hipMemcpyAsync(w.warm_lux.p, sx.lu, nx * D8, hipMemcpyDeviceToDevice, s));
         }
         w.warm_key = key;
+        w.warm_mu = mu_target;
         remembered = true;
       }
       if (h.mu > mu_peak) mu_peak = h.mu;
       if (mu_target > 0.0) {  // centred AT mu_target: every complementarity product equals it
-        if (h.dev_max <= 1e-9 * mu_target && h.res_max <= 1e-10 && h.nu <= 1e-8) { status = 0; break; }
+        if (barrier_done) { status = 0; break; }
       } else if (h.mu <= tol * mu_peak && h.res_max <= 1e-10 && h.nu <= 1e-8) {
         status = 0;
         // converged on its own (every finish attempt on the way failed, or none was due): one more attempt from the
