@@ -2206,10 +2206,14 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, p
       // cheaper than it, every full-weight particle costlier (KKT of the epigraph problem, multipliers lambda_i = w_i)
       const double jk = 0.5 * (J[a_] + J[b_]), tolj = 1e-9 * std::max(1.0, std::fabs(jk));
       settled = std::fabs(J[a_] - J[b_]) <= 1e-8 * std::max(1.0, std::fabs(jk));
-      for (size_t i = 0; i < M && settled; i++) {
+      for (size_t i = 0; i < M && (settled || verbose); i++) {
         if (i == a_ || i == b_) continue;
-        if (rw[i] >= w_hi && J[i] < jk - tolj) settled = false;  // a full-weight particle dips below the threshold cost
-        if (rw[i] < w_hi && J[i] > jk + tolj) settled = false;   // a down-weighted particle rises above it
+        const bool dips = rw[i] >= w_hi && J[i] < jk - tolj;  // a full-weight particle dips below the threshold cost
+        const bool rises = rw[i] < w_hi && J[i] > jk + tolj;  // a down-weighted particle rises above it
+        if (dips || rises) {
+          settled = false;
+          if (verbose) printf("pmpc_hip: cone kink: particle %zu (weight %.3e) is on the wrong side of the threshold cost by %.3e (J_thr %.9e)\n", i, rw[i], J[i] - jk, jk);
+        }
       }
       break;
     }
