@@ -447,3 +447,27 @@ def test_a_context_says_once_when_it_leaves_the_register_resident_path(capfd):
     quiet.sync()
     assert "generic kernels" not in capfd.readouterr().err
     quiet.close()
+
+
+def test_every_documented_option_exists_with_its_documented_default():
+    """include/pmpc_abi.h lists the per-context options (key, environment variable, default): each is known to pmpc_get_option and
+    starts at that default (the variables are not set in the test environment), and can be set and read back."""
+    import os
+    import re
+    from pathlib import Path
+
+    from pmpc_amd.device import DeviceSolver
+
+    header = (Path(__file__).resolve().parents[1] / "include" / "pmpc_abi.h").read_text()
+    rows = re.findall(r"^ \*   (\w+) (PMPC_\w+) ([0-9.e+-]+)", header, flags=re.M)
+    rows += re.findall(r", (\w+) (PMPC_\w+) ([0-9.e+-]+)", header)
+    keys = {k: (env, float(d)) for k, env, d in rows}
+    assert {"as_warm", "xbox_as", "cone_as", "polish_mu", "as_cold_rounds", "cone_rank_memory", "as_wave_cons", "warn_slow_path"} <= set(keys), keys
+    s = DeviceSolver(0)
+    for k, (env, dflt) in keys.items():
+        if env in os.environ:
+            continue
+        assert s.get_option(k) == dflt, (k, s.get_option(k), dflt)
+        s.set_option(k, dflt + 1.0)
+        assert s.get_option(k) == dflt + 1.0
+    s.close()
