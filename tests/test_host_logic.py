@@ -426,3 +426,48 @@ def test_general_conic_oracle_agrees_with_the_stage_cone_oracle(oracle):
                                   z0=np.tile(u_int, ncu // u))
     assert np.abs(X - Xo).max() < 1e-9 and np.abs(U - Uo).max() < 1e-9
 
+
+
+def test_cone_rounds_model_matches_the_cone_oracle_over_an_scp_sequence(oracle):
+    """The METHOD of pmpc_amd/csrc/kernels_cone.hip restated in numpy (tools/proto/cone_ssn.py: semismooth Newton on the natural map
+    of each stage cone — interior / apex / boundary branch of the projection's generalised Jacobian —, boxes by the primal-dual
+    active-set rule, one structured Newton solve per round) on the quadrotor with config E's thrust cones: three SCP iterations,
+    cold start then warm starts from the previous branches and multipliers, each against the sparse cone oracle.  (CPU check of the
+    algorithm; the HIP path itself is tests/test_cone_gpu.py and tests/test_configs_gpu.py.)"""
+    import importlib.util
+    from pathlib import Path
+
+    from pmpc_amd import dynamics as dyn
+    from tests.support.structured_np import Problem
+
+    spec = importlib.util.spec_from_file_location("cone_ssn", Path(__file__).resolve().parents[1] / "tools" / "proto" / "cone_ssn.py")
+    ssn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ssn)
+    M, N, Nc = 4, 20, 1
+    prob = dyn.make_quadrotor_problem(M=M, N=N, Nc=Nc)
+    W = np.zeros((2, 4))
+    W[0, 1] = W[1, 2] = 1.0
+    v, v0, w0 = np.array([0.3, 0, 0, 0.0]), 0.0, np.zeros(2)
+    Xp, Up, state, rounds = prob["X_prev"].copy(), prob["U_prev"].copy(), None, []
+    for it in range(3):
+        X_ = np.concatenate([prob["x0"][:, None, :], Xp[:, :-1]], 1)
+        f, fx, fu = prob["f_fx_fu_fn"](X_, Up)
+        p = Problem(f, fx, fu, Xp, Up, prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], prob["reg_x"], prob["reg_u"], Nc=Nc, u_l=prob["u_l"],
+                    u_u=prob["u_u"])
+        cas = ssn.ConeAS(p, W, w0, v, v0)
+        if state is None:
+            U0 = np.tile(np.array([9.81, 0, 0, 0.0]), (M, N, 1))
+            act0, apex0, z0 = ssn.initial_from_solution(cas, U0)
+        else:
+            U0, z0, act0, apex0 = state
+        U, z, act, apex, r, ok = cas.solve(U0, z0, act0, apex0)
+        assert ok
+        X = p.rollout(U)
+        Xo, Uo = oracle.lsoc_solve_py(prob["x0"], f, fx, fu, Xp, Up, prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], reg_x=prob["reg_x"],
+                                      reg_u=prob["reg_u"], Nc=Nc, u_l=prob["u_l"], u_u=prob["u_u"], soc_W=W, soc_w0=w0, soc_v=v, soc_v0=v0,
+                                      u_interior=np.array([9.81, 0, 0, 0.0]))
+        assert np.linalg.norm(X - Xo) / np.linalg.norm(Xo) < 1e-8 and np.linalg.norm(U - Uo) / np.linalg.norm(Uo) < 1e-8, it
+        assert np.max(np.linalg.norm(U[..., 1:3], axis=-1) - 0.3 * U[..., 0]) < 1e-9  # inside every thrust cone
+        rounds.append(r)
+        state, Xp, Up = (U, z, act, apex), X, U
+    assert max(rounds) <= 12, rounds
