@@ -653,23 +653,29 @@ int pmpc_linearize_device(pmpc_ctx *c, int model, size_t N, size_t M, const doub
 // -------------------------------------------------------------------------------------------------
 static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc);
 constexpr int PMPC_NEEDS_F64 = -7;  // solve_impl_body on an fp32-storage problem: this solve needs a path that runs the fp64 kernels
+// fp32-storage problem -> the same problem with fx, fu, Q, R widened (exactly) into workspace copies, flag cleared
+static pmpc_problem widened_f32_problem(pmpc_ctx *c, const pmpc_problem *p, bool jacobians = true) {
+  Workspace &w = c->ws;
+  const long long rows = (long long)p->M * (long long)p->N, x = (long long)p->xdim, u = (long long)p->udim;
+  const long long cnt[4] = {rows * x * x, rows * x * u, rows * x * x, rows * u * u};
+  const double *src[4] = {p->fx, p->fu, p->Q, p->R};
+  for (int k = jacobians ? 0 : 2; k < 4; k++) {
+    w.m64[k].ensure((size_t)cnt[k] * sizeof(double));
+    launch_widen_f32((const float *)src[k], w.m64[k].d(), cnt[k], c->stream);
+  }
+  pmpc_problem q = *p;
+  q.flags &= ~(unsigned)PMPC_F32_MATRICES;
+  if (jacobians) { q.fx = w.m64[0].d(); q.fu = w.m64[1].d(); }
+  q.Q = w.m64[2].d(); q.R = w.m64[3].d();
+  return q;
+}
 static int solve_impl(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose, bool soc) {
   try {
     int st = solve_impl_body(c, p, info, verbose, soc);
     if (st == PMPC_NEEDS_F64) {
       // fp32-storage mode outside the warm-started active-set rounds (first solve of a loop, fallbacks, other dims / consensus
       // horizons): widen fx, fu, Q, R into workspace copies — exact — and run the ordinary solve on them
-      Workspace &w = c->ws;
-      const long long rows = (long long)p->M * (long long)p->N, x = (long long)p->xdim, u = (long long)p->udim;
-      const long long cnt[4] = {rows * x * x, rows * x * u, rows * x * x, rows * u * u};
-      const double *src[4] = {p->fx, p->fu, p->Q, p->R};
-      for (int k = 0; k < 4; k++) {
-        w.m64[k].ensure((size_t)cnt[k] * sizeof(double));
-        launch_widen_f32((const float *)src[k], w.m64[k].d(), cnt[k], c->stream);
-      }
-      pmpc_problem q = *p;
-      q.flags &= ~(unsigned)PMPC_F32_MATRICES;
-      q.fx = w.m64[0].d(); q.fu = w.m64[1].d(); q.Q = w.m64[2].d(); q.R = w.m64[3].d();
+      const pmpc_problem q = widened_f32_problem(c, p);
       if (verbose) printf("pmpc_hip: fp32-storage problem: widened for the fp64 kernels\n");
       st = solve_impl_body(c, &q, info, verbose, soc);
     }
@@ -2013,9 +2019,17 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
 // -------------------------------------------------------------------------------------------------
 // cone path (c_lcone_solve): the epsilon-anchored epigraph objective as a sequence of weighted QPs
 // -------------------------------------------------------------------------------------------------
-int pmpc_particle_costs_device(pmpc_ctx *c, const pmpc_problem *p, const double *X, const double *U, double *J_out) {
+int pmpc_particle_costs_device(pmpc_ctx *c, const pmpc_problem *p0, const double *X, const double *U, double *J_out) {
   HIP_CHECK(hipSetDevice(c->device));
   Workspace &w = c->ws;
+  // (the cost kernel reads Q, R as doubles: an fp32-storage problem's blocks are widened first — found by `bench.py --cone --fp32`,
+  //  which read the float arrays as doubles, past their end)
+  pmpc_problem pw_;
+  const pmpc_problem *p = p0;
+  if (p0->flags & PMPC_F32_MATRICES) {
+    pw_ = widened_f32_problem(c, p0, /*jacobians=*/false);
+    p = &pw_;
+  }
   const size_t M = p->M, u = p->udim, D8 = sizeof(double);
   LQArgs a;
   memset(&a, 0, sizeof(a));
@@ -2044,10 +2058,17 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
     return fail_after_error(c, p, info);
   }
 }
-static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose) {
+static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, pmpc_info *info, int verbose) {
   HIP_CHECK(hipSetDevice(c->device));
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
+  // (an fp32-storage problem runs the cone objective on widened copies: its weighted QPs and the particle costs read doubles)
+  pmpc_problem pwide;
+  const pmpc_problem *p = p0;
+  if (p0->flags & PMPC_F32_MATRICES) {
+    pwide = widened_f32_problem(c, p0);
+    p = &pwide;
+  }
   // particles are sharded in equal contiguous blocks (bench.py's layout): the ranking of the particle costs is global, so
   // every rank gathers all costs (all-reduce(sum) of a zero-padded vector) and takes the same decisions
   const size_t Ml = p->M, M = Ml * (size_t)c->world, off = (size_t)c->rank * Ml, D8 = sizeof(double);

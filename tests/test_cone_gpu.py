@@ -285,3 +285,33 @@ def test_the_settled_weight_assignment_starts_the_next_cone_solve(oracle):
     assert outer[1][0] == 1 and outer[2][0] == 1 and outer[1][1] >= 2  # the remembered assignment is consistent: one weighted QP
     mem.close()
     plain.close()
+
+
+def test_cone_objective_and_particle_costs_on_fp32_stored_matrices(oracle):
+    """PMPC_F32_MATRICES meets the cone path: the weighted QPs and the particle-cost kernel read doubles, so the float blocks are
+    widened first (`bench.py --cone --fp32` once read them as doubles, past their end).  Same answer as the fp64 call to the storage
+    rounding, costs included."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    M, N, x, u, Nc = 12, 8, 4, 2, 1
+    args, kw = rand_problem(np.random.default_rng(77), M, N, x, u, 0.5)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda")
+    T = lambda a, dt=torch.float64: dev(np.swapaxes(a, -1, -2), dt)
+    s = DeviceSolver(0)
+    out = {}
+    for name, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        opt = dict(f=dev(f), fx=T(fx, dt), fu=T(fu, dt), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q, dt), R=T(R, dt), X_ref=dev(X_ref),
+                   U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]), symmetric_cost=True)
+        X, U, status = s.lcone_solve(cold_start=True, **opt)
+        s.sync()
+        assert status == 0
+        J = s.particle_costs(X, U, **opt)
+        out[name] = (X.cpu().numpy(), U.cpu().numpy(), J.cpu().numpy())
+    Xo, Uo = oracle.lcone_solve_py(*args, Nc=Nc, **kw)
+    assert _rel(out["f64"][0], Xo) < TOL and _rel(out["f64"][1], Uo) < TOL
+    assert _rel(out["f32"][0], Xo) < 1e-5 and _rel(out["f32"][1], Uo) < 1e-5  # (storage rounding of fx, fu, Q, R: 6e-8 relative each)
+    assert np.allclose(out["f32"][2], out["f64"][2], rtol=1e-5)
+    s.close()
