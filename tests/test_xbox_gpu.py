@@ -26,6 +26,14 @@ XBOX_CASES = [
     (4, 8, 8, 4, 3, None, 0.5),     # many rows bind: the rounds may hand over to the interior-point iteration and finish it
     (8, 10, 6, 2, 1, 0.3, 0.45),
     (33, 7, 9, 3, 1, 0.5, 0.8),
+    # edge cases: single-stage and two-stage horizons, one particle, full consensus, many particles
+    (4, 1, 4, 2, 0, 0.4, 0.8),
+    (4, 1, 4, 2, 1, 0.4, 0.8),
+    (1, 1, 2, 1, 0, None, 0.8),
+    (3, 2, 12, 4, 1, 0.4, 0.8),
+    (5, 1, 3, 3, -1, None, 0.8),
+    (2, 2, 6, 2, 2, 0.5, 0.8),
+    (300, 3, 2, 1, 1, 0.5, 0.8),
 ]
 
 
