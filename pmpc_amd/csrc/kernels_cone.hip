@@ -143,6 +143,9 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
   double wh[Q], w0, nb;
   int cs = classify(s, z, wh, w0, nb);
   if (decided >= 0 && !(decided == 1 && !(nb > 0.0))) cs = decided;  // (the case the hysteresis kept)
+  // a cone that was off and stays off (most of them, most rounds): its terms and record are zero already, nothing counts, nothing
+  // to write — 280 of the ~600 bytes this pass moves per cone, and the strided read of R's diagonal
+  if (a.finish && cs == 0 && (int)rec[0] == 0 && !bad) return;
   double tr = 0.0;
 #pragma unroll
   for (int k = 0; k < UD; k++) tr += a.r32 ? (double)((const float *)a.R)[idx * UD * UD + k * (UD + 1)] : a.R[idx * UD * UD + k * (UD + 1)];
