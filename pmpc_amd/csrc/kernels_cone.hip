@@ -61,12 +61,28 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
 #pragma unroll
   for (int k = 0; k < UD; k++) u[k] = a.U[idx * UD + k];
   s_of(u, s);
-#pragma unroll
-  for (int r = 0; r < Q1; r++) z[r] = a.z[idx * Q1 + r];
   double *rec = a.rec + idx * PMPC_CONE_REC;
   bool bad = false;
 #pragma unroll
   for (int r = 0; r < Q1; r++) bad |= !(s[r] == s[r]);
+  // A cone that was off (no multiplier, zero terms) and is still off — most cones, most rounds — needs none of the rest: s alone
+  // classifies it (w = s - 0), nothing counts, nothing is to be written.  Decided from the controls and ONE word of the record.
+  if (a.finish && (int)rec[0] == 0 && !bad) {
+    double zz[Q1], whx[Q], w0x, nbx;
+#pragma unroll
+    for (int r = 0; r < Q1; r++) zz[r] = 0.0;
+    int cn = classify(s, zz, whx, w0x, nbx);
+    if (cn != 0) {  // (the hysteresis of the general path below: a change counts only beyond the round's tolerance)
+      const double m = cn == 2 ? -w0x - nbx : fmin(nbx - w0x, nbx + w0x);
+      double ns0 = 0.0;
+#pragma unroll
+      for (int r = 0; r < Q1; r++) ns0 = fmax(ns0, fabs(s[r]));
+      if (m <= 10.0 * (a.ctl ? a.ctl->tol_l : 1e-11 * a.dual_scale) + 1e-13 * fmax(1.0, ns0)) cn = 0;
+    }
+    if (cn == 0) return;
+  }
+#pragma unroll
+  for (int r = 0; r < Q1; r++) z[r] = a.z[idx * Q1 + r];
 
   int changed = 0, open = 0, decided = -1;
   if (a.finish) {
