@@ -702,8 +702,8 @@ static bool slew_increment_form_applies(const pmpc_ctx *c, const pmpc_problem *p
   if (p->N < 2) return false;  // N = 1: the reference's diagonal rule is not the plain penalty (lqp_utils.jl:31-39)
   // With boxes the control boxes become STATE boxes of the restated problem.  Until r03 those met the interior-point iteration only
   // (1.8x - 2.6x slower cold and ~10x slower warm than the generic kernels' active-set rounds), so boxed slew problems stayed on the
-  // generic kernels; with the state-box rounds of kernels_xbox.hip the restated form is 2.1x - 5.5x FASTER than the generic kernels cold, 1.5x - 2.1x warm,
-  // and agrees with them to 1e-15 (tools/debug/slew_paths.py, profiles/r03_e_slew_paths.txt, CHANGELOG.md 3.3).  It needs the XBOX instantiation of the
+  // generic kernels; with the state-box rounds of kernels_xbox.hip the restated form is 2.1x - 5.4x FASTER than the generic kernels cold, 1.45x - 2x warm,
+  // and agrees with them to 1e-15 (tools/debug/slew_paths.py, profiles/r03_f_slew_paths.txt, CHANGELOG.md 3.3).  It needs the XBOX instantiation of the
   // factor sweep for (x + u, u); the options slew_increment_boxes = 0 / xbox_as = 0 put boxed slew problems back on the generic kernels.
   const bool with_boxes = c->opt[OPT_SLEW_INCREMENT_BOXES] != 0.0 && c->opt[OPT_XBOX_AS] != 0.0;
   if ((p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS)) && !(with_boxes && xbox_as_dims_supported((int)(p->xdim + p->udim), (int)p->udim))) return false;
