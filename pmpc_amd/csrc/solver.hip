@@ -1769,7 +1769,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   // this shape (first iterate with mu <= 0.5: interior, centred, far from its boxes — a late iterate jams) is a better
   // start than the clipped equality-only optimum: 11 -> 9.3 iterations at config D, 11 -> 7.1 on the unicycle.  It is
   // used only if it is strictly inside the new boxes, and a warm-started iteration that fails is repeated cold.
-  const double tol = 1e-12;  // complementarity (1e-10 leaves ~3e-7 relative trajectory error on the quadrotor: too close to the 1e-6 bar)
+  // complementarity (1e-10 leaves ~3e-7 relative trajectory error on the quadrotor: too close to the 1e-6 bar).  State boxes WITHOUT the
+  // state-row rounds (generic kernels, or xbox_as = 0) have nothing that finishes the iteration exactly: 1e-12 left up to 1.9e-6 on
+  // slew problems with ~15 % of the state entries binding (tools/debug/fuzz_xbox.py), 1e-14 leaves 8e-8 — a breakdown on the way
+  // there returns the last good iterate (see below)
+  const double tol = (has_xb && !xbox_as) ? 1e-14 : 1e-12;
   const int max_iter = 80;
   // slabs as the fused per-iteration pass sees them (an unbounded slab still takes the step and feeds the
   // gradient pre-pass)
