@@ -761,13 +761,9 @@ __global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part
   as_ctl_block(ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol, open_part);
 }
 
-// (xdim, udim) pairs with CONE instantiations of the two sweeps (a subset: every pair costs ten more kernels to compile)
+// CONE instantiations of the two sweeps: every compiled (xdim, udim) pair with udim >= 2 (ten more kernels each)
 template <int XD, int UD>
-constexpr bool cone_dims() {
-  return UD >= 2 && ((XD == 12 && UD == 4) || (XD == 8 && UD == 4) || (XD == 6 && UD == 4) || (XD == 4 && UD == 4) || (XD == 9 && UD == 3) ||
-                     (XD == 6 && UD == 3) || (XD == 5 && UD == 3) || (XD == 3 && UD == 3) || (XD == 8 && UD == 2) || (XD == 4 && UD == 2) ||
-                     (XD == 2 && UD == 2));
-}
+constexpr bool cone_dims() { return UD >= 2; }
 // (xdim, udim) pairs with fp32-storage instantiations (class MT = float) of the two sweeps
 template <int XD, int UD>
 constexpr bool f32_dims() { return (XD == 12 && UD == 4) || (XD == 6 && UD == 3) || (XD == 4 && UD == 2); }

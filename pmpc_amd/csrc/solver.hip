@@ -1057,7 +1057,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     HIP_CHECK(hipMemcpyAsync(w.cone_c.d() + 1, p->soc_w0, (size_t)p->soc_q * D8, hipMemcpyDeviceToDevice, s));
     if (has_ub) launch_cone_drop_redundant_lo(w.su.lo.d(), w.cone_A.d(), w.cone_c.d(), (int)p->soc_q, (long long)M * N, u, s);
   }
-  auto soc_interior_point = [&]() -> int {
+  // (finish_now = false: the caller finishes — it may replace the last digits by cone rounds started from this iterate, see the dispatch)
+  auto soc_interior_point = [&](bool finish_now) -> int {
     reset_scalars();
     // ---- stage-wise control cones: primal-dual path following on the same Riccati kernels (kernels_soc.hip) ----------
     const int q = (int)p->soc_q;
@@ -1233,7 +1234,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     inf.ipm_iters = newton;
     inf.mu = mu;
     if (verbose) printf("pmpc_hip: stage cones: status %d after %d Newton steps\n", status, newton);
-    return finish(status);
+    return (finish_now || status != 0) ? finish(status) : 0;
   };
 
   // returns 0: the equality-only optimum satisfies every box (done), 1: boxes violated (interior-point phase), 2: failure
@@ -1295,7 +1296,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
     w.as_key = -1;
     // stage cones (mode 0 warm / 3 cold): Newton terms per round from kernels_cone.hip, see the header there
-    const bool cone = cone_as && (mode == 0 || mode == 3);
+    const bool cone = cone_as && (mode == 0 || mode == 3 || mode == 5);
     ConeArgs ca;
     memset(&ca, 0, sizeof(ca));
     if (cone) {
@@ -1375,7 +1376,11 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       // no copy was kept then) with a consensus horizon the no-rollout start above does not cover — the caller's U_prev
       st.z = (mode == 0 && !w.as_U_valid) ? const_cast<double *>(p->U_prev) : w.U.d();
       st.D = nullptr; st.w = nullptr;
-      launch_as_setup(st, mode, 0, act, p->U_out, big, s);
+      if (mode == 5) {  // finish of the cone path-following iteration: box statuses from ITS duals, cone multipliers = its cone duals
+        st.ll = w.soc_zl.d(); st.lu = w.soc_zu.d();
+        HIP_CHECK(hipMemcpyAsync(w.cone_z.p, w.soc_zc.p, (size_t)M * N * cone_rows * D8, hipMemcpyDeviceToDevice, s));
+      }
+      launch_as_setup(st, mode == 5 ? 1 : mode, 0, act, p->U_out, big, s);
       launch_rollout_fast(b, p->U_out, p->X_out, s);
     }
     // (same conditions as the in-wave consensus solve of structured_solve: one rank, one consensus stage)
@@ -1476,7 +1481,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (verbose)
         for (int r = round; r < h.round && r < 16; r++)
           printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest violation behind a change %.2e)\n",
-                 mode == 4 ? "state rows" : (mode >= 2 ? "cold" : (mode ? "finish" : "warm")), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
+                 mode == 5 ? "finish" : (mode == 4 ? "state rows" : (mode >= 2 ? "cold" : (mode ? "finish" : "warm"))), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
       if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
       if (verbose > 1 && xbox) {  // debugging aid: the state rows after this batch — held rows, largest multiplier, largest |x|, per worst particle
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1708,7 +1713,23 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (verbose) printf("pmpc_hip: stage cones (general form): the rounds did not settle\n");
       return finish(1);
     }
-    return soc_interior_point();
+    // the path-following iteration, then — one shared cone on the register-resident path — cone rounds started from its iterate (box
+    // statuses from its duals, cone multipliers = its cone duals): they replace its last digits (5e-7 -> round-off against the cone
+    // oracle, tools/debug/fuzz_soc.py) and leave set and multipliers for the next solve's warm start; if they do not settle the
+    // iterate itself is the answer, as before
+    if (!cone_as) return soc_interior_point(true);
+    const int st_pf = soc_interior_point(false);
+    if (st_pf != 0) return st_pf;  // (failed: already finished, NaN outputs)
+    const pmpc_info pf = inf;
+    a.Du = nullptr; a.wu = nullptr; a.du_full = 0;
+    const int r5 = active_set_fast(1.0, 5, 10);
+    if (r5 != 0) {
+      if (r5 == 2) HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+      outputs_written = false;
+    }
+    inf.ipm_iters = pf.ipm_iters;
+    inf.mu = r5 == 0 ? 0.0 : pf.mu;
+    return finish(0);
   }
   const bool as_can_defect = as_defect_on && (p->flags & PMPC_PREV_IS_LAST_SOLUTION) && fast;
   // (the caller's U_prev is the stored set's solution; one rank only: the shared controls' base must be the same on every rank,
