@@ -286,6 +286,9 @@ void pmpc_profile_read_all(pmpc_ctx *ctx, double *ms, long long *launches, int c
 
 /* version / build probe used by the loader and the tests */
 const char *pmpc_version(void);
+/* sizeof(pmpc_problem), sizeof(pmpc_info) as the library was built: a binding that mirrors the structs compares them with its
+ * own at load time and refuses a mismatch (a stale .so under a newer binding silently misreads the trailing fields) */
+void pmpc_abi_struct_sizes(size_t *problem, size_t *info);
 
 #ifdef __cplusplus
 }

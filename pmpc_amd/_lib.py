@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libpmpc_hip.so"
+LIB_PATH = Path(os.environ["PMPC_HIP_LIB"]) if os.environ.get("PMPC_HIP_LIB") else _HERE / "libpmpc_hip.so"  # (env: diagnostic / A-B builds)
 _lib = None
 
 c_dp = ctypes.POINTER(ctypes.c_double)
@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
     "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device", "pmpc_linearize_device_f32",
-    "pmpc_set_option", "pmpc_get_option",
+    "pmpc_set_option", "pmpc_get_option", "pmpc_abi_struct_sizes",
 ]
 
 
@@ -116,6 +116,16 @@ def load():
     lib.pmpc_scp_loop_device.restype = ctypes.c_int
     lib.pmpc_version.argtypes = []
     lib.pmpc_version.restype = ctypes.c_char_p
+    # layout check: the library's structs against this binding's mirrors (include/pmpc_abi.h: pmpc_abi_struct_sizes)
+    if not hasattr(lib, "pmpc_abi_struct_sizes"):
+        raise ImportError(f"{LIB_PATH} predates this binding (no pmpc_abi_struct_sizes): rebuild it (make -C pmpc_amd/csrc)")
+    lib.pmpc_abi_struct_sizes.argtypes = [ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.pmpc_abi_struct_sizes.restype = None
+    sp, si = sz(0), sz(0)
+    lib.pmpc_abi_struct_sizes(ctypes.byref(sp), ctypes.byref(si))
+    if (sp.value, si.value) != (ctypes.sizeof(PmpcProblem), ctypes.sizeof(PmpcInfo)):
+        raise ImportError(f"{LIB_PATH} ({lib.pmpc_version().decode()}) and pmpc_amd/_lib.py disagree on the ABI structs: library "
+                          f"{sp.value}/{si.value} bytes, binding {ctypes.sizeof(PmpcProblem)}/{ctypes.sizeof(PmpcInfo)}: rebuild the library")
     _lib = lib
     return lib
 

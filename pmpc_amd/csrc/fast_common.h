@@ -186,7 +186,12 @@ __device__ __forceinline__ void chol_solve(const double (&Lc)[UD][UD], const dou
 
 }  // namespace
 
-// (xdim, udim) pairs with compiled instances
+// (xdim, udim) pairs with compiled instances (PMPC_DIAG_DIMS_12_4: diagnostic / A-B builds of the quadrotor shape only — the full
+// list takes minutes per file)
+#ifdef PMPC_DIAG_DIMS_12_4
+#define PMPC_FAST_DIMS(X) X(12, 4)
+#else
 #define PMPC_FAST_DIMS(X)                                                                                          \
   X(12, 4) X(12, 3) X(12, 2) X(10, 4) X(10, 2) X(9, 4) X(9, 3) X(8, 4) X(8, 2) X(7, 3) X(6, 4) X(6, 3) X(6, 2) X(5, 3) \
   X(5, 2) X(4, 4) X(4, 3) X(4, 2) X(4, 1) X(3, 3) X(3, 2) X(3, 1) X(2, 2) X(2, 1) X(1, 1)
+#endif

@@ -23,6 +23,22 @@
 #include "fast_common.h"
 #include "as_ctl_dev.h"
 
+// Diagnostic build only (-DPMPC_STAGE_TIMELINE, tools/micro/stage_timeline.py; never in the shipped library): s_memtime stamps at the
+// phase boundaries of every stage of ONE wave (the block in the middle of the grid) of the two sweeps, written to a buffer of their
+// own that no kernel reads.  Scheduling barriers pin each stamp between the phases, so the instrumented stage is not the shipped
+// schedule: the stamps say where the time of a stage goes, not what the shipped stage costs to the cycle.
+#ifdef PMPC_STAGE_TIMELINE
+#define PMPC_TL_STAMPS 10
+__device__ unsigned long long pmpc_tl[3][128][PMPC_TL_STAMPS];  // [0 full factor sweep, 1 (unused), 2 forward sweep][stage][stamp]
+#define TL_DECL(kind) unsigned long long tl_[PMPC_TL_STAMPS] = {}; const int tl_kind = (kind); const bool tl_on = blockIdx.x == gridDim.x / 2
+#define TL(k) do { __builtin_amdgcn_sched_barrier(0); tl_[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TL_FLUSH(j) do { if (tl_on && threadIdx.x == 0 && (j) < 128) { for (int k_ = 0; k_ < PMPC_TL_STAMPS; k_++) pmpc_tl[tl_kind][j][k_] = tl_[k_]; } } while (0)
+#else
+#define TL_DECL(kind)
+#define TL(k)
+#define TL_FLUSH(j)
+#endif
+
 #ifndef PMPC_AS_LEAN_WAVES
 #define PMPC_AS_LEAN_WAVES 4  // occupancy the lean backward sweep is compiled for (A/B builds: -DPMPC_AS_LEAN_WAVES=1 lifts the cap)
 #endif
@@ -206,6 +222,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 
   double S[KS], s_row[KS], s_col;
   bool bad = false;  // a pivot of some Huu was not positive
+  TL_DECL(SKIP ? 1 : 0);
   // ---- terminal: S = Q~_{N-1}, s = g_x,N-1 ---------------------------------------------------------------------
   {
     double Q0[KS], xm0[KS], part = 0.0;
@@ -232,6 +249,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   // one stage.  MAIN: a free stage with j >= 1 (no branches).  Returns nothing; the caller stops after stage 0.
   auto stage = [&](auto main_tag, const int j, const Pipe &cur, Pipe &nxt) {
     constexpr bool MAIN = decltype(main_tag)::value;
+    TL(0);  // stage entry
     const bool cons = MAIN ? false : j < Nc;
     const bool below = MAIN ? true : j > 0;  // a stage j - 1 exists
     double Fr[KS], Qc[KS], xm_row[KS], gx_c, Du_c;
@@ -262,8 +280,10 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     // variant behind the Cholesky phase of this stage (its registers are free again by then; the loads still have the rest of
     // this stage and the head of the next to land — with 4 waves per SIMD interleaved that covers the memory latency)
     auto late_pf = [&]() { if (below) fetch_late(j - 1, j >= 2 ? j - 2 : 0, nxt); };
+    TL(1);  // control word decoded, this stage's operands in place (waited for the loads of this stage)
     if (MODE == 1) late_pf();
     if (MODE != 2 && below) fetch_early(j - 1, nxt);  // (deep2: the caller's ring has requested stage j - 2 already)
+    TL(2);  // next stage's loads issued
 
     if (DEFECT) {  // x_j = F [x_{j-1}; u_j] + r_j: the cost-to-go gradient seen through the stage is s + S r
 #pragma unroll
@@ -278,6 +298,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 #pragma unroll
     for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
 
+    TL(3);  // gradient h = F' (s + S r) formed, control rows read out
     // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) ------------------------------------------------------
     v4d H = {0.0, 0.0, 0.0, 0.0};
     double p2q = 0.0;  // Q_{j-1} xm_{j-1} part of s_{j-1}, formed now: Qc / xm_row are dead before the Cholesky phase (registers)
@@ -316,6 +337,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
       return;
     }
 
+    TL(4);  // six MFMAs issued
     // ---- Cholesky of Huu on lane-uniform values (readlane broadcast of the lower triangle) --------
     double Lc[UD][UD], Ld[UD], col[UD];
 #pragma unroll
@@ -337,6 +359,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     }
     // ---- gather the control rows column-wise and substitute in-lane: state columns give K[:, c], the control columns
     //      get unit right-hand sides and give Huu^-1[:, c - XP] -------------------------------------------------
+    TL(5);  // Cholesky factor of Huu done (its first read waited for the MFMA chain)
     double rows4[4];
     grp_gather(H[KS], rows4);
 #pragma unroll
@@ -344,6 +367,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     chol_solve<UD>(Lc, Ld, col);
     const double Kg = pick<UD>(col, g);
     const double rec = frec ? Kg : 0.0;
+    TL(6);  // gains by substitution
     v4d Sn = mfma(H[KS], (L.cxv && gu) ? -Kg : 0.0, H);  // S' = Hxx - Hxu K
 #pragma unroll
     for (int r = 0; r < KS; r++) S[r] = Sn[r];
@@ -359,11 +383,14 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     kq += dpp_d<0xB1>(kq);
     kq += dpp_d<0x4E>(kq);
     if (c == XP && gu) gsto(ubase(kff_, uoff(j)), lug, kq);
-    if (!MAIN && j == 0) return;
+    TL(7);  // record + feed-forward stored
+    if (!MAIN && j == 0) { TL_FLUSH(j); return; }
     // ---- s_{j-1} = h_x - K' hu + g_x,j-1 -------------------------------------------------------------
     const double red2 = grp_allsum(fma(-Kreg, hug, p2q));
     s_col = L.cxv ? h_col + red2 + gx_c : 0.0;
     col_to_row<KS>(s_col, g, s_row);
+    TL(8);  // next cost-to-go gradient in place
+    TL_FLUSH(j);
   };
 
   const int jmin = Nc > 1 ? Nc : 1;  // the MAIN body covers the free stages N-1 .. jmin
@@ -532,6 +559,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   for (int r = 0; r < KS; r++) V[r] = 0.0;
   int nrel = 0, nadd = 0, nbad = 0;
   double vworst = 0.0;
+  TL_DECL(2);
   // consensus step of k-group g when this wave solves the consensus system itself (a.cons_G block partials; Nc == 1): lane e
   // sums entry e of [H | g] in block order — the same operations in every wave, so every particle applies the same step —,
   // then a Cholesky solve on lane-uniform values (arithmetic of k_cons_small's single-thread solve)
@@ -590,12 +618,14 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   const double inv_dual = 1.0 / ((a.as_ctl ? a.as_ctl->dual_scale : 1.0) * pwi);
   auto stage = [&](auto main_tag, const int j, const Pipe &cur) {
     constexpr bool MAIN = decltype(main_tag)::value;
+    TL(0);  // stage entry
     // first pass: [A dx ; K dx] of the incoming state (stage 0 has none: A~_0 = 0 and nothing to feed back)
     v4d D = {0.0, 0.0, 0.0, 0.0};
     if (MAIN || j > 0) {
 #pragma unroll
       for (int r = 0; r < KS; r++) D = mfma(cur.T[r], V[r], D);
     }
+    TL(1);  // first-pass MFMAs issued (waited for this stage's loads)
     const double raw = D[KS];  // (K dx)[g] in every lane of k-group g
     // gather the per-control inputs in lane c = 0 (the other lanes of the k-group compute on whatever they get: ignored)
     const double ubc = cur.grp;                // lane 0's own word
@@ -605,6 +635,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     const int actc = __builtin_amdgcn_mov_dpp(__double2loint(cur.grp), 0x141, 0xF, 0xF, true);  // half-row mirror: lane 7 -> lane 0
     // base control of this stage: in the first round of a warm start the caller's U_prev, which must already BE the base point
     // of the stored set (inside its box, exactly on the bound where held) — else the caller's promise does not hold
+    TL(2);  // control word gathered
     if (DEFECT) {
       const double snapped = actc == 1 ? loc : (actc == 2 ? hic : fmin(fmax(ubc, loc), hic));
       nbad |= (store_u && !(snapped == ubc)) ? 1 : 0;  // (also catches an empty box and a NaN)
@@ -639,6 +670,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       const double dv = release ? -lam * inv_dual : 0.0;
       vworst = fmax(vworst, cnt_here ? fmax(pv, dv) : 0.0);
     }
+    TL(3);  // decisions taken (the first use of `raw` waited for the MFMA chain)
     const double du_q = dpp_d<0x00>(dug);  // the decision of lane 0, in the four lanes of the k-group whose columns are kept
     // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
     // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
@@ -655,6 +687,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     }
     pS += UD * (int)D8;
     if (store_u) gsto_i(ubase(act_, uoff(j) >> 1), lug >> 1, anew);
+    TL(4);  // control / status stores issued
     // second pass: + B du.  The C layout of the result IS the B layout of the next stage's state: nothing moves.
     D[KS] = 0.0;
     D = mfma(cur.T[KS], (c < 4 && gu) ? du_q : 0.0, D);
@@ -672,6 +705,8 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < KS; r++) V[r] = (c < 4) ? D[r] : 0.0;  // (the other columns of the tile carry nothing: kept at zero)
+    TL(5);  // new state stored and in place
+    TL_FLUSH(j);
   };
 
   const int jmin = Nc > 1 ? Nc : 1;  // MAIN covers the free stages jmin .. N-1
@@ -882,6 +917,11 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef PMPC_STAGE_TIMELINE
+extern "C" int pmpc_debug_timeline_read(unsigned long long *out) {  // 3 x 128 x PMPC_TL_STAMPS stamps of the last launches
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pmpc_tl), sizeof(unsigned long long) * 3 * 128 * PMPC_TL_STAMPS);
+}
+#endif
 bool f32_as_dims_supported(int x, int u) {
 #define X(xd, ud) if (x == xd && u == ud) return f32_dims<xd, ud>();
   PMPC_FAST_DIMS(X)

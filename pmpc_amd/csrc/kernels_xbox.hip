@@ -30,8 +30,11 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
     __syncthreads();
   }
   const double pw = a.pw ? a.pw[i] : 1.0;
-  double rho = a.rho_scale * pw * (redd[0] + a.reg_x);
-  if (!(rho > 0.0)) rho = a.rho_scale * pw;
+  // (the scale follows the particle's cost weight, with a floor: a weight of zero — the cone objective's weighted QPs can hand one out —
+  //  must not switch the rows of that particle off)
+  const double pws = fmax(pw, 1e-6);
+  double rho = a.rho_scale * pws * (redd[0] + a.reg_x);
+  if (!(rho > 0.0)) rho = a.rho_scale * pws;
   const double margin0 = 10.0 * (a.ctl ? a.ctl->tol_l : 1e-11 * a.dual_scale);
   int changed = 0, open = 0;
   const bool clamped = a.keep_on_clamp && a.finish && a.cnt[3 * i + 1] > 0;  // (read by every thread before thread 0 adds to it, two barriers further down)

@@ -443,7 +443,9 @@ void fill_nan_outputs(pmpc_ctx *c, const pmpc_problem *p) {
 // =================================================================================================
 extern "C" {
 
-const char *pmpc_version(void) { return "pmpc_hip 0.1 (gfx950)"; }
+const char *pmpc_version(void) { return "pmpc_hip 0.4 (gfx950)"; }
+// layout check of the two structs the bindings mirror (a stale library under a newer binding, or the reverse, must fail loudly)
+void pmpc_abi_struct_sizes(size_t *problem, size_t *info) { *problem = sizeof(pmpc_problem); *info = sizeof(pmpc_info); }
 
 int pmpc_create(pmpc_ctx **out, int device) {
   int ndev = 0;
@@ -1319,7 +1321,9 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       ca.R = p->R; ca.r32 = a.mat32; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
       ca.z = w.cone_z.d(); ca.rec = w.cone_rec.d(); ca.H = w.Hadd.d(); ca.g = w.wu_soc.d();
       ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done; ca.ctl = ctl;
-      ca.tol_step = 1e-6; ca.tol_phi = 1e-9;  // (measured at config E: 1e-6 .. 1e-3 changes the round count by 7.25 -> 6.75 only — the rounds behind the last status change are the Newton iteration itself) ca.dual_scale = dual_scale;
+      // (measured at config E: 1e-6 .. 1e-3 changes the round count by 7.25 -> 6.75 only — the rounds behind the last status change are the Newton iteration itself)
+      ca.tol_step = 1e-6; ca.tol_phi = 1e-9;
+      ca.dual_scale = dual_scale;
     }
     // state boxes: penalty + multiplier terms per round from kernels_xbox.hip, see the header there
     const bool xbox = xbox_as && xb != 0;
@@ -1335,7 +1339,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       } else if (mode == 1) {
         launch_xbox_from_ipm(sx, (int *)w.xb_st.p, w.xb_z.d(), s);
       }
-      b.xb_D = w.xb_D.d(); b.xb_g = w.xb_g.d();
+      b.xb_D = w.xb_D.d(); b.xb_g = w.xb_g.d(); b.as_open = (int *)w.as_open.p;  // (the merged exchange of a sharded run carries the open rows: tail[4])
       xa.M = M; xa.N = N; xa.x = x; xa.lo = p->lx; xa.hi = p->ux; xa.Q = p->Q; xa.pw = p->weights; xa.reg_x = p->reg_x; xa.rho_scale = 1e7;  // (measured, bench.py --vmax: 1e5 .. 1e2 only add rounds)
       xa.z = w.xb_z.d(); xa.st = (int *)w.xb_st.p; xa.D = w.xb_D.d(); xa.g = w.xb_g.d();
       xa.cnt = (int *)w.as_cntp.p; xa.settled = (int *)w.as_settled.p; xa.open = (int *)w.as_open.p; xa.done = &ctl->done; xa.ctl = ctl;
@@ -1925,7 +1929,18 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         }
         break;
       }
-      if (it == max_iter) break;
+      if (it == max_iter) {
+        // out of iterations between the kept iterate (mu <= 1e-10 mu_peak, small residuals) and the convergence test: that iterate
+        // is a certified near-optimal point, returned as the breakdown case above returns it — not a failed solve
+        if (late_mu >= 0.0 && mu_target == 0.0) {
+          if (verbose) printf("pmpc_hip: interior-point iteration stalled above the tolerance: returning the iterate of mu %.3e\n", late_mu);
+          HIP_CHECK(hipMemcpyAsync(w.X.p, w.lateX.p, nx * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.U.p, w.lateU.p, nu * D8, hipMemcpyDeviceToDevice, s));
+          inf.mu = late_mu;
+          status = 0;
+        }
+        break;
+      }
       if (polish_on && it > 1 && h.mu <= polish_next * mu_peak && !(has_xb && !xbox_as && w.xb_block_key == as_key)) {
         const double mu_now = h.mu;  // (h aliases the host snapshot)
         const int r = active_set_solve(std::max(1.0, mu_peak), 1, xbox_as ? 10 : 6);
