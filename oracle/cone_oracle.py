@@ -362,6 +362,8 @@ def conic_solve_py(prob: ConeProblem, xi0, mu0=1.0, mu_final=1e-12, exp_conventi
             grad = c + mu * g
             dxi, _, _ = orc._kkt_solve((mu * H).tocsc(), A.tocsc(), sp.csc_matrix((0, n)), -grad, zero_eq, np.zeros(0))
             dec = float(-grad @ dxi)
+            if dec < 0.0 and abs(dec) <= 1e-9:  # round-off of a converged iterate
+                break
             if dec < 0.0:
                 raise RuntimeError(f"conic oracle: negative Newton decrement {dec:.3e} at mu {mu:.1e} (KKT solve lost its accuracy)")
             if dec <= 1e-12 * max(1.0, mu):

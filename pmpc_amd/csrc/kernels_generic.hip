@@ -903,6 +903,41 @@ int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, in
   return G;
 }
 
+// Consensus weights (cone objective, solver.hip lcone_body): the sweeps run UNWEIGHTED — scaling a particle's whole cost leaves its
+// gains, its active set and its conditional optimum given the shared controls unchanged — and the weights lambda_i enter only where
+// the particles meet:  sum_i lambda_i (H_i, g_i).  One elementwise pass writes lambda_i H_i, lambda_i g_i for the reductions; the terms
+// of the SHARED controls' box, which the owner's particle 0 carries on its diagonal / in its gradient (the 1e30 penalty of a held
+// control in the active-set rounds, the barrier diagonal and shift Du / wu in the interior-point sweeps), are not part of its cost
+// and keep weight one.
+__global__ void __launch_bounds__(256) k_cons_scale(const double *Hc_part, const double *gc_part, const double *w, int M, int nc, int with_H,
+                                                    double *outH, double *outg, const int *as_act, double as_big, const double *Du,
+                                                    const double *wu, int u, int owner) {
+  const int nH = nc * nc, E = with_H ? nH + nc : nc;
+  const long long tot = (long long)M * E;
+  for (long long k = blockIdx.x * 256ll + threadIdx.x; k < tot; k += (long long)gridDim.x * 256) {
+    const int i = (int)(k / E), e = (int)(k % E);
+    const bool isH = with_H && e < nH;
+    const int r = isH ? e % nc : (with_H ? e - nH : e), cc = isH ? e / nc : -1;
+    const double v = isH ? Hc_part[(size_t)i * nH + e] : gc_part[(size_t)i * nc + r];
+    double keep = 0.0;  // the part of v that is not the particle's own cost
+    if (i == 0 && owner) {
+      // (stage j = r / u, control r % u of particle 0: index (0 * N + j) * u + r % u = r)
+      if (isH && cc == r) keep = as_act ? (as_act[r] ? as_big : 0.0) : (Du ? Du[r] : 0.0);
+      if (!isH && !as_act && wu) keep = wu[r];
+    }
+    const double o = fma(w[i], v - keep, keep);
+    if (isH) outH[(size_t)i * nH + e] = o;
+    else outg[(size_t)i * nc + r] = o;
+  }
+}
+void launch_cons_scale(const double *Hc_part, const double *gc_part, const double *w, int M, int nc, bool with_H, double *outH, double *outg,
+                       const int *as_act, double as_big, const double *Du, const double *wu, int u, int owner, hipStream_t s) {
+  const long long tot = (long long)M * (with_H ? nc * nc + nc : nc);
+  const long long blocks = (tot + 255) / 256;
+  hipLaunchKernelGGL(k_cons_scale, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, s, Hc_part, gc_part, w, M, nc,
+                     with_H ? 1 : 0, outH, outg, as_act, as_big, Du, wu, u, owner);
+}
+
 size_t lq_generic_lds_bytes(const LQArgs &a) { return lds_doubles(a.x, a.u, a.n) * sizeof(double); }
 
 void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s) {

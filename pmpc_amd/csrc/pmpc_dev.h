@@ -61,6 +61,7 @@ struct LQArgs {
   int n;  // x + w
   double reg_x, reg_u;
   const double *pw;  // per-particle cost weights (null = 1): J = sum_i pw_i J_i (cone path, `weights` setting)
+  const double *cons_w;  // per-particle CONSENSUS weights (null = 1): sum_i cons_w_i (H_i, g_i) at the shared controls, sweeps unweighted (cone objective)
   // ABI inputs
   const double *f, *fx, *fu, *Q, *R, *X_prev, *U_prev, *X_ref, *U_ref;
   const double *slew, *slew0, *um1;  // per particle, never null (zeros when absent)
@@ -200,6 +201,9 @@ void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int 
                        double *Lc, double *duc, int *fail, hipStream_t s);
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s);
+// lambda_i (H_i, g_i) for the reductions (cone objective: consensus weights, see kernels_generic.hip)
+void launch_cons_scale(const double *Hc_part, const double *gc_part, const double *w, int M, int nc, bool with_H, double *outH, double *outg,
+                       const int *as_act, double as_big, const double *Du, const double *wu, int u, int owner, hipStream_t s);
 
 // ---- kernels_fast.hip ---------------------------------------------------------------------------
 bool lq_fast_supported(const LQArgs &a);

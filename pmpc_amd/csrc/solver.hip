@@ -142,6 +142,7 @@ struct SlabBufs {
 
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
+  DevBuf Hc_w, gc_w, cons_w;  // consensus weights of the cone objective and the scaled copies the reductions read
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc, Jg;  // cone path: particle weights / particle costs (local, gathered)
   DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
@@ -187,7 +188,7 @@ struct ProfCat {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COUNT
 };
 static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COUNT] = {
     {"as_warm", "PMPC_AS_WARM", 1},                // warm start of the active-set rounds from the previous solve's set
@@ -205,6 +206,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"host_reuse", "PMPC_HOST_REUSE", 1},          // host ABI: unchanged 8 MB chunks are not uploaded again
     {"warn_slow_path", "PMPC_WARN_SLOW_PATH", 1},  // one line on stderr when a context first leaves the register-resident path
     {"cone_rank_memory", "PMPC_CONE_RANK_MEMORY", 1},  // cone objective: the weight assignment the previous solve of the shape settled on is tried first
+    {"cone_epigraph", "PMPC_CONE_EPIGRAPH", 1},    // cone objective with hard boxes: epigraph problem in the shared-control space (any tie pattern); 0: weighted-QP fixed point
 };
 
 struct pmpc_ctx {
@@ -212,6 +214,9 @@ struct pmpc_ctx {
   bool warned_slow_path = false;
   std::vector<double> cone_rw;  // cone objective: the weight assignment (by cost rank) the last solve settled on, and what it belongs to
   long long cone_rw_key = -1;
+  std::vector<double> cone_lam;  // cone objective in the shared-control space: multipliers of the epigraph rows the last solve settled on
+  long long cone_lam_key = -1;
+  const double *cons_w_active = nullptr;  // consensus weights of the sub-problem solves lcone_body issues (LQArgs::cons_w)
   int xb_ctrl_from = -1;  // set around the inner solve of the slew increment form: state entries from this index on are the controls (their boxes the control boxes)
   AsCtlCall as_pend{};  // round control of the previous active-set round, to ride in the next consensus-partials launch (structured_solve)
   int prof = 0;  // 0 off, 1 dominant kernel (factor sweep) only, 2 every launch class
@@ -371,16 +376,25 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
     };
     const bool wave_solve = c->opt[OPT_AS_WAVE_CONS] != 0.0;
     a.cons_G = 0;
+    // consensus weights (cone objective): the reductions read lambda_i (H_i, g_i) from scaled copies; the per-particle arrays stay
+    // unweighted (the settled particles' g_i += H_i delta and the host's epigraph solve want them so)
+    const double *HcP = a.Hc_part, *gcP = a.gc_part;
+    if (a.cons_w) {
+      w.Hc_w.ensure((size_t)a.M * nc * nc * sizeof(double)); w.gc_w.ensure((size_t)a.M * nc * sizeof(double));
+      launch_cons_scale(a.Hc_part, a.gc_part, a.cons_w, a.M, nc, factor, w.Hc_w.d(), w.gc_w.d(), a.as_act, a.as_big, a.as_act ? nullptr : a.Du,
+                        a.as_act ? nullptr : a.wu, a.u, a.owner, s);
+      HcP = factor ? w.Hc_w.d() : a.Hc_part; gcP = w.gc_w.d();
+    }
     if (fast && a.as_act && factor && !c->multi() && a.Nc == 1 && wave_solve) {
       // active-set round on one rank with one consensus stage: block partials only — every wave of the forward sweep sums
       // them (same order everywhere) and solves the u x u system itself: the second launch of the reduction is gone
-      a.cons_G = launch_cons_partials(a.Hc_part, a.gc_part, a.M, nc, w.red_tmp.d(), c->as_pend, s);
+      a.cons_G = launch_cons_partials(HcP, gcP, a.M, nc, w.red_tmp.d(), c->as_pend, s);
       c->as_pend.ctl = nullptr;
       a.cons_tH = w.red_tmp.d();
       a.cons_tg = w.red_tmp.d() + (size_t)64 * nc * nc;
     } else if (nc * nc + nc <= 32) {
       const bool solve_now = !c->multi();
-      launch_cons_small(a.Hc_part, a.gc_part, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
+      launch_cons_small(HcP, gcP, a.M, nc, factor, Hc, w.red_tmp.d(), solve_now, w.Lc.d(), w.duc.d(), (int *)w.fail.p, s);
       if (!solve_now) {
         merged_exchange();
         if (fast && a.as_act && factor && a.Nc == 1 && wave_solve) {
@@ -391,8 +405,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
         }
       }
     } else {
-      if (factor) launch_reduce_particles_hg(a.Hc_part, a.gc_part, w.red_tmp.d(), Hc, a.M, nc, s);  // (gc sits right behind Hc)
-      else launch_reduce_particles(a.gc_part, w.red_tmp.d(), gc, a.M, nc, s);
+      if (factor) launch_reduce_particles_hg(HcP, gcP, w.red_tmp.d(), Hc, a.M, nc, s);  // (gc sits right behind Hc)
+      else launch_reduce_particles(gcP, w.red_tmp.d(), gc, a.M, nc, s);
       merged_exchange();
       launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
     }
@@ -504,7 +518,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   if (c->comm && c->mock_comm) delete (MockRank *)c->comm;
   else if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.scratch,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
@@ -828,6 +842,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
   a.any_slew = (has_slew || has_slew0) ? 1 : 0;
   a.sym_cost = (p->flags & PMPC_SYMMETRIC_COST) ? 1 : 0;
   a.pw = p->weights;
+  a.cons_w = c->cons_w_active;  // (set by lcone_body around its sub-problem solves; null otherwise)
 
   // ---- workspace ---------------------------------------------------------------------------------
   w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8);
@@ -2116,6 +2131,8 @@ int pmpc_particle_costs_device(pmpc_ctx *c, const pmpc_problem *p0, const double
 }
 
 static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose);
+int pmpc_epigraph_solve_host(int M, int nc, const double *J, const double *H, const double *g, const unsigned char *held, double K, double cap,
+                             double *lam_io, double *delta, double *t_out, int verbose);  // epigraph_host.hip
 int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose) {
   try {
     return lcone_body(c, p, smooth_alpha, info, verbose);
@@ -2230,6 +2247,129 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
   if (M == 1) {  // one particle: weight 1 - eps, same minimiser as the QP (k = 1)
     rw[0] = 1.0 - eps;
     return finish(solve_with(rw));
+  }
+  // ---- hard boxes: the epigraph problem in the space of the shared controls (epigraph_host.hip) ------------------------------------
+  // Scaling a particle's whole cost changes neither its gains nor its active set nor its optimum GIVEN the shared controls, so the
+  // sweeps run unweighted (a particle of weight zero takes the minimum-cost completion: the limit of the floor weight of the
+  // weighted-QP iteration below, without the floor) and the multipliers lam_i of the M epigraph rows enter only where the particles
+  // meet: the consensus system sum_i lam_i (H_i, g_i) (LQArgs::cons_w).  Each sub-problem solve leaves the particles' condensed
+  // quadratics behind; when its costs J_i and the multipliers violate the KKT conditions of the epigraph problem (lam = 1 + eps above
+  // the threshold cost, 0 below, anything on it), the host solves that problem on those quadratics — ties among any number of
+  // particles are ordinary degenerate rows there — and the next solve applies the result: one more round if no box changes status.
+  const int Ncc = p->Nc < 0 ? (int)p->N : (int)std::min<long long>(p->Nc, (long long)p->N), ncv = Ncc * (int)p->udim;
+  const bool epi_on = c->opt[OPT_CONE_EPIGRAPH] != 0.0 && !(q.barrier_mu > 0.0) && !c->multi() && c->world == 1 &&
+                      (double)M * ncv * ncv <= 2e7 && !(p->flags & PMPC_FORCE_GENERIC);
+  if (epi_on) {
+    pmpc_problem qq = *p;
+    qq.weights = nullptr;
+    qq.barrier_mu = 0.0;
+    const double Ksum = (1.0 - eps) * kk, cap = 1.0 + eps;
+    std::vector<double> lam(M, Ksum / (double)M), cw(M);
+    auto solve_cons = [&](bool weighted) -> int {
+      bool need = p->weights != nullptr || weighted;
+      if (need) {
+        for (size_t i = 0; i < M; i++) cw[i] = (weighted ? lam[i] : 1.0) * user[i];
+        w.cons_w.ensure(M * D8);
+        HIP_CHECK(hipMemcpyAsync(w.cons_w.p, cw.data(), M * D8, hipMemcpyHostToDevice, s));
+      }
+      c->cons_w_active = (need && ncv > 0) ? w.cons_w.d() : nullptr;
+      int st_;
+      try {
+        st_ = pmpc_lqp_solve_device(c, &qq, &inf, verbose > 1);
+      } catch (...) {
+        c->cons_w_active = nullptr;
+        throw;
+      }
+      c->cons_w_active = nullptr;
+      qq.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;  // (later solves of this call start from the workspace's set and solution)
+      outer++;
+      solves_total += inf.structured_solves;
+      ipm_total += inf.ipm_iters;
+      last = inf;
+      if (st_ != 0) return st_;
+      pmpc_particle_costs_device(c, p, p->X_out, p->U_out, w.Jc.d());
+      gather(w.Jc.d(), J);
+      for (size_t i = 0; i < M; i++) J[i] *= user[i];
+      return 0;
+    };
+    const long long lkey = ((((((long long)M * 1000003 + (long long)p->N) * 131 + (long long)p->xdim) * 131 + (long long)p->udim) * 131 + p->Nc + 2) * 1000003 + (long long)kk);
+    int st_ = 0;
+    if (ncv == 0) return finish(solve_cons(false));  // no shared controls: every particle minimises its own cost, whatever its multiplier
+    const bool remembered = c->opt[OPT_CONE_RANK_MEMORY] != 0.0 && !(p->flags & PMPC_COLD_START) && c->cone_lam_key == lkey && c->cone_lam.size() == M;
+    if (remembered) lam = c->cone_lam;
+    c->cone_lam_key = -1;
+    st_ = solve_cons(remembered);
+    if (st_ != 0) return finish(st_);
+    std::vector<double> Hh, gh, dl(ncv), delta(ncv);
+    std::vector<int> act0(ncv);
+    std::vector<unsigned char> held(ncv);
+    bool settled = false;
+    for (int it = 0; it < 30; it++) {
+      // KKT of the epigraph rows at (lam, J): threshold cost t from the rows strictly inside (0, cap)
+      double tsum = 0.0, jmin_full = 1e300, jmax_zero = -1e300;
+      size_t nfr = 0;
+      for (size_t i = 0; i < M; i++) {
+        if (lam[i] > 1e-12 && lam[i] < cap - 1e-12) { tsum += J[i]; nfr++; }
+        else if (lam[i] >= cap - 1e-12) jmin_full = std::min(jmin_full, J[i]);
+        else jmax_zero = std::max(jmax_zero, J[i]);
+      }
+      const double tthr = nfr ? tsum / (double)nfr : (jmin_full < 1e300 && jmax_zero > -1e300 ? 0.5 * (jmin_full + jmax_zero) : (jmin_full < 1e300 ? jmin_full : jmax_zero));
+      double viol = 0.0;
+      for (size_t i = 0; i < M; i++) {
+        if (lam[i] > 1e-12 && lam[i] < cap - 1e-12) viol = std::max(viol, std::fabs(J[i] - tthr));
+        else if (lam[i] >= cap - 1e-12) viol = std::max(viol, tthr - J[i]);
+        else viol = std::max(viol, J[i] - tthr);
+      }
+      if (verbose) printf("pmpc_hip: cone epigraph outer %d: threshold cost %.9e, %zu rows on it, KKT violation %.3e\n", it, tthr, nfr, viol);
+      if (viol <= 1e-9 * std::max(1.0, std::fabs(tthr))) { settled = true; break; }
+      // the particles' quadratics around the accepted point: left by the LAST round of the active-set rounds (gradient at that round's
+      // base point, the consensus step it applied).  A solve that ended elsewhere (equality-only optimum, interior-point iteration) is
+      // repeated warm: one round that changes nothing.
+      for (int rep = 0; rep < 2 && !(last.fast_path && last.ipm_iters == 0 && last.active_set_rounds >= 1); rep++) {
+        st_ = solve_cons(true);
+        if (st_ != 0) return finish(st_);
+      }
+      if (!(last.fast_path && last.ipm_iters == 0 && last.active_set_rounds >= 1)) {
+        if (verbose) printf("pmpc_hip: cone epigraph: the sub-problem does not end in the active-set rounds; weighted-QP iteration instead\n");
+        break;
+      }
+      Hh.resize(M * (size_t)ncv * ncv); gh.resize(M * (size_t)ncv);
+      HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, Hh.size() * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(gh.data(), w.gc_part.p, gh.size() * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(dl.data(), w.as_delta.p, ncv * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(act0.data(), w.as_act.p, ncv * sizeof(int), hipMemcpyDeviceToHost, s));  // (particle 0's stages < Nc come first)
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (int r = 0; r < ncv; r++) held[r] = act0[r] != 0 ? 1 : 0;
+      for (size_t i = 0; i < M; i++) {
+        double *Hi = &Hh[i * (size_t)ncv * ncv], *gi = &gh[i * (size_t)ncv];
+        for (int r = 0; r < ncv; r++)
+          for (int cc = r + 1; cc < ncv; cc++) Hi[cc + (size_t)ncv * r] = Hi[r + (size_t)ncv * cc];  // (off-diagonal blocks live in the upper triangle)
+        if (i == 0)
+          for (int r = 0; r < ncv; r++)
+            if (held[r]) Hi[r + (size_t)ncv * r] = 1.0;  // (the 1e30 penalty of a held shared control is not part of the cost; the step there is zero)
+        for (int r = 0; r < ncv; r++) {  // gradient at the accepted point = gradient at the last round's base + H_i (applied step)
+          double acc = 0.0;
+          for (int cc = 0; cc < ncv; cc++) acc += (held[cc] ? 0.0 : Hi[r + (size_t)ncv * cc] * dl[cc]);
+          gi[r] += acc;
+        }
+        if (user[i] != 1.0) {
+          for (size_t e_ = 0; e_ < (size_t)ncv * ncv; e_++) Hi[e_] *= user[i];
+          for (int r = 0; r < ncv; r++) gi[r] *= user[i];
+        }
+      }
+      double tpred = 0.0;
+      const int est = pmpc_epigraph_solve_host((int)M, ncv, J.data(), Hh.data(), gh.data(), held.data(), Ksum, cap, lam.data(), delta.data(), &tpred, verbose);
+      if (est != 0 && verbose) printf("pmpc_hip: cone epigraph: the host solve stopped short of its tolerance (the next check decides)\n");
+      st_ = solve_cons(true);
+      if (st_ != 0) return finish(st_);
+    }
+    if (settled) {
+      c->cone_lam = lam;
+      c->cone_lam_key = lkey;
+      return finish(0);
+    }
+    if (verbose) printf("pmpc_hip: cone epigraph: not settled; weighted-QP iteration\n");
+    q.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;
   }
   // Inside an SCP loop the ranking of the particle costs rarely changes between iterations: the assignment the previous solve of this
   // shape settled on is tried FIRST — if the ranking at its optimum reproduces it, that is the fixed point (the same consistency test
