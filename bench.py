@@ -240,7 +240,8 @@ def main():
         import functools
 
         solve_fn = functools.partial(solver.lcone_solve, smooth_alpha=args.smooth_alpha)
-        args.python_loop = True  # (pmpc_scp_loop_device drives the QP / stage-cone sub-problems only)
+    # the library loop drives the cone objective itself (PMPC_CONE_OBJECTIVE; smoothing: barrier_mu = 1 / alpha)
+    cone_kw = dict(cone_objective=True, barrier_mu=(1.0 / args.smooth_alpha if args.smooth_alpha == args.smooth_alpha else 0.0)) if args.cone else {}
     solve_events = []  # (start, end) HIP events on the solver's stream around the convex sub-problem (repeat windows only)
 
     def step(Xp, Up, Xo, Uo, first, time_solve=False):
@@ -280,7 +281,7 @@ def main():
             model, d["params"], k, f2=f2, fx2=fx2, fu2=fu2, first_cold=len(hist) == 0, **soc_kw, **xb_kw, f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua,
             Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"],
             lu=d.get("lu"), uu=d.get("uu"), X_out=Xb, U_out=Ub, force_generic=args.force_generic, symmetric_cost=True,
-            wait_current_stream=False)
+            wait_current_stream=False, **cone_kw)
         if done != k and not args.ignore_status:
             raise SystemExit(f"solver failed with status {infos[-1]['status']} in SCP iteration {len(hist) + done + 1}")
         for i in range(done):

@@ -113,6 +113,10 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                                           the base point of the stored set under the boxes this solve uses): a broken promise
                                           costs time, not correctness. */
 
+#define PMPC_CONE_OBJECTIVE 1024u /* pmpc_scp_loop_device only: the sub-problem of every iteration is the reference's DEFAULT solver path
+                                    (solver = "ecos" -> c_lcone_solve, pmpc/static_backend.py:242-253: the eps-anchored epigraph objective of
+                                    PMPC.jl/src/main.jl:204-238; barrier_mu > 0: log-barrier smoothing with alpha = 1 / barrier_mu) instead of
+                                    the QP of c_lqp_solve */
 #define PMPC_F32_MATRICES 512u /* fp32-STORAGE mode (BASELINE config E's "fp32"; the reference is fp64-only, c_interface.jl:6-25): fx, fu,
                                  Q, R point to FLOAT arrays of the same layouts (cast to const double * in the struct).  The
                                  active-set sweeps of an SCP loop's warm-started solves (control boxes and / or stage cones,

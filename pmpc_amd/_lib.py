@@ -18,7 +18,7 @@ _lib = None
 c_dp = ctypes.POINTER(ctypes.c_double)
 
 # flags of pmpc_problem.flags (include/pmpc_abi.h)
-HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, COLD_START, STATIC_CONS_BOUNDS, PREV_IS_LAST_SOLUTION, F32_MATRICES = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+HAS_XBOUNDS, HAS_UBOUNDS, HAS_SLEW, HAS_SLEW0, FORCE_GENERIC, SYMMETRIC_COST, COLD_START, STATIC_CONS_BOUNDS, PREV_IS_LAST_SOLUTION, F32_MATRICES, CONE_OBJECTIVE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 
 ABI_SYMBOLS = [
     "c_lqp_solve", "c_lcone_solve", "pmpc_lqp_solve_host", "pmpc_lcone_solve_host", "pmpc_create", "pmpc_destroy", "pmpc_stream", "pmpc_sync", "pmpc_lqp_solve_device",

@@ -938,6 +938,67 @@ void launch_cons_scale(const double *Hc_part, const double *gc_part, const doubl
                      with_H ? 1 : 0, outH, outg, as_act, as_big, Du, wu, u, owner);
 }
 
+// KKT check of the epigraph rows of the cone objective (solver.hip lcone_body) on the device: multipliers lam_i in [0, cap], particle
+// costs J_i (scaled by the caller's weights if any).  Threshold cost t = mean cost of the rows strictly inside (0, cap) (none: the midpoint
+// between the cheapest full row and the costliest empty one); violation = max over rows of  |J_i - t| (inside), t - J_i (full),
+// J_i - t (empty).  out = {violation, t, rows inside, 0}.  One block.
+__global__ void __launch_bounds__(1024) k_epi_check(const double *lam, const double *J, const double *user, int M, double cap, double *out,
+                                                   double *mirror, unsigned long long *mirror_seq, unsigned long long seq) {
+  __shared__ double rs[1024], rmin[1024], rmax[1024];
+  __shared__ int rn[1024];
+  __shared__ double tsh;
+  const int t = threadIdx.x;
+  double s = 0.0, jmin = 1e300, jmax = -1e300;
+  int n = 0;
+  for (int i = t; i < M; i += 1024) {
+    const double l = lam[i], j = J[i] * (user ? user[i] : 1.0);
+    if (l > 1e-12 && l < cap - 1e-12) { s += j; n++; }
+    else if (l >= cap - 1e-12) jmin = fmin(jmin, j);
+    else jmax = fmax(jmax, j);
+  }
+  rs[t] = s; rn[t] = n; rmin[t] = jmin; rmax[t] = jmax;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (t < w) { rs[t] += rs[t + w]; rn[t] += rn[t + w]; rmin[t] = fmin(rmin[t], rmin[t + w]); rmax[t] = fmax(rmax[t], rmax[t + w]); }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double a = rmin[0], b = rmax[0];
+    tsh = rn[0] ? rs[0] / (double)rn[0] : ((a < 1e300 && b > -1e300) ? 0.5 * (a + b) : (a < 1e300 ? a : b));
+  }
+  __syncthreads();
+  const double th = tsh;
+  double v = 0.0;
+  bool bad = false;
+  for (int i = t; i < M; i += 1024) {
+    const double l = lam[i], j = J[i] * (user ? user[i] : 1.0);
+    bad |= !(j == j);
+    if (l > 1e-12 && l < cap - 1e-12) v = fmax(v, fabs(j - th));
+    else if (l >= cap - 1e-12) v = fmax(v, th - j);
+    else v = fmax(v, j - th);
+  }
+  const int nin = rn[0];
+  __syncthreads();
+  rs[t] = bad ? 1e300 : v;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if (t < w) rs[t] = fmax(rs[t], rs[t + w]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    out[0] = rs[0]; out[1] = th; out[2] = (double)nin; out[3] = 0.0;
+    if (mirror) {  // host-coherent copy + sequence number: the host polls it without draining the stream (work enqueued behind keeps running)
+      mirror[0] = rs[0]; mirror[1] = th; mirror[2] = (double)nin; mirror[3] = 0.0;
+      __threadfence_system();
+      *(volatile unsigned long long *)mirror_seq = seq;
+    }
+  }
+}
+void launch_epi_check(const double *lam, const double *J, const double *user, int M, double cap, double *out, hipStream_t s, double *mirror,
+                      unsigned long long *mirror_seq, unsigned long long seq) {
+  hipLaunchKernelGGL(k_epi_check, dim3(1), dim3(1024), 0, s, lam, J, user, M, cap, out, mirror, mirror_seq, seq);
+}
+
 size_t lq_generic_lds_bytes(const LQArgs &a) { return lds_doubles(a.x, a.u, a.n) * sizeof(double); }
 
 void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s) {

@@ -201,6 +201,9 @@ void launch_cons_small(const double *Hc_part, const double *gc_part, int M, int 
                        double *Lc, double *duc, int *fail, hipStream_t s);
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s);
+// KKT check of the cone objective's epigraph rows on the device: out = {violation, threshold cost, rows on the threshold, 0}
+void launch_epi_check(const double *lam, const double *J, const double *user, int M, double cap, double *out, hipStream_t s, double *mirror = nullptr,
+                      unsigned long long *mirror_seq = nullptr, unsigned long long seq = 0);
 // lambda_i (H_i, g_i) for the reductions (cone objective: consensus weights, see kernels_generic.hip)
 void launch_cons_scale(const double *Hc_part, const double *gc_part, const double *w, int M, int nc, bool with_H, double *outH, double *outg,
                        const int *as_act, double as_big, const double *Du, const double *wu, int u, int owner, hipStream_t s);

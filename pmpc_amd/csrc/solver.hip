@@ -142,7 +142,7 @@ struct SlabBufs {
 
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
-  DevBuf Hc_w, gc_w, cons_w;  // consensus weights of the cone objective and the scaled copies the reductions read
+  DevBuf Hc_w, gc_w, cons_w, epi_lam, epi_out;  // consensus weights of the cone objective and the scaled copies the reductions read
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc, Jg;  // cone path: particle weights / particle costs (local, gathered)
   DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
@@ -216,6 +216,7 @@ struct pmpc_ctx {
   long long cone_rw_key = -1;
   std::vector<double> cone_lam;  // cone objective in the shared-control space: multipliers of the epigraph rows the last solve settled on
   long long cone_lam_key = -1;
+  std::vector<double> cons_w_host, epi_lam_host;  // what the device copies of the consensus weights / multipliers hold
   const double *cons_w_active = nullptr;  // consensus weights of the sub-problem solves lcone_body issues (LQArgs::cons_w)
   int xb_ctrl_from = -1;  // set around the inner solve of the slew increment form: state entries from this index on are the controls (their boxes the control boxes)
   AsCtlCall as_pend{};  // round control of the previous active-set round, to ride in the next consensus-partials launch (structured_solve)
@@ -233,9 +234,9 @@ struct pmpc_ctx {
   IpmScal *sc_host = nullptr;  // host snapshot of the device scalars
   int *fail_host = nullptr;
   // host-coherent mapped mirror the exchange kernel publishes into (zero-copy; the host polls `seq`)
-  struct ScMirror { IpmScal sc; unsigned long long seq; int as_cnt[4]; unsigned long long as_seq; AsCtl ctl; };
+  struct ScMirror { IpmScal sc; unsigned long long seq; int as_cnt[4]; unsigned long long as_seq; AsCtl ctl; double epi[4]; unsigned long long epi_seq; };
   ScMirror *mirror = nullptr, *mirror_dev = nullptr;
-  unsigned long long seq = 0, as_seq = 0;
+  unsigned long long seq = 0, as_seq = 0, epi_seq = 0;
   // RCCL
   ncclComm_t comm = nullptr;
   bool mock_comm = false;  // comm is a MockRank (test hook), not an RCCL communicator
@@ -518,7 +519,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   if (c->comm && c->mock_comm) delete (MockRank *)c->comm;
   else if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.scratch,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.epi_lam, &w.epi_out, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
@@ -2016,6 +2017,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
 // -------------------------------------------------------------------------------------------------
 // SCP loop with the host out of the loop body (built-in dynamics)
 // -------------------------------------------------------------------------------------------------
+static int lcone_body(pmpc_ctx *c, const pmpc_problem *p, double smooth_alpha, pmpc_info *info, int verbose);
 int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmpc_problem *p0, double *f2, double *fx2, double *fu2,
                          int steps, int first_cold, double *res, pmpc_info *infos, int *last_in_out) {
   pmpc_problem p = *p0;
@@ -2023,6 +2025,7 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
   double *XA = const_cast<double *>(p0->X_prev), *UA = const_cast<double *>(p0->U_prev), *XB = p0->X_out, *UB = p0->U_out;
   double *F[2][3] = {{const_cast<double *>(p0->f), const_cast<double *>(p0->fx), const_cast<double *>(p0->fu)}, {f2, fx2, fu2}};
   const bool soc = p0->soc_u_interior != nullptr || p0->cone_count > 0;
+  const bool cone_obj = (p0->flags & PMPC_CONE_OBJECTIVE) != 0;  // the sub-problem is the reference's default path (c_lcone_solve)
   const int jac32 = (p0->flags & PMPC_F32_MATRICES) ? 1 : 0;  // (f / fx / fu scratch sets: fx, fu FLOAT arrays then)
   int done = 0, cur = 0;
   bool lin_ready = false;  // the linearisation of iteration `done` is already enqueued (valid speculation of the previous one)
@@ -2064,7 +2067,8 @@ int pmpc_scp_loop_device(pmpc_ctx *c, int model, const double *params, const pmp
       c->spec_fired = c->spec_ok = false;
       c->post_batch = [&]() { follow_up(true); };
       pmpc_info inf;
-      const int st = solve_impl(c, &p, &inf, 0, soc);
+      const int st = cone_obj ? lcone_body(c, &p, p.barrier_mu > 0.0 ? 1.0 / p.barrier_mu : std::numeric_limits<double>::quiet_NaN(), &inf, 0)
+                              : solve_impl(c, &p, &inf, 0, soc);
       c->post_batch = nullptr;
       if (infos) infos[done] = inf;
       if (st != 0) break;
@@ -2265,32 +2269,72 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
     qq.barrier_mu = 0.0;
     const double Ksum = (1.0 - eps) * kk, cap = 1.0 + eps;
     std::vector<double> lam(M, Ksum / (double)M), cw(M);
+    // KKT check of the epigraph rows on the device (k_epi_check): costs of the accepted point, threshold cost, violation — 32 bytes back.
+    // Inside pmpc_scp_loop_device both kernels go in BEHIND the first batch of rounds, ahead of the speculative follow-up work (residual,
+    // next linearisation), so the answer is there when the host has seen the rounds end.
+    if (w.epi_lam.ensure(M * D8)) c->epi_lam_host.clear();  // (fresh allocations hold nothing of what the host mirrors remember)
+    if (w.cons_w.ensure(M * D8)) c->cons_w_host.clear();
+    w.epi_out.ensure(4 * D8);
+    double chk[4] = {0.0, 0.0, 0.0, 0.0};
+    auto enqueue_check = [&]() {
+      pmpc_particle_costs_device(c, p, p->X_out, p->U_out, w.Jc.d());
+      launch_epi_check(w.epi_lam.d(), w.Jc.d(), p->weights, (int)M, cap, w.epi_out.d(), s, c->mirror_dev->epi, &c->mirror_dev->epi_seq, ++c->epi_seq);
+    };
+    int n_solves = 0, hook_solve = -1;
     auto solve_cons = [&](bool weighted) -> int {
       bool need = p->weights != nullptr || weighted;
       if (need) {
         for (size_t i = 0; i < M; i++) cw[i] = (weighted ? lam[i] : 1.0) * user[i];
-        w.cons_w.ensure(M * D8);
-        HIP_CHECK(hipMemcpyAsync(w.cons_w.p, cw.data(), M * D8, hipMemcpyHostToDevice, s));
+        if (c->cons_w_host != cw) {  // (unchanged since the last upload — the steady state of an SCP loop: nothing to send)
+          HIP_CHECK(hipMemcpyAsync(w.cons_w.p, cw.data(), M * D8, hipMemcpyHostToDevice, s));
+          c->cons_w_host = cw;
+        }
+      }
+      if (c->epi_lam_host != lam) {
+        HIP_CHECK(hipMemcpyAsync(w.epi_lam.p, lam.data(), M * D8, hipMemcpyHostToDevice, s));
+        c->epi_lam_host = lam;
       }
       c->cons_w_active = (need && ncv > 0) ? w.cons_w.d() : nullptr;
+      bool fired_here = false;
+      std::function<void()> orig;
+      if (c->post_batch) {
+        orig.swap(c->post_batch);
+        c->post_batch = [&]() {
+          fired_here = true;
+          enqueue_check();
+          orig();
+        };
+      }
       int st_;
       try {
         st_ = pmpc_lqp_solve_device(c, &qq, &inf, verbose > 1);
       } catch (...) {
         c->cons_w_active = nullptr;
+        c->post_batch = nullptr;
         throw;
       }
       c->cons_w_active = nullptr;
+      if (c->post_batch) {  // not fired (the solve did not go through a first batch of rounds): the caller's hook stays for a later solve
+        c->post_batch = nullptr;
+        c->post_batch.swap(orig);
+      }
+      if (fired_here) hook_solve = n_solves;
+      n_solves++;
       qq.flags &= ~(unsigned)PMPC_PREV_IS_LAST_SOLUTION;  // (later solves of this call start from the workspace's set and solution)
       outer++;
       solves_total += inf.structured_solves;
       ipm_total += inf.ipm_iters;
       last = inf;
       if (st_ != 0) return st_;
-      pmpc_particle_costs_device(c, p, p->X_out, p->U_out, w.Jc.d());
+      if (!(fired_here && c->spec_ok)) enqueue_check();  // (what the hook computed saw unfinished outputs, or there was no hook)
+      // (polled from the host-coherent mirror: the stream — which may hold the next linearisation behind the check — is not drained)
+      wait_published(c, &c->mirror->epi_seq, c->epi_seq);
+      memcpy(chk, (const void *)c->mirror->epi, 4 * D8);
+      return 0;
+    };
+    auto fetch_costs = [&]() {
       gather(w.Jc.d(), J);
       for (size_t i = 0; i < M; i++) J[i] *= user[i];
-      return 0;
     };
     const long long lkey = ((((((long long)M * 1000003 + (long long)p->N) * 131 + (long long)p->xdim) * 131 + (long long)p->udim) * 131 + p->Nc + 2) * 1000003 + (long long)kk);
     int st_ = 0;
@@ -2305,23 +2349,11 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
     std::vector<unsigned char> held(ncv);
     bool settled = false;
     for (int it = 0; it < 30; it++) {
-      // KKT of the epigraph rows at (lam, J): threshold cost t from the rows strictly inside (0, cap)
-      double tsum = 0.0, jmin_full = 1e300, jmax_zero = -1e300;
-      size_t nfr = 0;
-      for (size_t i = 0; i < M; i++) {
-        if (lam[i] > 1e-12 && lam[i] < cap - 1e-12) { tsum += J[i]; nfr++; }
-        else if (lam[i] >= cap - 1e-12) jmin_full = std::min(jmin_full, J[i]);
-        else jmax_zero = std::max(jmax_zero, J[i]);
-      }
-      const double tthr = nfr ? tsum / (double)nfr : (jmin_full < 1e300 && jmax_zero > -1e300 ? 0.5 * (jmin_full + jmax_zero) : (jmin_full < 1e300 ? jmin_full : jmax_zero));
-      double viol = 0.0;
-      for (size_t i = 0; i < M; i++) {
-        if (lam[i] > 1e-12 && lam[i] < cap - 1e-12) viol = std::max(viol, std::fabs(J[i] - tthr));
-        else if (lam[i] >= cap - 1e-12) viol = std::max(viol, tthr - J[i]);
-        else viol = std::max(viol, J[i] - tthr);
-      }
-      if (verbose) printf("pmpc_hip: cone epigraph outer %d: threshold cost %.9e, %zu rows on it, KKT violation %.3e\n", it, tthr, nfr, viol);
+      // KKT of the epigraph rows at (lam, J), from the device: {violation, threshold cost, rows on the threshold}
+      const double viol = chk[0], tthr = chk[1];
+      if (verbose) printf("pmpc_hip: cone epigraph outer %d: threshold cost %.9e, %d rows on it, KKT violation %.3e\n", it, tthr, (int)chk[2], viol);
       if (viol <= 1e-9 * std::max(1.0, std::fabs(tthr))) { settled = true; break; }
+      fetch_costs();
       // the particles' quadratics around the accepted point: left by the LAST round of the active-set rounds (gradient at that round's
       // base point, the consensus step it applied).  A solve that ended elsewhere (equality-only optimum, interior-point iteration) is
       // repeated warm: one round that changes nothing.
@@ -2363,6 +2395,8 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
       st_ = solve_cons(true);
       if (st_ != 0) return finish(st_);
     }
+    // work the caller enqueued behind the first batch of rounds (pmpc_scp_loop_device) saw the final outputs only if that solve was the last
+    if (c->spec_fired && hook_solve != n_solves - 1) c->spec_ok = false;
     if (settled) {
       c->cone_lam = lam;
       c->cone_lam_key = lkey;

@@ -101,7 +101,7 @@ class DeviceSolver:
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
                  barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, static_cons_bounds=False, prev_is_last_solution=False, soc_W=None, soc_w0=None,
-                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0, cones=None):
+                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0, cones=None, cone_objective=False):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
@@ -129,6 +129,8 @@ class DeviceSolver:
             flags |= _lib.PREV_IS_LAST_SOLUTION
         if symmetric_cost:  # Q_j, R_j exactly symmetric (enables the register-resident MFMA path)
             flags |= _lib.SYMMETRIC_COST
+        if cone_objective:  # scp_loop: the sub-problem is the reference's default path (c_lcone_solve semantics; barrier_mu = 1 / smooth_alpha)
+            flags |= _lib.CONE_OBJECTIVE
         # fp32-STORAGE mode (include/pmpc_abi.h PMPC_F32_MATRICES): fx, fu, Q, R as float32 tensors — all four or none
         md = torch.float32 if fx.dtype == torch.float32 else torch.float64
         assert fx.dtype == fu.dtype == Q.dtype == R.dtype == md, "fx, fu, Q, R must share one dtype (float64, or float32 for the fp32-storage mode)"

@@ -94,3 +94,52 @@ def test_weightless_particles_take_their_minimum_cost_completion():
     Xo, Uo, info = orc.lcone_solve_py(*args, Nc=Nc, return_info=True, **kw)
     X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=float("nan"), solver="ecos")
     assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+
+
+@pytest.mark.parametrize("model,M,N,Nc,steps", [("quadrotor", 96, 20, 1, 4), ("unicycle", 40, 12, 3, 2), ("quadrotor", 640, 8, 1, 3)])
+def test_library_scp_loop_drives_the_cone_objective(model, M, N, Nc, steps):
+    """pmpc_scp_loop_device with PMPC_CONE_OBJECTIVE (the reference's default solver path as the sub-problem of every iteration; the
+    epigraph rows are checked on the device behind the first batch of rounds) walks the sequence of a Python loop of linearise /
+    lcone_solve / residual calls: same residuals and iterates."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, DeviceSolver, to_device_problem
+
+    prob = dyn.make_quadrotor_problem(M=M, N=N, Nc=Nc) if model == "quadrotor" else dyn.make_unicycle_problem(M=M, N=N, Nc=Nc)
+    mid = MODEL_QUADROTOR if model == "quadrotor" else MODEL_UNICYCLE
+    d = to_device_problem(prob)
+    common = dict(Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"], lu=d["lu"],
+                  uu=d["uu"], symmetric_cost=True)
+    # (the unicycle's `where(u >= 0, eps, -eps)` turns a 1e-12 difference into 1e-6 within three iterations: two iterations there)
+    outs = []
+    for lib_loop in (False, True):
+        solver = DeviceSolver(0)  # fresh memories for both runs
+        Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+        Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+        if not lib_loop:
+            res = []
+            for it in range(steps):
+                f, fx, fu = solver.linearize(mid, d["x0"], Xa, Ua, d["params"])
+                _, _, st = solver.lcone_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, static_cons_bounds=True,
+                                              prev_is_last_solution=it > 0, cold_start=it == 0, **common)
+                assert st == 0, (it, solver.last_info)
+                res.append(float(solver.scp_residual(Xb, Xa, Ub, Ua)[0].item()))
+                Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+            outs.append((np.array(res), Xa.clone(), Ua.clone()))
+        else:
+            x, u = Xa.shape[-1], Ua.shape[-1]
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float64, device="cuda")
+            bufs = [mk(M, N, x), mk(M, N, x, x), mk(M, N, u, x), mk(M, N, x), mk(M, N, x, x), mk(M, N, u, x)]
+            res, infos, last_in_out, done = solver.scp_loop(mid, d["params"], steps, f=bufs[0], fx=bufs[1], fu=bufs[2], f2=bufs[3], fx2=bufs[4],
+                                                            fu2=bufs[5], X_prev=Xa, U_prev=Ua, X_out=Xb, U_out=Ub, first_cold=True, cone_objective=True,
+                                                            **common)
+            solver.sync()
+            assert done == steps and all(i["status"] == 0 for i in infos), infos
+            X_lib, U_lib = (Xb, Ub) if last_in_out else (Xa, Ua)
+            outs.append((res.cpu().numpy(), X_lib.clone(), U_lib.clone()))
+        solver.close()
+    # (same sequence; not bit for bit: a point whose epigraph rows are consistent to the 1e-9 of the acceptance test is accepted on
+    #  either path, and the two reach it through different launch sequences)
+    np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6, atol=1e-9)
+    assert torch.allclose(outs[1][1], outs[0][1], rtol=0, atol=1e-6) and torch.allclose(outs[1][2], outs[0][2], rtol=0, atol=1e-6)
