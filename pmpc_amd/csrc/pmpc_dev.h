@@ -340,6 +340,17 @@ void launch_soc_update(const SocArgs &a, double alpha, double *X, const double *
                        long long nu, long long ncz, hipStream_t s);
 void launch_soc_fill_u(double *U, const double *u0, long long tot, int u, hipStream_t s);
 
+// ---- kernels_epi.hip (cone objective with log-barrier smoothing: elementwise passes of the full-space Newton iteration) -------------
+void launch_bar_prep(const double *X, const double *U, const double *lx, const double *ux, const double *lu, const double *uu, double *Dx, double *wx,
+                     double *Du, double *wu, double mu, long long nx, long long nu, int u, int N, int Nc, int owner, double *part_val, double *part_min,
+                     double *out2, hipStream_t s);  // out2 = {barrier value, smallest slack}
+void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2, const double *dU2,
+                      double *out, hipStream_t s);  // per particle {grad J . d1, grad J . d2, d1' hess J d1}
+void launch_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot, hipStream_t s);
+void launch_step_to(const double *a_, const double *b_, double alpha, double *y, long long tot, hipStream_t s);
+void launch_interior(double *U, const double *lo, const double *hi, long long tot, double frac, hipStream_t s);
+void launch_share_cons(double *U, int M, int N, int u, int Nc, hipStream_t s);  // consensus stages: particle 0's controls in every particle
+
 // ---- dynamics.hip -------------------------------------------------------------------------------
 // slew penalties on the MFMA path: the problem restated in control increments (kernels_slew.hip)
 struct SlewAug {

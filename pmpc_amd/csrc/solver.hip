@@ -142,7 +142,9 @@ struct SlabBufs {
 
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
-  DevBuf Hc_w, gc_w, cons_w, epi_lam, epi_out;  // consensus weights of the cone objective and the scaled copies the reductions read
+  DevBuf Hc_w, gc_w, cons_w, epi_lam, epi_out;
+  DevBuf es_Dx, es_wx, es_Du, es_wu, es_xm, es_xd, es_um, es_ud, es_kff2, es_kff3, es_gc2, es_dots, es_coef, es_out2, es_Xt, es_Ut, es_U, es_zero;  // smoothed cone objective (lcone_smooth_body)
+  long long es_key = -1;  // consensus weights of the cone objective and the scaled copies the reductions read
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
   DevBuf pw, Jc, Jg;  // cone path: particle weights / particle costs (local, gathered)
   DevBuf soc_zl, soc_zu, soc_zc, soc_dzl, soc_dzu, soc_dzc, soc_sl, soc_su, soc_sc, soc_dsl, soc_dsu, soc_dsc;
@@ -519,7 +521,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   if (c->comm && c->mock_comm) delete (MockRank *)c->comm;
   else if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.epi_lam, &w.epi_out, &w.scratch,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.epi_lam, &w.epi_out, &w.es_Dx, &w.es_wx, &w.es_Du, &w.es_wu, &w.es_xm, &w.es_xd, &w.es_um, &w.es_ud, &w.es_kff2, &w.es_kff3, &w.es_gc2, &w.es_dots, &w.es_coef, &w.es_out2, &w.es_Xt, &w.es_Ut, &w.es_U, &w.es_zero, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
@@ -2144,6 +2146,327 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
     return fail_after_error(c, p, info);
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// cone objective WITH log-barrier smoothing (main.jl:246-262): proximal method of multipliers on the epigraph rows, damped Newton in
+// the full space (kernels_epi.hip).  Any number of particles on the threshold — with the barrier a particle's optimum given the shared
+// controls depends on its multiplier, so every particle whose cost range brackets the threshold carries a fractional multiplier.
+//   F(z, t; lam) = (1 - eps) k t + sum_i psi(J_i(z_i) - t; lam_i) - mu_b sum log(slack),  psi(v; l) = max over m in [0, 1 + eps] of  m v - rho/2 (m - l)^2
+// Newton step: per particle the Hessian  m_i grad^2 J_i + grad^2 B_i  (one Riccati factor sweep with cost weight m_i and the barrier
+// diagonals) plus, for a row with m_i strictly inside, the rank-one term (1/rho) (grad J_i; -1)(grad J_i; -1)' coupling its variables
+// to t: a second sweep with the right-hand side grad J_i gives v_i = K^-1 grad J_i, its condensed gradient and kappa_i = grad J_i' v_i,
+// and Sherman-Morrison folds the term into the (Nc u + 1)-dimensional system of the shared controls and t, assembled on the host from
+// per-particle scalars.  Returns -1 when the problem is outside what this path covers (the caller takes the weighted-QP iteration).
+// -------------------------------------------------------------------------------------------------
+static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pmpc_info *info, int verbose) {
+  Workspace &w = c->ws;
+  hipStream_t s = c->stream;
+  const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
+  const int Nc = p->Nc < 0 ? N : (int)std::min<long long>(p->Nc, (long long)N), nc = Nc * u;
+  const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
+  if (c->multi() || c->world != 1 || p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || Nc > 1 || M < 2 ||
+      !(has_xb || has_ub) || !(mu_b > 0.0))
+    return -1;
+  const size_t nx = (size_t)M * N * x, nu = (size_t)M * N * u, D8 = sizeof(double);
+  LQArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.u = u; a.N = N; a.M = M; a.Nc = Nc; a.w = 0; a.n = x;
+  a.reg_x = p->reg_x; a.reg_u = p->reg_u;
+  a.f = p->f; a.fx = p->fx; a.fu = p->fu; a.Q = p->Q; a.R = p->R;
+  a.X_prev = p->X_prev; a.U_prev = p->U_prev; a.X_ref = p->X_ref; a.U_ref = p->U_ref;
+  a.owner = 1; a.any_slew = 0; a.sym_cost = (p->flags & PMPC_SYMMETRIC_COST) ? 1 : 0;
+  if (!lq_fast_supported(a)) return -1;
+  const double eps = 1e-3, cap = 1.0 + eps;
+  const double kk = (p->cone_k > 0 && p->cone_k < (long long)M) ? (double)p->cone_k : (double)M, K = (1.0 - eps) * kk;
+  // workspace
+  w.X.ensure(nx * D8); w.U.ensure(nu * D8); w.dX.ensure(nx * D8); w.dU.ensure(nu * D8); w.dX2.ensure(nx * D8); w.dU2.ensure(nu * D8);
+  w.xm.ensure(nx * D8); w.xd.ensure(nx * D8); w.um.ensure(nu * D8); w.ud.ensure(nu * D8);
+  w.es_xm.ensure(nx * D8); w.es_xd.ensure(nx * D8); w.es_um.ensure(nu * D8); w.es_ud.ensure(nu * D8);
+  w.es_Dx.ensure(nx * D8); w.es_wx.ensure(nx * D8); w.es_Du.ensure(nu * D8); w.es_wu.ensure(nu * D8);
+  w.es_Xt.ensure(nx * D8); w.es_Ut.ensure(nu * D8);
+  w.K.ensure((size_t)M * N * 64 * D8); w.Hinv.ensure(nu * u * D8);
+  w.kff.ensure(nu * D8); w.es_kff2.ensure(nu * D8); w.es_kff3.ensure(nu * D8);
+  w.gc_part.ensure((size_t)M * std::max(nc, 1) * D8); w.es_gc2.ensure((size_t)M * std::max(nc, 1) * D8); w.Hc_part.ensure((size_t)M * std::max(nc * nc, 1) * D8);
+  w.scratch.ensure((size_t)M * 3 * x * std::max(nc, 1) * D8);
+  w.es_dots.ensure((size_t)3 * M * D8); w.es_coef.ensure((size_t)M * D8); w.es_out2.ensure(2 * D8); w.pw.ensure((size_t)M * D8); w.Jc.ensure((size_t)M * D8);
+  w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_max.ensure(2 * PMPC_RED_BLOCKS * D8);
+  w.duc.ensure((size_t)std::max(nc, 1) * D8); w.fail.ensure(sizeof(int));
+  if (w.es_zero.ensure(64 * D8)) HIP_CHECK(hipMemsetAsync(w.es_zero.p, 0, 64 * D8, s));
+  if (w.zeros.bytes == 0) {
+    w.zeros.ensure(64 * D8);
+    HIP_CHECK(hipMemsetAsync(w.zeros.p, 0, 64 * D8, s));
+  }
+  if (w.zslew.bytes < (size_t)M * D8 || w.zum1.bytes < (size_t)M * u * D8) {
+    w.zslew.ensure((size_t)M * D8); w.zslew0.ensure((size_t)M * D8); w.zum1.ensure((size_t)M * u * D8);
+    HIP_CHECK(hipMemsetAsync(w.zslew.p, 0, (size_t)M * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, (size_t)M * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, (size_t)M * u * D8, s));
+  }
+  a.slew = w.zslew.d(); a.slew0 = w.zslew0.d(); a.um1 = w.zum1.d();
+  a.zeros = w.zeros.d();
+  a.K = w.K.d(); a.Hinv = w.Hinv.d(); a.kff = w.kff.d(); a.gc_part = w.gc_part.d(); a.Hc_part = w.Hc_part.d(); a.scratch = w.scratch.d();
+  a.duc = w.es_zero.d(); a.dX = w.dX.d(); a.dU = w.dU.d(); a.fail = (int *)w.fail.p; a.X = w.X.d(); a.U = w.U.d();
+  a.xm = w.xm.d(); a.xd = w.xd.d(); a.um = w.um.d(); a.ud = w.ud.d();
+  a.pw = w.pw.d();
+  a.Dx = has_xb ? w.es_Dx.d() : nullptr; a.wx = has_xb ? w.es_wx.d() : nullptr;
+  a.Du = has_ub ? w.es_Du.d() : nullptr; a.wu = has_ub ? w.es_wu.d() : nullptr;
+  w.as_key = -1;  // (the workspace's factor records and warm-start memories of the QP path are overwritten)
+  w.warm_key = -1;
+  pmpc_info inf;
+  memset(&inf, 0, sizeof(inf));
+  inf.fast_path = 1;
+  auto finish = [&](int status) {
+    inf.status = status;
+    if (status == 0) {
+      HIP_CHECK(hipMemcpyAsync(p->X_out, w.X.p, nx * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(p->U_out, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+    } else {
+      fill_nan_outputs(c, p);
+      w.es_key = -1;
+      c->cone_lam_key = -1;
+    }
+    if (info) *info = inf;
+    return status;
+  };
+  // ---- host pieces ---------------------------------------------------------------------------------------------------------
+  std::vector<double> J(M), Jt(M), lam(M, K / (double)M), mu(M), sig(M), coef(M), Hh((size_t)M * std::max(nc * nc, 1)), gb((size_t)M * std::max(nc, 1)),
+      ga((size_t)M * std::max(nc, 1)), dots((size_t)3 * M);
+  double rho = 1.0, out2[2] = {0.0, 0.0};
+  auto clipm = [&](double v) { return v < 0.0 ? 0.0 : (v > cap ? cap : v); };
+  auto solve_t = [&](const std::vector<double> &Jv) {  // sum_i clip(lam_i + (J_i - t) / rho) = K  (continuous, non-increasing in t)
+    double lo = 1e300, hi = -1e300;
+    for (int i = 0; i < M; i++) { lo = std::min(lo, Jv[i] + rho * (lam[i] - cap)); hi = std::max(hi, Jv[i] + rho * lam[i]); }
+    lo -= 1.0; hi += 1.0;
+    for (int it = 0; it < 200 && hi - lo > 1e-15 * std::max(1.0, std::fabs(lo) + std::fabs(hi)); it++) {
+      const double mid = 0.5 * (lo + hi);
+      double sm = 0.0;
+      for (int i = 0; i < M; i++) sm += clipm(lam[i] + (Jv[i] - mid) / rho);
+      if (sm > K) lo = mid; else hi = mid;
+    }
+    const double tm = 0.5 * (lo + hi);
+    double num = 0.0, ncap = 0.0;
+    int nun = 0;
+    for (int i = 0; i < M; i++) {
+      const double xx = lam[i] + (Jv[i] - tm) / rho;
+      if (xx >= cap) ncap += 1.0;
+      else if (xx > 0.0) { num += lam[i] * rho + Jv[i]; nun++; }
+    }
+    if (nun == 0) return tm;
+    const double tt = (num + rho * (cap * ncap - K)) / nun;
+    return (tt >= lo - 1e-9 * std::max(1.0, std::fabs(tm)) && tt <= hi + 1e-9 * std::max(1.0, std::fabs(tm))) ? tt : tm;
+  };
+  auto Fval = [&](const std::vector<double> &Jv, double t, double bval) {
+    double f = K * t + bval;
+    for (int i = 0; i < M; i++) {
+      const double v = Jv[i] - t, m = clipm(lam[i] + v / rho);
+      f += m * v - 0.5 * rho * (m - lam[i]) * (m - lam[i]);
+    }
+    return f;
+  };
+  // barrier terms + particle costs at (Xe, Ue): -> Jv, out2 = {barrier value, smallest slack}
+  auto eval_at = [&](const double *Xe, const double *Ue, std::vector<double> &Jv) {
+    launch_bar_prep(Xe, Ue, has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
+                    w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s);
+    launch_particle_cost(a, Xe, Ue, w.Jc.d(), s);
+    HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(Jv.data(), w.Jc.p, (size_t)M * D8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  };
+  // ---- starting point: the previous smoothed solution of this shape (strictly inside the same boxes), else the caller's U_prev pulled inside ----
+  const long long skey = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
+  bool warm = !(p->flags & PMPC_COLD_START) && w.es_key == skey && w.es_U.bytes >= nu * D8;
+  const bool lam_mem = c->opt[OPT_CONE_RANK_MEMORY] != 0.0 && !(p->flags & PMPC_COLD_START) && c->cone_lam_key == -(skey + 7) && (int)c->cone_lam.size() == M;
+  if (lam_mem) lam = c->cone_lam;
+  c->cone_lam_key = -1;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (warm) {
+      HIP_CHECK(hipMemcpyAsync(w.U.p, w.es_U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+    } else {
+      HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_prev, nu * D8, hipMemcpyDeviceToDevice, s));
+      if (has_ub) launch_interior(w.U.d(), p->lu, p->uu, (long long)nu, 0.05, s);
+    }
+    launch_share_cons(w.U.d(), M, N, u, Nc, s);
+    launch_rollout_fast(a, w.U.d(), w.X.d(), s);
+    eval_at(w.X.d(), w.U.d(), J);
+    if (out2[1] > 0.0 && out2[0] == out2[0]) break;
+    if (warm) { warm = false; continue; }
+    if (verbose) printf("pmpc_hip: smoothed cone objective: no strictly feasible start (smallest slack %.3e)\n", out2[1]);
+    return finish(1);
+  }
+  w.es_key = -1;
+  {
+    double jlo = 1e300, jhi = -1e300;
+    for (int i = 0; i < M; i++) { jlo = std::min(jlo, J[i]); jhi = std::max(jhi, J[i]); }
+    rho = 1e-6 * std::max(1.0, std::max(std::fabs(jlo), std::fabs(jhi)));
+  }
+  double bval = out2[0], t = solve_t(J), Fcur = Fval(J, t, bval);
+  int newton = 0;
+  bool converged = false;
+  for (int outer = 0; outer < 40 && !converged; outer++) {
+    bool inner_ok = false;
+    for (int it = 0; it < 80; it++) {
+      t = solve_t(J);
+      Fcur = Fval(J, t, bval);
+      double summu = 0.0;
+      for (int i = 0; i < M; i++) {
+        const double xx = lam[i] + (J[i] - t) / rho;
+        mu[i] = clipm(xx);
+        sig[i] = (xx > 0.0 && xx < cap) ? 1.0 / rho : 0.0;
+        summu += mu[i];
+        coef[i] = std::max(mu[i], 1e-8);  // (cost weight of the sweeps: a particle of multiplier zero keeps a strictly convex sub-problem)
+      }
+      HIP_CHECK(hipMemcpyAsync(w.pw.p, coef.data(), (size_t)M * D8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
+      // right-hand side b: gradient of sum m_i J_i + barrier (the barrier arrays were written by the last eval_at at this point)
+      launch_grad_prep(a, s);
+      launch_bwd_fast(a, true, s);
+      launch_fwd_fast(a, s);  // (duc = 0: the particles' own Newton steps p_b, in dX / dU)
+      // right-hand side a_i = grad J_i (unweighted, no barrier shift), same Hessian
+      LQArgs ag = a;
+      ag.pw = nullptr; ag.wx = ag.wu = nullptr;
+      ag.xm = w.es_xm.d(); ag.xd = w.es_xd.d(); ag.um = w.es_um.d(); ag.ud = w.es_ud.d();
+      launch_grad_prep(ag, s);
+      LQArgs a2 = a;
+      a2.xm = ag.xm; a2.xd = ag.xd; a2.um = ag.um; a2.ud = ag.ud;
+      a2.kff = w.es_kff2.d(); a2.gc_part = w.es_gc2.d(); a2.dX = w.dX2.d(); a2.dU = w.dU2.d();
+      launch_bwd_fast(a2, true, s);
+      launch_fwd_fast(a2, s);  // -> -v_i = -K^-1 grad J_i in dX2 / dU2
+      launch_cost_dots(a, w.X.d(), w.U.d(), w.dX2.d(), w.dU2.d(), w.dX.d(), w.dU.d(), w.es_dots.d(), s);
+      int failflag = 0;
+      if (nc > 0) {
+        HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, (size_t)M * nc * nc * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(gb.data(), w.gc_part.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(ga.data(), w.es_gc2.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+      }
+      HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      inf.structured_solves += 2;
+      if (failflag) {
+        if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep failed (flag %d)\n", failflag);
+        return finish(2);
+      }
+      // (nc + 1) system of the shared controls and t
+      const int n1 = nc + 1;
+      std::vector<double> A((size_t)n1 * n1, 0.0), rhs(n1, 0.0), sol(n1, 0.0), sp(M), kap(M), pi_(M);
+      double cc = 0.0;
+      for (int i = 0; i < M; i++) {
+        kap[i] = std::max(0.0, -dots[3 * i]);
+        pi_[i] = dots[3 * i + 1];
+        sp[i] = sig[i] / (1.0 + sig[i] * kap[i]);
+        const double *Hi = &Hh[(size_t)i * nc * nc], *gbi = &gb[(size_t)i * nc], *gai = &ga[(size_t)i * nc];
+        for (int r = 0; r < nc; r++) {
+          for (int q_ = 0; q_ < nc; q_++) A[r + (size_t)n1 * q_] += Hi[(r <= q_ ? r : q_) + (size_t)nc * (r <= q_ ? q_ : r)] + sp[i] * gai[r] * gai[q_];
+          A[r + (size_t)n1 * nc] -= sp[i] * gai[r];
+          A[nc + (size_t)n1 * r] -= sp[i] * gai[r];
+          rhs[r] -= gbi[r] + sp[i] * pi_[i] * gai[r];
+        }
+        cc += sp[i];
+        rhs[nc] += sp[i] * pi_[i];
+      }
+      rhs[nc] -= K - summu;
+      A[nc + (size_t)n1 * nc] = cc > 0.0 ? cc : 1.0;  // (no row strictly inside: t stays — it is re-optimised exactly at the next point)
+      if (!(cc > 0.0)) {
+        rhs[nc] = 0.0;
+        for (int r = 0; r < nc; r++) A[r + (size_t)n1 * nc] = A[nc + (size_t)n1 * r] = 0.0;
+      }
+      {  // Gaussian elimination with partial pivoting (the matrix is positive definite; n1 <= 5 on this path)
+        std::vector<double> Mx = A;
+        sol = rhs;
+        for (int k = 0; k < n1; k++) {
+          int pv = k;
+          for (int r = k + 1; r < n1; r++)
+            if (std::fabs(Mx[r + (size_t)n1 * k]) > std::fabs(Mx[pv + (size_t)n1 * k])) pv = r;
+          if (pv != k) {
+            for (int q_ = 0; q_ < n1; q_++) std::swap(Mx[k + (size_t)n1 * q_], Mx[pv + (size_t)n1 * q_]);
+            std::swap(sol[k], sol[pv]);
+          }
+          const double d = Mx[k + (size_t)n1 * k];
+          if (!(std::fabs(d) > 0.0)) return finish(2);
+          for (int r = k + 1; r < n1; r++) {
+            const double fct = Mx[r + (size_t)n1 * k] / d;
+            for (int q_ = k; q_ < n1; q_++) Mx[r + (size_t)n1 * q_] -= fct * Mx[k + (size_t)n1 * q_];
+            sol[r] -= fct * sol[k];
+          }
+        }
+        for (int k = n1 - 1; k >= 0; k--) {
+          double v = sol[k];
+          for (int q_ = k + 1; q_ < n1; q_++) v -= Mx[k + (size_t)n1 * q_] * sol[q_];
+          sol[k] = v / Mx[k + (size_t)n1 * k];
+        }
+      }
+      const double dt = sol[nc];
+      for (int i = 0; i < M; i++) {
+        double e_ = pi_[i] - dt;
+        for (int r = 0; r < nc; r++) e_ += ga[(size_t)i * nc + r] * sol[r];
+        coef[i] = sig[i] * e_ / (1.0 + sig[i] * kap[i]);
+      }
+      // total direction: feed-forward k_b + c_i k_a, shared step du_c
+      HIP_CHECK(hipMemcpyAsync(w.es_coef.p, coef.data(), (size_t)M * D8, hipMemcpyHostToDevice, s));
+      if (nc > 0) HIP_CHECK(hipMemcpyAsync(w.duc.p, sol.data(), (size_t)nc * D8, hipMemcpyHostToDevice, s));
+      launch_axpy_particle(w.kff.d(), w.es_kff2.d(), w.es_coef.d(), w.es_kff3.d(), (long long)N * u, (long long)nu, s);
+      LQArgs a3 = a;
+      a3.kff = w.es_kff3.d(); a3.duc = nc > 0 ? w.duc.d() : w.es_zero.d();
+      launch_fwd_fast(a3, s);  // -> direction in dX / dU
+      newton++;
+      // backtracking: stay strictly inside the boxes, do not increase F (t re-optimised at every trial point)
+      double al = 1.0, Ft = 0.0, tt = t, bt = 0.0;
+      bool accepted = false;
+      for (int ls = 0; ls < 40; ls++) {
+        launch_step_to(w.X.d(), w.dX.d(), al, w.es_Xt.d(), (long long)nx, s);
+        launch_step_to(w.U.d(), w.dU.d(), al, w.es_Ut.d(), (long long)nu, s);
+        eval_at(w.es_Xt.d(), w.es_Ut.d(), Jt);
+        if (out2[1] > 0.0 && out2[0] == out2[0]) {
+          bt = out2[0];
+          tt = solve_t(Jt);
+          Ft = Fval(Jt, tt, bt);
+          if (Ft <= Fcur + 1e-13 * std::max(1.0, std::fabs(Fcur))) { accepted = true; break; }
+        }
+        al *= 0.5;
+      }
+      if (!accepted) {
+        // no decrease along the Newton direction: at the precision floor of F if the last decrease was already round-off, else a failure
+        eval_at(w.X.d(), w.U.d(), J);  // (restores the barrier arrays of the current point)
+        if (verbose) printf("pmpc_hip: smoothed cone objective: line search found no decrease (Newton step %d)\n", newton);
+        inner_ok = true;
+        break;
+      }
+      // step size in the residual's own measure (largest stage-wise 2-norm of the change)
+      const double dF = Fcur - Ft;
+      HIP_CHECK(hipMemcpyAsync(w.X.p, w.es_Xt.p, nx * D8, hipMemcpyDeviceToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(w.U.p, w.es_Ut.p, nu * D8, hipMemcpyDeviceToDevice, s));
+      J = Jt; bval = bt; t = tt; Fcur = Ft;
+      if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d Newton %d  alpha %.4f  F %.12e  decrease %.3e  t %.9e  rows inside %d\n", outer + 1, newton, al, Fcur, dF,
+                          t, (int)std::count_if(sig.begin(), sig.end(), [](double v) { return v > 0.0; }));
+      if (al == 1.0 && dF <= 1e-13 * std::max(1.0, std::fabs(Fcur))) { inner_ok = true; break; }
+    }
+    // multiplier update of the proximal method
+    t = solve_t(J);
+    double dl = 0.0;
+    for (int i = 0; i < M; i++) {
+      const double m = clipm(lam[i] + (J[i] - t) / rho);
+      dl = std::max(dl, std::fabs(m - lam[i]));
+      lam[i] = m;
+    }
+    if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d done (%d Newton steps so far), multiplier change %.3e%s\n", outer + 1, newton, dl, inner_ok ? "" : " (inner limit)");
+    Fcur = Fval(J, solve_t(J), bval);
+    if (inner_ok && dl <= 1e-9 * cap) converged = true;
+  }
+  inf.ipm_iters = newton;
+  inf.outer_solves = newton;
+  inf.mu = mu_b;
+  if (!converged) {
+    if (verbose) printf("pmpc_hip: smoothed cone objective: not converged\n");
+    return finish(1);
+  }
+  w.es_U.ensure(nu * D8);
+  HIP_CHECK(hipMemcpyAsync(w.es_U.p, w.U.p, nu * D8, hipMemcpyDeviceToDevice, s));
+  w.es_key = skey;
+  c->cone_lam = lam;
+  c->cone_lam_key = -(skey + 7);
+  return finish(0);
+}
+
 static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, pmpc_info *info, int verbose) {
   HIP_CHECK(hipSetDevice(c->device));
   Workspace &w = c->ws;
@@ -2194,6 +2517,11 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
   q.weights = w.pw.d();
   // smooth_cstr = "logbarrier" (main.jl:246-262): -1/alpha sum log(alpha slack) replaces the hard boxes
   q.barrier_mu = (smooth_alpha == smooth_alpha && smooth_alpha > 0.0) ? 1.0 / smooth_alpha : 0.0;
+  if (q.barrier_mu > 0.0 && !(p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS))) q.barrier_mu = 0.0;  // (no boxes: nothing to smooth, main.jl:248)
+  if (q.barrier_mu > 0.0 && c->opt[OPT_CONE_EPIGRAPH] != 0.0 && M > 1) {
+    const int st_s = lcone_smooth_body(c, p, q.barrier_mu, info, verbose);
+    if (st_s >= 0) return st_s;
+  }
   pmpc_info inf, last;
   memset(&last, 0, sizeof(last));
   int outer = 0, solves_total = 0, ipm_total = 0;

@@ -143,3 +143,41 @@ def test_library_scp_loop_drives_the_cone_objective(model, M, N, Nc, steps):
     #  either path, and the two reach it through different launch sequences)
     np.testing.assert_allclose(outs[1][0], outs[0][0], rtol=1e-6, atol=1e-9)
     assert torch.allclose(outs[1][1], outs[0][1], rtol=0, atol=1e-6) and torch.allclose(outs[1][2], outs[0][2], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("copies,others,alpha,dims", [(3, 3, 10.0, (6, 4, 2)), (5, 3, 10.0, (6, 4, 2)), (9, 4, 1.0, (6, 4, 2)), (3, 3, 100.0, (6, 4, 2)), (3, 2, 10.0, (5, 12, 4))])
+def test_logbarrier_smoothing_with_ties(co, copies, others, alpha, dims):
+    """Smoothed boxes (main.jl:246-262) and several particles on the threshold: with the barrier every particle whose cost range brackets
+    the threshold carries a fractional multiplier — the full-space Newton iteration of lcone_smooth_body against the direct program."""
+    from pmpc_amd import backend
+
+    N, x, u = dims
+    args, kw = tied_problem(np.random.default_rng(300 * copies + others + x), copies, others, N, x, u, 0.4, 1)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=1, smooth_alpha=alpha, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, 1), smooth_alpha=alpha, solver="ecos")
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(U))
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+    for i in range(1, copies):
+        assert np.abs(X[i] - X[0]).max() <= 1e-8 and np.abs(U[i] - U[0]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("seed,M,alpha", [(1, 12, 10.0), (2, 20, 1.0), (3, 8, 100.0)])
+def test_logbarrier_smoothing_random_particles_match_the_direct_program(co, seed, M, alpha):
+    from pmpc_amd import backend
+
+    args, kw = rand_problem(np.random.default_rng(950 + seed), M, 6, 4, 2, 0.4)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=1, smooth_alpha=alpha, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, 1), smooth_alpha=alpha, solver="ecos")
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+
+
+def test_logbarrier_smoothing_all_particles_identical(co):
+    from pmpc_amd import backend
+
+    M, N, x, u = 6, 6, 4, 2
+    a1, kw = rand_problem(np.random.default_rng(21), 1, N, x, u, 0.4)
+    args = tuple(np.repeat(np.asarray(a), M, axis=0) for a in a1)
+    kwM = {k: (np.repeat(v, M, axis=0) if isinstance(v, np.ndarray) and v.ndim and v.shape[0] == 1 else v) for k, v in kw.items()}
+    Xo, Uo = co.lcone_direct_py(*args, Nc=1, smooth_alpha=10.0, **kwM)
+    X, U = backend.lcone_solve(*abi_args(args, kwM, 1), smooth_alpha=10.0, solver="ecos")
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
