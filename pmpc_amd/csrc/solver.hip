@@ -218,6 +218,7 @@ struct pmpc_ctx {
   long long cone_rw_key = -1;
   std::vector<double> cone_lam;  // cone objective in the shared-control space: multipliers of the epigraph rows the last solve settled on
   long long cone_lam_key = -1;
+  double cone_rho = 0.0;  // proximal parameter the smoothed cone objective ended with (next solve of the shape starts there)
   std::vector<double> cons_w_host, epi_lam_host;  // what the device copies of the consensus weights / multipliers hold
   const double *cons_w_active = nullptr;  // consensus weights of the sub-problem solves lcone_body issues (LQArgs::cons_w)
   int xb_ctrl_from = -1;  // set around the inner solve of the slew increment form: state entries from this index on are the controls (their boxes the control boxes)
@@ -2229,39 +2230,45 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     return status;
   };
   // ---- host pieces ---------------------------------------------------------------------------------------------------------
-  std::vector<double> J(M), Jt(M), lam(M, K / (double)M), mu(M), sig(M), coef(M), Hh((size_t)M * std::max(nc * nc, 1)), gb((size_t)M * std::max(nc, 1)),
+  std::vector<double> J(M), Jt(M), lam(M, std::log((K / (double)M) / (cap - K / (double)M))), mu(M), sig(M), coef(M), Hh((size_t)M * std::max(nc * nc, 1)), gb((size_t)M * std::max(nc, 1)),
       ga((size_t)M * std::max(nc, 1)), dots((size_t)3 * M);
   double rho = 1.0, out2[2] = {0.0, 0.0};
-  auto clipm = [&](double v) { return v < 0.0 ? 0.0 : (v > cap ? cap : v); };
-  auto solve_t = [&](const std::vector<double> &Jv) {  // sum_i clip(lam_i + (J_i - t) / rho) = K  (continuous, non-increasing in t)
+  // Entropic proximal term (exponential method of multipliers for multipliers boxed in [0, cap]): with l_i = logit(lam_i / cap)
+  //   m_i(v) = cap * sigmoid(l_i + v / rho),   psi(v; l_i) = rho cap [softplus(l_i + v / rho) - softplus(l_i)],   psi'' = m (cap - m) / (rho cap) > 0:
+  // every row carries a rank-one term, F is smooth (the quadratic proximal term's clipping makes its second derivative jump between 0
+  // and 1/rho — at config D the semismooth Newton iteration then flips a handful of rows in and out of the hinge for ever), and the
+  // update l_i += v_i / rho sends the multiplier of a row below the threshold to zero geometrically.  `lam` holds the logits.
+  auto sigm = [](double w_) { return w_ >= 0.0 ? 1.0 / (1.0 + std::exp(-w_)) : std::exp(w_) / (1.0 + std::exp(w_)); };
+  auto softplus = [](double w_) { return w_ > 0.0 ? w_ + std::log1p(std::exp(-w_)) : std::log1p(std::exp(w_)); };
+  auto mult = [&](int i, const std::vector<double> &Jv, double t) { return cap * sigm(lam[i] + (Jv[i] - t) / rho); };
+  double t_guess = std::numeric_limits<double>::quiet_NaN();
+  auto solve_t = [&](const std::vector<double> &Jv) {  // sum_i m_i(J_i - t) = K  (smooth, strictly decreasing in t): safeguarded Newton
     double lo = 1e300, hi = -1e300;
-    for (int i = 0; i < M; i++) { lo = std::min(lo, Jv[i] + rho * (lam[i] - cap)); hi = std::max(hi, Jv[i] + rho * lam[i]); }
-    lo -= 1.0; hi += 1.0;
-    for (int it = 0; it < 200 && hi - lo > 1e-15 * std::max(1.0, std::fabs(lo) + std::fabs(hi)); it++) {
-      const double mid = 0.5 * (lo + hi);
-      double sm = 0.0;
-      for (int i = 0; i < M; i++) sm += clipm(lam[i] + (Jv[i] - mid) / rho);
-      if (sm > K) lo = mid; else hi = mid;
+    for (int i = 0; i < M; i++) { const double c0 = Jv[i] + rho * lam[i]; lo = std::min(lo, c0); hi = std::max(hi, c0); }
+    lo -= 50.0 * rho + 1.0; hi += 50.0 * rho + 1.0;
+    double tt = (t_guess == t_guess && t_guess > lo && t_guess < hi) ? t_guess : 0.5 * (lo + hi);
+    for (int it = 0; it < 200; it++) {
+      double sm = 0.0, ds = 0.0;
+      for (int i = 0; i < M; i++) {
+        const double m = mult(i, Jv, tt);
+        sm += m;
+        ds += m * (cap - m);
+      }
+      const double S = sm - K;
+      if (S > 0.0) lo = tt; else hi = tt;
+      if (std::fabs(S) <= 1e-13 * K || hi - lo <= 1e-15 * std::max(1.0, std::fabs(lo) + std::fabs(hi))) break;
+      ds /= rho * cap;  // = -dS/dt
+      double tn = ds > 0.0 ? tt + S / ds : 0.5 * (lo + hi);
+      if (!(tn > lo && tn < hi)) tn = 0.5 * (lo + hi);
+      tt = tn;
     }
-    const double tm = 0.5 * (lo + hi);
-    double num = 0.0, ncap = 0.0;
-    int nun = 0;
-    for (int i = 0; i < M; i++) {
-      const double xx = lam[i] + (Jv[i] - tm) / rho;
-      if (xx >= cap) ncap += 1.0;
-      else if (xx > 0.0) { num += lam[i] * rho + Jv[i]; nun++; }
-    }
-    if (nun == 0) return tm;
-    const double tt = (num + rho * (cap * ncap - K)) / nun;
-    return (tt >= lo - 1e-9 * std::max(1.0, std::fabs(tm)) && tt <= hi + 1e-9 * std::max(1.0, std::fabs(tm))) ? tt : tm;
+    t_guess = tt;
+    return tt;
   };
   auto Fval = [&](const std::vector<double> &Jv, double t, double bval) {
-    double f = K * t + bval;
-    for (int i = 0; i < M; i++) {
-      const double v = Jv[i] - t, m = clipm(lam[i] + v / rho);
-      f += m * v - 0.5 * rho * (m - lam[i]) * (m - lam[i]);
-    }
-    return f;
+    double f = 0.0;
+    for (int i = 0; i < M; i++) f += softplus(lam[i] + (Jv[i] - t) / rho) - softplus(lam[i]);
+    return K * t + bval + rho * cap * f;
   };
   // barrier terms + particle costs at (Xe, Ue): -> Jv, out2 = {barrier value, smallest slack}
   auto eval_at = [&](const double *Xe, const double *Ue, std::vector<double> &Jv) {
@@ -2299,19 +2306,30 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     for (int i = 0; i < M; i++) { jlo = std::min(jlo, J[i]); jhi = std::max(jhi, J[i]); }
     rho = 1e-6 * std::max(1.0, std::max(std::fabs(jlo), std::fabs(jhi)));
   }
+  // proximal parameter rho = width of the smoothed hinge in cost units.  The method converges for ANY rho (the multipliers are exact at
+  // its fixed point); a narrow hinge makes one multiplier update nearly exact but its inner problem nearly non-smooth — with few rows
+  // strictly inside, every Newton step crosses kinks and the line search cuts it to nothing (measured at config D: steps of 1e-4 below
+  // rho ~ 1e-3 max|J|) —, a wide one gives inner problems that settle in a few full steps and more multiplier updates.  Adaptive: start
+  // wide, narrow by 3 after an inner solve that took full steps, widen by 3 after one that was damped throughout.
+  const double rho_min = rho, rho_max = 1e5 * rho;
+  rho = lam_mem ? 3.0 * c->cone_rho : 1e4 * rho_min;
+  if (!(rho >= rho_min && rho <= rho_max)) rho = 1e4 * rho_min;
   double bval = out2[0], t = solve_t(J), Fcur = Fval(J, t, bval);
   int newton = 0;
   bool converged = false;
-  for (int outer = 0; outer < 40 && !converged; outer++) {
+  double dl_prev = 1e300, dl_last = 1e300, rho_floor = 0.0;
+  for (int outer = 0; outer < 500 && !converged; outer++) {
     bool inner_ok = false;
-    for (int it = 0; it < 80; it++) {
+    const bool last_stage = true;
+    const double step_tol = std::max(1e-9, std::min(1e-5, 1e-3 * dl_prev));  // (the inner problems are solved as sharply as the multipliers are known)
+    int n_damped = 0;
+    for (int it = 0; it < 25; it++) {
       t = solve_t(J);
       Fcur = Fval(J, t, bval);
       double summu = 0.0;
       for (int i = 0; i < M; i++) {
-        const double xx = lam[i] + (J[i] - t) / rho;
-        mu[i] = clipm(xx);
-        sig[i] = (xx > 0.0 && xx < cap) ? 1.0 / rho : 0.0;
+        mu[i] = mult(i, J, t);
+        sig[i] = mu[i] * (cap - mu[i]) / (rho * cap);
         summu += mu[i];
         coef[i] = std::max(mu[i], 1e-8);  // (cost weight of the sweeps: a particle of multiplier zero keeps a strictly convex sub-problem)
       }
@@ -2408,49 +2426,83 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       LQArgs a3 = a;
       a3.kff = w.es_kff3.d(); a3.duc = nc > 0 ? w.duc.d() : w.es_zero.d();
       launch_fwd_fast(a3, s);  // -> direction in dX / dU
+      // along the step the particle costs are EXACT quadratics in the step length: J_i(al) = J_i + al s_i + al^2/2 q_i with s_i = grad J_i . d,
+      // q_i = d' hess J_i d (one pass); only the barrier has to be evaluated at the trial points
+      launch_cost_dots(a, w.X.d(), w.U.d(), w.dX.d(), w.dU.d(), w.dX.d(), w.dU.d(), w.es_dots.d(), s);
+      launch_step_to(w.X.d(), w.dX.d(), 1.0, w.es_Xt.d(), (long long)nx, s);
+      launch_step_to(w.U.d(), w.dU.d(), 1.0, w.es_Ut.d(), (long long)nu, s);
+      launch_scp_residual(w.es_Xt.d(), w.X.d(), w.es_Ut.d(), w.U.d(), (long long)M * N, x, u, w.es_out2.d(), s, true);
+      double stepmax = 0.0;
+      HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(&stepmax, w.es_out2.p, D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
       newton++;
-      // backtracking: stay strictly inside the boxes, do not increase F (t re-optimised at every trial point)
+      auto bar_at = [&](const double *Xe, const double *Ue) {  // barrier arrays + value + smallest slack at a point
+        launch_bar_prep(Xe, Ue, has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
+                        w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s);
+        HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+      };
+      // backtracking: strictly inside the boxes, no increase of F beyond its round-off (t re-optimised at every trial point); a step
+      // that is already tiny is taken in full as soon as it is feasible — F cannot resolve it
+      const double f_noise = 1e-13 * std::max(1.0, std::fabs(Fcur)) * std::sqrt((double)M);
       double al = 1.0, Ft = 0.0, tt = t, bt = 0.0;
       bool accepted = false;
-      for (int ls = 0; ls < 40; ls++) {
-        launch_step_to(w.X.d(), w.dX.d(), al, w.es_Xt.d(), (long long)nx, s);
-        launch_step_to(w.U.d(), w.dU.d(), al, w.es_Ut.d(), (long long)nu, s);
-        eval_at(w.es_Xt.d(), w.es_Ut.d(), Jt);
+      for (int ls = 0; ls < 30; ls++) {
+        if (ls > 0) {
+          launch_step_to(w.X.d(), w.dX.d(), al, w.es_Xt.d(), (long long)nx, s);
+          launch_step_to(w.U.d(), w.dU.d(), al, w.es_Ut.d(), (long long)nu, s);
+        }
+        bar_at(w.es_Xt.d(), w.es_Ut.d());
         if (out2[1] > 0.0 && out2[0] == out2[0]) {
+          for (int i = 0; i < M; i++) Jt[i] = J[i] + al * (dots[3 * i] + 0.5 * al * dots[3 * i + 2]);
           bt = out2[0];
           tt = solve_t(Jt);
           Ft = Fval(Jt, tt, bt);
-          if (Ft <= Fcur + 1e-13 * std::max(1.0, std::fabs(Fcur))) { accepted = true; break; }
+          if (Ft <= Fcur + f_noise || stepmax * al <= 1e-7) { accepted = true; break; }
         }
         al *= 0.5;
       }
       if (!accepted) {
-        // no decrease along the Newton direction: at the precision floor of F if the last decrease was already round-off, else a failure
-        eval_at(w.X.d(), w.U.d(), J);  // (restores the barrier arrays of the current point)
-        if (verbose) printf("pmpc_hip: smoothed cone objective: line search found no decrease (Newton step %d)\n", newton);
-        inner_ok = true;
+        bar_at(w.X.d(), w.U.d());  // (restores the barrier arrays of the current point)
+        if (verbose) printf("pmpc_hip: smoothed cone objective: line search found no decrease (Newton step %d, step size %.3e)\n", newton, stepmax);
+        inner_ok = stepmax <= 1e-6;
         break;
       }
-      // step size in the residual's own measure (largest stage-wise 2-norm of the change)
       const double dF = Fcur - Ft;
       HIP_CHECK(hipMemcpyAsync(w.X.p, w.es_Xt.p, nx * D8, hipMemcpyDeviceToDevice, s));
       HIP_CHECK(hipMemcpyAsync(w.U.p, w.es_Ut.p, nu * D8, hipMemcpyDeviceToDevice, s));
       J = Jt; bval = bt; t = tt; Fcur = Ft;
-      if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d Newton %d  alpha %.4f  F %.12e  decrease %.3e  t %.9e  rows inside %d\n", outer + 1, newton, al, Fcur, dF,
-                          t, (int)std::count_if(sig.begin(), sig.end(), [](double v) { return v > 0.0; }));
-      if (al == 1.0 && dF <= 1e-13 * std::max(1.0, std::fabs(Fcur))) { inner_ok = true; break; }
+      if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d (rho %.1e) Newton %d  alpha %.4f  step %.3e  F %.12e  decrease %.3e  t %.9e  rows inside %d\n", outer + 1, rho,
+                          newton, al, stepmax * al, Fcur, dF, t, (int)std::count_if(mu.begin(), mu.end(), [&](double v) { return v > 1e-6 && v < cap - 1e-6; }));
+      if (al < 0.2) n_damped++;
+      if (al == 1.0 && stepmax <= step_tol) { inner_ok = true; break; }
+    }
+    if (!inner_ok) {  // the inner problem was not solved: the multipliers stay, the hinge widens (a smoother inner problem from the same point)
+      if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d: inner iteration limit at rho %.1e, widening\n", outer + 1, rho);
+      if (rho >= rho_max) break;
+      rho_floor = std::max(rho_floor, 3.0 * rho);
+      rho = std::min(rho_max, 10.0 * rho);
+      continue;
     }
     // multiplier update of the proximal method
     t = solve_t(J);
     double dl = 0.0;
     for (int i = 0; i < M; i++) {
-      const double m = clipm(lam[i] + (J[i] - t) / rho);
-      dl = std::max(dl, std::fabs(m - lam[i]));
-      lam[i] = m;
+      const double m_old = cap * sigm(lam[i]), m_new = mult(i, J, t);
+      dl = std::max(dl, std::fabs(m_new - m_old));
+      lam[i] = std::min(700.0, std::max(-700.0, lam[i] + (J[i] - t) / rho));
     }
     if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d done (%d Newton steps so far), multiplier change %.3e%s\n", outer + 1, newton, dl, inner_ok ? "" : " (inner limit)");
+    (void)last_stage;
+    if (inner_ok && step_tol <= 1e-9 * 1.0000001 && dl <= 1e-7 * cap) converged = true;
+    dl_prev = dl;
+    // (a sharper hinge makes the multiplier updates contract faster — wanted while they are far off or contracting slowly; never below a
+    //  width whose inner problem this solve has already failed to solve)
+    if (inner_ok && n_damped == 0 && (dl > 1e-2 * cap || dl > 0.3 * dl_last)) rho = std::max(std::max(rho_min, rho_floor), rho / 3.0);
+    else if (n_damped >= 3) rho = std::min(rho_max, 3.0 * rho);
+    dl_last = dl;
     Fcur = Fval(J, solve_t(J), bval);
-    if (inner_ok && dl <= 1e-9 * cap) converged = true;
   }
   inf.ipm_iters = newton;
   inf.outer_solves = newton;
@@ -2464,6 +2516,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   w.es_key = skey;
   c->cone_lam = lam;
   c->cone_lam_key = -(skey + 7);
+  c->cone_rho = rho;
   return finish(0);
 }
 
