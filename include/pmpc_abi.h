@@ -82,6 +82,11 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                            double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
                            long long verbose, double smooth_alpha, unsigned rowmajor, long long cone_k);
 /* (cone_k: the reference's `k` setting, see pmpc_problem.cone_k; <= 0 = M) */
+/* ... and with `smooth_cstr` (0 logbarrier, 1 squareplus) / `smooth_beta` (see pmpc_problem.smooth_cstr) */
+void pmpc_lcone_solve_host_ex(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc, double *x0, double *f,
+                              double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R, double *X_ref, double *U_ref, double *lx,
+                              double *ux, double *lu, double *uu, double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                              long long verbose, double smooth_alpha, unsigned rowmajor, long long cone_k, int smooth_cstr, double smooth_beta);
 
 /* ---------------------------------------------------------------------------------------------
  * Part 2 — device-resident extension
@@ -168,6 +173,11 @@ typedef struct pmpc_problem {
    * default, and the only value its C ABI reaches) is the sum of the particle costs up to the eps-anchoring; k < M is a
    * worst-k objective: only about k (1 - eps) / (1 + eps) costliest particles carry weight.  <= 0 or >= M (all ranks' particles): k = M. */
   long long cone_k;
+  /* cone path with smoothing (barrier_mu > 0 = 1 / smooth_alpha): the reference's `smooth_cstr` setting (PMPC.jl/src/main.jl:247-279) —
+   * 0 "logbarrier" (the default): -(1/alpha) log(alpha slack) per box side; 1 "squareplus": soft boxes, every side a'z <= b costs
+   * beta/2 (v + sqrt(v^2 + 1/alpha^2)), v = a'z - b (smooth_beta = beta, cone_utils.jl:222-228).  Pyjulia-only upstream. */
+  int smooth_cstr;
+  double smooth_beta;
 } pmpc_problem;
 
 typedef struct pmpc_info {

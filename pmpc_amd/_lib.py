@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
     "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device", "pmpc_linearize_device_f32",
-    "pmpc_set_option", "pmpc_get_option", "pmpc_abi_struct_sizes",
+    "pmpc_set_option", "pmpc_get_option", "pmpc_abi_struct_sizes", "pmpc_lcone_solve_host_ex",
 ]
 
 
@@ -38,7 +38,7 @@ class PmpcProblem(ctypes.Structure):
         + [("barrier_mu", ctypes.c_double), ("soc_q", ctypes.c_size_t), ("soc_W", ctypes.c_void_p), ("soc_w0", ctypes.c_void_p),
            ("soc_v", ctypes.c_void_p), ("soc_v0", ctypes.c_double), ("soc_u_interior", ctypes.c_void_p),
            ("cone_count", ctypes.c_size_t), ("cone_sizes", ctypes.POINTER(ctypes.c_int)), ("cone_A", ctypes.c_void_p), ("cone_c", ctypes.c_void_p),
-           ("cone_per_stage", ctypes.c_int), ("cone_k", ctypes.c_longlong)]
+           ("cone_per_stage", ctypes.c_int), ("cone_k", ctypes.c_longlong), ("smooth_cstr", ctypes.c_int), ("smooth_beta", ctypes.c_double)]
     )
 
 
@@ -67,6 +67,8 @@ def load():
     lib.pmpc_lqp_solve_host.restype = None
     lib.pmpc_lcone_solve_host.argtypes = common + [dbl, ctypes.c_uint, ll]
     lib.pmpc_lcone_solve_host.restype = None
+    lib.pmpc_lcone_solve_host_ex.argtypes = common + [dbl, ctypes.c_uint, ll, ctypes.c_int, dbl]
+    lib.pmpc_lcone_solve_host_ex.restype = None
     lib.pmpc_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
     lib.pmpc_create.restype = ctypes.c_int
     lib.pmpc_destroy.argtypes = [vp]

@@ -75,7 +75,7 @@ def _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu,
 
 
 def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
-          slew_um1, verbose, extra=(), cone_k=None):
+          slew_um1, verbose, extra=(), cone_k=None, smooth=None):
     lib = _lib.load()
     xdim, udim, N, M = _check_shapes(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, slew_reg,
                                      slew_reg0, slew_um1)
@@ -93,11 +93,13 @@ def _call(entry, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, 
     X_out, U_out = np.empty(xdim * N * M), np.empty(udim * N * M)
     ptr = lambda a: a.ctypes.data_as(_lib.c_dp)
     cone_k = int(cone_k) if cone_k is not None else 0
-    if rowmajor or cone_k > 0:
+    if rowmajor or cone_k > 0 or smooth is not None:
         entry = {"c_lqp_solve": "pmpc_lqp_solve_host", "c_lcone_solve": "pmpc_lcone_solve_host"}[entry]
         extra = tuple(extra[:1]) + (rowmajor,)  # the `solver` string only selects the conic back end upstream
         if entry == "pmpc_lcone_solve_host":
             extra = extra + (cone_k,)  # the `k` setting cannot cross the reference's C ABI; the extension entry carries it
+            if smooth is not None:  # smooth_cstr / smooth_beta (main.jl:247-279): a second extension entry
+                entry, extra = "pmpc_lcone_solve_host_ex", extra + (int(smooth[0]), float(smooth[1]))
     CALLS[entry] = CALLS.get(entry, 0) + 1
     getattr(lib, entry)(ptr(X_out), ptr(U_out), xdim, udim, N, M, int(Nc), *[ptr(a) for a in arrs[:14]], float(reg_x),
                         float(reg_u), *[ptr(a) for a in arrs[14:]], int(verbose), *extra)
@@ -113,7 +115,7 @@ def lqp_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu,
 
 
 def lcone_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
-                slew_um1, smooth_alpha=1e1, verbose=False, solver="ecos", k=None):
+                slew_um1, smooth_alpha=1e1, verbose=False, solver="ecos", k=None, smooth_cstr=None, smooth_beta=1.0):
     """pmpc/static_backend.py:107-191.  `k` (the reference's worst-k setting, PMPC.jl/src/main.jl:204-227) is reachable only
     through pyjulia upstream; here it rides on the extension entry point `pmpc_lcone_solve_host`."""
     if k is not None:
@@ -125,8 +127,18 @@ def lcone_solve(Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, l
         elif k == 0 or k > x0.shape[-1]:
             raise ValueError(f"lcone_solve: k = {k} is not supported (1 <= k <= M = {x0.shape[-1]}, or negative / None for k = M)")
     extra = (float(smooth_alpha), str(solver).encode())
+    # `smooth_cstr` (main.jl:247-279; pyjulia-only upstream): "logbarrier" is what a finite smooth_alpha means anyway, "squareplus" (soft
+    # boxes, slope smooth_beta) rides on the second extension entry, "" = hard boxes
+    smooth = None
+    if smooth_cstr is not None:
+        if smooth_cstr not in ("", "logbarrier", "squareplus"):
+            raise ValueError(f"Unknown smoothing method: [{smooth_cstr}]")  # main.jl:289
+        if smooth_cstr == "":
+            extra = (float("nan"), extra[1])
+        elif smooth_cstr == "squareplus" and smooth_alpha == smooth_alpha:
+            smooth = (1, float(smooth_beta))
     return _call("c_lcone_solve", Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u,
-                 slew_reg, slew_reg0, slew_um1, verbose, extra, cone_k=k)
+                 slew_reg, slew_reg0, slew_um1, verbose, extra, cone_k=k, smooth=smooth)
 
 
 _SOC_SOLVER = None
@@ -283,6 +295,9 @@ def aff_solve(
     if method == "qp":
         X, U = lqp_solve(*args, verbose=verbose)
     else:
-        X, U = lcone_solve(*args, smooth_alpha, verbose=verbose, solver=solver_settings["solver"], k=solver_settings.get("k"))
+        skw = {}  # (only when asked for: the call is the reference's otherwise, static_backend.py:189)
+        if solver_settings.get("smooth_cstr") is not None:
+            skw = dict(smooth_cstr=solver_settings["smooth_cstr"], smooth_beta=solver_settings.get("smooth_beta", 1.0))
+        X, U = lcone_solve(*args, smooth_alpha, verbose=verbose, solver=solver_settings["solver"], k=solver_settings.get("k"), **skw)
     X_traj = np.concatenate([np.swapaxes(x0, -1, -2)[:, None, :], X], -2)  # static_backend.py:311
     return X_traj, U, dict()

@@ -16,12 +16,27 @@ namespace {
 // partials of the barrier value -mu sum log(slack) and of the smallest slack (<= 0: infeasible point).  One launch for both slabs.
 __global__ void __launch_bounds__(256) k_bar_prep(const double *X, const double *U, const double *lx, const double *ux, const double *lu, const double *uu,
                                                   double *Dx, double *wx, double *Du, double *wu, double mu, long long nx, long long nu, int u, int N, int Nc,
-                                                  int owner, double *part_val, double *part_min) {
+                                                  int owner, double *part_val, double *part_min, int mode, double beta) {
   __shared__ double sv[256], sm[256];
   double val = 0.0, smin = 1e300;
   const long long stride = (long long)gridDim.x * 256;
+  // mode 1, smooth_cstr = "squareplus" (main.jl:265-279, cone_utils.jl:222-228): every box side a'z <= b costs
+  //   tau(v) = beta/2 (v + sqrt(v^2 + 1/alpha^2)),  v = a'z - b  (the second-order-cone rows (2/beta) tau - v >= |(v, 1/alpha)| with
+  // cost 1 on tau): a smooth hinge — soft boxes, no interior to stay in.  `mu` carries 1/alpha here.
+  auto sq = [&](double v, double sgn, double &D, double &w) {
+    const double r = sqrt(v * v + mu * mu);
+    val += 0.5 * beta * (v + r);
+    w += sgn * 0.5 * beta * (1.0 + v / r);
+    D += 0.5 * beta * mu * mu / (r * r * r);
+  };
   auto one = [&](double z, double lo, double hi, double &D, double &w) {
     D = 0.0; w = 0.0;
+    if (mode == 1) {
+      if (lo > -1e300) sq(lo - z, -1.0, D, w);
+      if (hi < 1e300) sq(z - hi, 1.0, D, w);
+      smin = fmin(smin, 1.0);
+      return;
+    }
     if (lo > -1e300) {
       const double s = z - lo;
       smin = fmin(smin, s);
@@ -156,9 +171,9 @@ inline unsigned grid_for(long long tot, unsigned cap = 2048) {
 
 void launch_bar_prep(const double *X, const double *U, const double *lx, const double *ux, const double *lu, const double *uu, double *Dx, double *wx,
                      double *Du, double *wu, double mu, long long nx, long long nu, int u, int N, int Nc, int owner, double *part_val, double *part_min,
-                     double *out2, hipStream_t s) {
+                     double *out2, hipStream_t s, int mode, double beta) {
   const unsigned G = grid_for(nx > nu ? nx : nu, PMPC_RED_BLOCKS);
-  hipLaunchKernelGGL(k_bar_prep, dim3(G), dim3(256), 0, s, X, U, lx, ux, lu, uu, Dx, wx, Du, wu, mu, nx, nu, u, N, Nc, owner, part_val, part_min);
+  hipLaunchKernelGGL(k_bar_prep, dim3(G), dim3(256), 0, s, X, U, lx, ux, lu, uu, Dx, wx, Du, wu, mu, nx, nu, u, N, Nc, owner, part_val, part_min, mode, beta);
   hipLaunchKernelGGL(k_bar_reduce, dim3(1), dim3(256), 0, s, (const double *)part_val, (const double *)part_min, (int)G, out2);
 }
 void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2, const double *dU2,

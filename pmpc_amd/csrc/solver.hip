@@ -2159,7 +2159,7 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
 // and Sherman-Morrison folds the term into the (Nc u + 1)-dimensional system of the shared controls and t, assembled on the host from
 // per-particle scalars.  Returns -1 when the problem is outside what this path covers (the caller takes the weighted-QP iteration).
 // -------------------------------------------------------------------------------------------------
-static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pmpc_info *info, int verbose) {
+static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pmpc_info *info, int verbose, int smode = 0, double sbeta = 1.0) {
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
   const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
@@ -2273,14 +2273,14 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   // barrier terms + particle costs at (Xe, Ue): -> Jv, out2 = {barrier value, smallest slack}
   auto eval_at = [&](const double *Xe, const double *Ue, std::vector<double> &Jv) {
     launch_bar_prep(Xe, Ue, has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
-                    w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s);
+                    w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s, smode, sbeta);
     launch_particle_cost(a, Xe, Ue, w.Jc.d(), s);
     HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipMemcpyAsync(Jv.data(), w.Jc.p, (size_t)M * D8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
   };
   // ---- starting point: the previous smoothed solution of this shape (strictly inside the same boxes), else the caller's U_prev pulled inside ----
-  const long long skey = (((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0);
+  const long long skey = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0)) * 2 + smode;
   bool warm = !(p->flags & PMPC_COLD_START) && w.es_key == skey && w.es_U.bytes >= nu * D8;
   const bool lam_mem = c->opt[OPT_CONE_RANK_MEMORY] != 0.0 && !(p->flags & PMPC_COLD_START) && c->cone_lam_key == -(skey + 7) && (int)c->cone_lam.size() == M;
   if (lam_mem) lam = c->cone_lam;
@@ -2290,7 +2290,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       HIP_CHECK(hipMemcpyAsync(w.U.p, w.es_U.p, nu * D8, hipMemcpyDeviceToDevice, s));
     } else {
       HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_prev, nu * D8, hipMemcpyDeviceToDevice, s));
-      if (has_ub) launch_interior(w.U.d(), p->lu, p->uu, (long long)nu, 0.05, s);
+      if (has_ub && smode == 0) launch_interior(w.U.d(), p->lu, p->uu, (long long)nu, 0.05, s);
     }
     launch_share_cons(w.U.d(), M, N, u, Nc, s);
     launch_rollout_fast(a, w.U.d(), w.X.d(), s);
@@ -2439,7 +2439,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       newton++;
       auto bar_at = [&](const double *Xe, const double *Ue) {  // barrier arrays + value + smallest slack at a point
         launch_bar_prep(Xe, Ue, has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
-                        w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s);
+                        w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s, smode, sbeta);
         HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
       };
@@ -2571,6 +2571,16 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
   // smooth_cstr = "logbarrier" (main.jl:246-262): -1/alpha sum log(alpha slack) replaces the hard boxes
   q.barrier_mu = (smooth_alpha == smooth_alpha && smooth_alpha > 0.0) ? 1.0 / smooth_alpha : 0.0;
   if (q.barrier_mu > 0.0 && !(p->flags & (PMPC_HAS_XBOUNDS | PMPC_HAS_UBOUNDS))) q.barrier_mu = 0.0;  // (no boxes: nothing to smooth, main.jl:248)
+  if (p->smooth_cstr == 1 && q.barrier_mu > 0.0) {
+    // smooth_cstr = "squareplus" (main.jl:265-279): soft boxes, tau(v) = beta/2 (v + sqrt(v^2 + 1/alpha^2)) per side; only the
+    // full-space Newton path has it (mu carries 1/alpha)
+    const int st_s = M > 1 ? lcone_smooth_body(c, p, q.barrier_mu, info, verbose, 1, p->smooth_beta > 0.0 ? p->smooth_beta : 1.0) : -1;
+    if (st_s >= 0) return st_s;
+    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs M > 1 particles on one rank, Nc <= 1, no slew penalties / particle weights and a compiled (xdim, udim) pair\n");
+    fill_nan_outputs(c, p);
+    if (info) { memset(info, 0, sizeof(*info)); info->status = 2; }
+    return 2;
+  }
   if (q.barrier_mu > 0.0 && c->opt[OPT_CONE_EPIGRAPH] != 0.0 && M > 1) {
     const int st_s = lcone_smooth_body(c, p, q.barrier_mu, info, verbose);
     if (st_s >= 0) return st_s;
@@ -2942,7 +2952,8 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
                        double *x0, double *f, double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R,
                        double *X_ref, double *U_ref, double *lx, double *ux, double *lu, double *uu, double reg_x,
                        double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1, long long verbose, bool cone = false,
-                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN(), unsigned rowmajor = 0, long long cone_k = 0) {
+                       double smooth_alpha = std::numeric_limits<double>::quiet_NaN(), unsigned rowmajor = 0, long long cone_k = 0, int smooth_cstr = 0,
+                       double smooth_beta = 1.0) {
   const size_t nx = xdim * N * M, nu = udim * N * M;
   const double nan = std::numeric_limits<double>::quiet_NaN();
   auto fail_out = [&]() {  // osqp_solver.jl:65-71 convention
@@ -3022,6 +3033,7 @@ static void host_solve(double *X_out, double *U_out, size_t xdim, size_t udim, s
   p.weights = nullptr;
   p.barrier_mu = 0.0;
   p.cone_k = cone_k;
+  p.smooth_cstr = smooth_cstr; p.smooth_beta = smooth_beta;
   if (cone) pmpc_lcone_solve_device(c, &p, smooth_alpha, &info, (int)verbose);
   else pmpc_lqp_solve_device(c, &p, &info, (int)verbose);
   HIP_CHECK(hipMemcpyAsync(X_out, p.X_out, nx * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -3076,6 +3088,15 @@ void pmpc_lcone_solve_host(double *X_out, double *U_out, size_t xdim, size_t udi
                            long long verbose, double smooth_alpha, unsigned rowmajor, long long cone_k) {
   host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x,
              reg_u, slew_reg, slew_reg0, slew_um1, verbose, true, smooth_alpha, rowmajor, cone_k);
+}
+// the same with the reference's `smooth_cstr` / `smooth_beta` settings (main.jl:247-279; pyjulia-only upstream): smooth_cstr 0 = "logbarrier",
+// 1 = "squareplus"
+void pmpc_lcone_solve_host_ex(double *X_out, double *U_out, size_t xdim, size_t udim, size_t N, size_t M, long long Nc, double *x0, double *f,
+                              double *fx, double *fu, double *X_prev, double *U_prev, double *Q, double *R, double *X_ref, double *U_ref, double *lx,
+                              double *ux, double *lu, double *uu, double reg_x, double reg_u, double *slew_reg, double *slew_reg0, double *slew_um1,
+                              long long verbose, double smooth_alpha, unsigned rowmajor, long long cone_k, int smooth_cstr, double smooth_beta) {
+  host_solve(X_out, U_out, xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu, reg_x, reg_u, slew_reg, slew_reg0,
+             slew_um1, verbose, true, smooth_alpha, rowmajor, cone_k, smooth_cstr, smooth_beta);
 }
 
 }  // extern "C"

@@ -101,7 +101,7 @@ class DeviceSolver:
     def _problem(self, *, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc=-1, x0=None, lx=None, ux=None,
                  lu=None, uu=None, slew_reg=None, slew_reg0=None, slew_um1=None, X_out=None, U_out=None, weights=None,
                  barrier_mu=0.0, force_generic=False, symmetric_cost=False, cold_start=False, static_cons_bounds=False, prev_is_last_solution=False, soc_W=None, soc_w0=None,
-                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0, cones=None, cone_objective=False):
+                 soc_v=None, soc_v0=0.0, soc_u_interior=None, cone_k=0, cones=None, cone_objective=False, smooth_cstr="logbarrier", smooth_beta=1.0):
         M, N, x = f.shape
         u = U_prev.shape[-1]
         assert fx.shape == (M, N, x, x) and fu.shape == (M, N, u, x) and Q.shape == (M, N, x, x) and R.shape == (M, N, u, u)
@@ -142,7 +142,7 @@ class DeviceSolver:
             X_ref=_p(X_ref), U_ref=_p(U_ref), lx=_p(lx), ux=_p(ux), lu=_p(lu), uu=_p(uu), slew_reg=_p(slew_reg),
             slew_reg0=_p(slew_reg0), slew_um1=_p(slew_um1), X_out=_p(X_out), U_out=_p(U_out), weights=_p(weights), barrier_mu=float(barrier_mu),
             soc_q=0 if soc_W is None else int(soc_W.shape[0]), soc_W=_p(soc_W), soc_w0=_p(soc_w0), soc_v=_p(soc_v), soc_v0=float(soc_v0),
-            soc_u_interior=_p(soc_u_interior), cone_k=int(cone_k))
+            soc_u_interior=_p(soc_u_interior), cone_k=int(cone_k), smooth_cstr={"logbarrier": 0, "squareplus": 1}[smooth_cstr], smooth_beta=float(smooth_beta))
         if cones is not None:  # general form of the stage cones: dict(sizes=[q_k], A=tensor, c=tensor); per-stage data if A is (M, N, rows, udim)
             sizes = [int(v) for v in cones["sizes"]]
             rows = sum(sizes) + len(sizes)

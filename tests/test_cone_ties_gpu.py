@@ -181,3 +181,22 @@ def test_logbarrier_smoothing_all_particles_identical(co):
     Xo, Uo = co.lcone_direct_py(*args, Nc=1, smooth_alpha=10.0, **kwM)
     X, U = backend.lcone_solve(*abi_args(args, kwM, 1), smooth_alpha=10.0, solver="ecos")
     assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+
+
+@pytest.mark.parametrize("alpha,beta,copies", [(10.0, 1.0, 1), (5.0, 20.0, 1), (10.0, 5.0, 3)])
+def test_squareplus_smoothing_matches_the_direct_program(co, alpha, beta, copies):
+    """smooth_cstr = "squareplus" (main.jl:265-279, cone_utils.jl:222-228): every box side costs beta/2 (v + sqrt(v^2 + 1/alpha^2)) of its
+    violation v — soft boxes.  The reference states it as three-row second-order cones with a new epigraph variable each; the direct
+    oracle solves exactly those rows."""
+    from pmpc_amd import backend
+
+    if copies > 1:
+        args, kw = tied_problem(np.random.default_rng(41), copies, 3, 6, 4, 2, 0.4, 1)
+    else:
+        args, kw = rand_problem(np.random.default_rng(40), 7, 6, 4, 2, 0.4)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=1, smooth_alpha=alpha, smooth_cstr="squareplus", smooth_beta=beta, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, 1), smooth_alpha=alpha, solver="ecos", smooth_cstr="squareplus", smooth_beta=beta)
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(U))
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+    if beta >= 20.0:  # a steep hinge keeps the controls (nearly) inside the boxes it replaces
+        assert np.max(np.abs(U)) <= 0.4 + 0.05
