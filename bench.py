@@ -29,6 +29,13 @@ if str(ROOT) not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 ELEMS_PER_UNIT = 420   # elements per (particle, stage) at x12,u4 with control bounds
+FP64_PEAK_TFLOPS = 78.6  # AMD MI355X data sheet: fp64 matrix = fp64 vector = 78.6 TFLOP/s (256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz: one
+#                          v_mfma_f64_16x16x4 = 2048 flop per 64 cycles per SIMD); the CDNA4 guide in this image quotes no fp64 figure
+
+
+def riccati_flops_per_unit(x, u):
+    """matrix Riccati work per (particle, stage), 4x^3 + 6x^2u + 4xu^2 + u^3/3 (11.2 kflop at x12, u4)."""
+    return 4 * x ** 3 + 6 * x * x * u + 4 * x * u * u + u ** 3 / 3.0
 
 
 def parse():
@@ -370,7 +377,21 @@ def main():
         # --pmc passes, corrections as the MI355X guide prescribes) AT CONFIG D, fp64 — attached only to that workload
         traffic = traffic_kernel = traffic_profile = None
         tf = ROOT / "profiles" / "traffic.json"
-        at_config_d = args.model == "quadrotor" and M_loc == 4096 and N == 50 and not (args.fp32 or args.soc or args.cone or args.force_generic or args.vmax > 0.0)
+        at_config_d = args.model == "quadrotor" and M_loc == 4096 and N == 50 and Nc == 1 and not (args.fp32 or args.soc or args.cone or args.force_generic or args.vmax > 0.0)
+        # other workloads with a PMC pass of their own (tools/profile_gpu.sh): keyed by a tag in profiles/traffic.json["workloads"]
+        wl_tag = None
+        if args.model == "quadrotor" and M_loc == 4096 and Nc == 1 and not (args.cone or args.force_generic or args.vmax > 0.0):
+            if args.soc and N == 100:
+                wl_tag = "E_soc_fp32" if args.fp32 else "E_soc"
+            elif args.fp32 and N == 50 and not args.soc:
+                wl_tag = "D_fp32"
+        if tf.exists() and wl_tag:
+            try:
+                tw = json.loads(tf.read_text()).get("workloads", {}).get(wl_tag)
+                if tw:
+                    traffic, traffic_kernel, traffic_profile = tw.get("bytes_per_launch"), tw.get("kernels"), tw.get("profile")
+            except Exception:
+                pass
         if tf.exists() and at_config_d:
             try:
                 tj = json.loads(tf.read_text())
@@ -390,6 +411,43 @@ def main():
             per_solve = {"aff_solve_ms": 1e3 * sm, "achieved": alg_bytes / sm / 1e9, "frac": alg_bytes / sm / 1e9 / HBM_PEAK_GBS,
                          "note": "BASELINE.md section 3's definition: algorithmic bytes of ONE sub-problem / seconds per aff_solve (HIP events on the "
                                  "solver's stream around the whole sub-problem, last repeat window)"}
+        # ---- what the dominant kernel is actually limited by: bytes AND flops fractions, and the A/B that names the limiter ----------
+        flop_unit = riccati_flops_per_unit(x, u)
+        flops_launch = flop_unit * M_loc * N
+        ach_tf = flops_launch / avg_s / 1e12 if n_f else 0.0
+        flops = {"flop_per_unit": flop_unit, "flop_per_launch": flops_launch, "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach_tf / FP64_PEAK_TFLOPS,
+                 "note": "useful flops of the matrix Riccati recursion (SURVEY.md section 8d) / launch time; the 16x16x4 fp64 MFMA tiles are "
+                         "padded 12 -> 16 rows, so the matrix pipe is busier than this figure by (16/12)^2 on the G and H products"}
+        limiter = {"name": "vector-instruction issue of one wave per particle walking N dependent stages",
+                   "evidence": ["fp32-storage A/B (bench.py --fp32): the launch moves 42 % fewer bytes (688 -> 400 MB) and runs 3.5 % faster "
+                                "(profiles/r03_f_bench_D_fp32.json): not bandwidth",
+                                "7 fp64 MFMAs of 64 cycles per stage = 448 of the ~2200 cycles a wave spends per stage at 4 waves per SIMD: not the matrix pipe",
+                                "ISA of k_bwd_as<12,4,1,false,true,0,double>: 375 instructions per stage in the main loop, ~300 of them VALU "
+                                "(moves, DPP / lane exchanges, selects and the lane-uniform 4x4 Cholesky + substitution); 4 waves x 375 x >= 4 cycles "
+                                "per SIMD and stage is 80 % of the measured stage period",
+                                "s_memtime stage timeline of the same kernel at 0.5 and 4 waves per SIMD: profiles/r04_stage_timeline.txt"],
+                   "bytes_frac_of_peak": achieved / HBM_PEAK_GBS, "flops_frac_of_peak": ach_tf / FP64_PEAK_TFLOPS}
+        # ---- Nc > 1 (the reference's default is Nc = N): the consensus launch class (condensing kernel + particle reduction + dense
+        #      solve) is a roofline object of its own.  SURVEY.md section 8(d) expected it MFMA-bound; measured it is HBM-bound on the
+        #      per-particle condensed Hessians (M x (Nc u)^2 doubles written by the condensing kernel and read back by the reduction).
+        cons_roof = None
+        if Nc > 1 and "consensus" in prof_all and prof_all["consensus"][1] > 0:
+            ncv = Nc * u
+            ms_cons = prof_all["consensus"][0] / args.steps  # per step (every round's consensus launches)
+            rounds_ps = max(1.0, float(np.mean(as_rounds))) if np.mean(as_rounds) > 0 else 1.0
+            solves_ps = max(rounds_ps, float(np.mean(solves)))
+            cond_flops = (x * x + x * u) * u * Nc * Nc * M_loc  # off-diagonal blocks: Y_j Gamma_{j-1,l} walked forward, 2 (x^2 + x u) flops per column and stage pair
+            hbytes = 2.0 * M_loc * ncv * ncv * 8  # written once by k_cond_fast / the factor sweep, read once by the reduction
+            t_one = ms_cons * 1e-3 / solves_ps
+            cons_roof = {"bound": "hbm", "kernel": "consensus launch class: k_cond_fast (off-diagonal blocks of the per-particle condensed Hessians) + particle reduction + dense Cholesky",
+                         "avg_ms_per_solve": 1e3 * t_one, "solves_per_step": solves_ps, "bytes_per_solve": hbytes, "achieved": hbytes / t_one / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": hbytes / t_one / 1e9 / HBM_PEAK_GBS,
+                         "flops": {"flop_per_solve": cond_flops, "achieved": cond_flops / t_one / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": cond_flops / t_one / 1e12 / FP64_PEAK_TFLOPS},
+                         "note": "SURVEY.md section 8(d) prices full-consensus condensing as a dense (N x) x (N u) contraction per particle against the fp64 MFMA "
+                                 "peak; the structured form walks the stages (O(Nc^2) small tile products, ~8 GFLOP at config D) and what it costs is the "
+                                 "round trip of M (Nc u)^2 doubles through HBM"}
         rates = [args.steps / t_ for t_ in rep_s]
         w0, w1 = args.warmup + 1, args.warmup + args.steps
         out = {
@@ -428,6 +486,7 @@ def main():
                                  "same figure for the plain instantiation, measured over the cold solves after the timed region",
                          "plain_full_sweep": plain, "per_solve": per_solve,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * avg_s, "launches": int(n_f),
+                         "flops": flops, "limiter": limiter, "consensus_class": cons_roof,
                          "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof_all.items() if v[1] > 0},
                          "kernel_ms_per_step_note": "every launch class, HIP events, last repeat window (not the reported one)"},
         }

@@ -226,6 +226,59 @@ def test_config_E_size_M4096_N100_thrust_cones_properties(solver):
             assert _objective(prob, _rollout_np(prob, f, fx, fu, U2), U2) >= J0 * (1 - 1e-12)
 
 
+def test_config_E_full_size_fp32_storage_properties(solver):
+    """BASELINE configs[4] AS STATED at FULL size — quadrotor M = 4096, N = 100, boxes + thrust cones, fp32 STORAGE (fx, fu, Q, R and the
+    factor records float32, arithmetic fp64) — by properties of the warm-started second SCP iteration (pmpc_info.fast_path == 2): consensus,
+    box and cone feasibility, the linearised dynamics of the float-stored Jacobians reproduced to round-off, and optimality of the
+    float-stored problem by feasible perturbations.  (The small-M comparison with the fp64 cone oracle is the test above.)"""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem
+    from tests.test_device_gpu import _objective, _rollout_np
+
+    M, N = 4096, 100
+    prob = dyn.make_quadrotor_problem(M=M, N=N)
+    d = to_device_problem(prob)
+    dev = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device="cuda")
+    soc, _ = _thrust_cone(dev)
+    Q32, R32 = d["Q"].to(torch.float32).contiguous(), d["R"].to(torch.float32).contiguous()
+    fx = torch.empty((M, N, 12, 12), dtype=torch.float32, device="cuda")
+    fu = torch.empty((M, N, 4, 12), dtype=torch.float32, device="cuda")
+    f = torch.empty((M, N, 12), dtype=torch.float64, device="cuda")
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    for it in range(2):
+        solver.linearize(MODEL_QUADROTOR, d["x0"], Xa, Ua, d["params"], f, fx, fu)
+        _, _, status = solver.lsoc_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, Q=Q32, R=R32, X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"],
+                                         reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d["lu"], uu=d["uu"], X_out=Xb, U_out=Ub, symmetric_cost=True,
+                                         static_cons_bounds=True, prev_is_last_solution=it > 0, **soc)
+        solver.sync()
+        assert status == 0, solver.last_info
+        if it == 0:
+            Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+    assert solver.last_info["fast_path"] == 2 and solver.last_info["ipm_iters"] == 0 and solver.last_info["active_set_rounds"] > 0, solver.last_info
+    X, U = Xb.cpu().numpy(), Ub.cpu().numpy()
+    # the problem the float-stored solve solved: fp32-rounded cost blocks and Jacobians, linearised at (Xa, Ua)
+    p32 = dict(prob, Q=Q32.double().cpu().numpy().swapaxes(-1, -2), R=R32.double().cpu().numpy().swapaxes(-1, -2), X_prev=Xa.cpu().numpy(), U_prev=Ua.cpu().numpy())
+    cone = lambda V: 0.3 * V[..., 0] - np.linalg.norm(V[..., 1:3], axis=-1)
+    assert np.all(U[:, 0] == U[0:1, 0]) and cone(U).min() > -1e-9
+    assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9)
+    Xr = _rollout_np(p32, f, fx.double(), fu.double(), U)
+    assert np.max(np.abs(Xr - X)) < 1e-8 * max(1.0, np.max(np.abs(X)))
+    J0 = _objective(p32, Xr, U)
+    rng = np.random.default_rng(12)
+    for scale in (1e-2, 1e-4):
+        dU = rng.standard_normal(U.shape)
+        dU[:, :1] = dU[0:1, :1]
+        U2 = np.clip(U + scale * dU, prob["u_l"], prob["u_u"])
+        nrm = np.maximum(np.linalg.norm(U2[..., 1:3], axis=-1), 1e-300)
+        U2[..., 1:3] *= np.where(cone(U2) < 0, np.maximum(0.3 * U2[..., 0], 0.0) / nrm, 1.0)[..., None]
+        U2[:, :1] = U2[0:1, :1]
+        if cone(U2).min() >= -1e-12:
+            assert _objective(p32, _rollout_np(p32, f, fx.double(), fu.double(), U2), U2) >= J0 * (1 - 1e-12)
+
+
 @pytest.mark.parametrize("Nc", [1, -1])
 def test_c_lcone_solve_600_particles_matches_cone_oracle(oracle, Nc):
     """`c_lcone_solve` beyond 500 particles (the reference's default solver "ecos" at any of the BASELINE particle counts):

@@ -1,0 +1,43 @@
+"""The fuzzers of tools/fuzz/ as a bounded `-m gpu` test: fixed seeds, a few hundred random problems each against the oracle
+(dims, consensus horizons, boxes, slew, state boxes that bind, stage cones, warm-start sequences).  Each script prints a summary
+line; the bar is the north star's 1e-6 on every case, and no failed solve that the oracle could solve."""
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(script, *argv, timeout=900):
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz" / script), *map(str, argv)], cwd=str(ROOT), capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    return r.stdout.strip().splitlines()
+
+
+def test_fuzz_parity_qp_path():
+    last = _run("fuzz_parity.py", 11, 200)[-1]
+    m = re.search(r"(\d+) cases, (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(2)) == 0 and float(m.group(3)) <= 1e-6, last
+
+
+def test_fuzz_stage_cones():
+    last = _run("fuzz_soc.py", 12, 120)[-1]
+    m = re.search(r"(\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(1)) == 0 and float(m.group(2)) <= 1e-6, last
+
+
+def test_fuzz_warm_start_sequences():
+    last = _run("fuzz_warm_as.py", 13, 60, 5)[-1]
+    m = re.search(r"(\d+) sequences, (\d+) solves, (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(3)) == 0 and float(m.group(4)) <= 1e-6, last
+
+
+@pytest.mark.parametrize("mode", ["boxes", "cone"])
+def test_fuzz_binding_state_boxes(mode):
+    out = _run("fuzz_xbox.py", 60, 14, *(["cone"] if mode == "cone" else []))
+    m = re.search(r"worst ([0-9.e+-]+)", out[-1])
+    assert m and float(m.group(1)) <= 1e-6, out[-1]

@@ -4,10 +4,10 @@ faulthandler.enable()
 sys.path.insert(0, ".")
 from pmpc_amd import backend
 from tests.support.problems import abi_args, rand_problem
-rng = np.random.default_rng(int(sys.argv[1]))
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dims = [(12, 4), (4, 2), (2, 1), (3, 2), (5, 3), (6, 2), (8, 4), (7, 3), (3, 1), (9, 5), (1, 1), (13, 2)]
 ok = nan = 0
-for k in range(int(sys.argv[2])):
+for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 50):
     x, u = dims[rng.integers(len(dims))]
     M, N = int(rng.integers(1, 40)), int(rng.integers(1, 14))
     Nc = int(rng.choice([0, min(1, N), min(2, N), -1, N, N + 3]))

@@ -5,12 +5,12 @@ sys.path.insert(0, ".")
 from oracle import lqp_oracle as orc
 from pmpc_amd.device import DeviceSolver
 from tests.support.problems import rand_problem
-rng = np.random.default_rng(int(sys.argv[1]))
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
 T = lambda a: dev(np.swapaxes(a, -1, -2))
 s = DeviceSolver(0)
 worst, fails = 0.0, 0
-for k in range(int(sys.argv[2])):
+for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 50):
     x, u = [(12, 4), (4, 2), (3, 3), (5, 3), (6, 2), (8, 4), (7, 3)][rng.integers(7)]
     M, N = int(rng.integers(1, 7)), int(rng.integers(1, 9))
     Nc = int(rng.choice([0, min(1, N), -1]))

@@ -40,3 +40,16 @@ cat $out/xbox_summary.txt
 for v in 3.0 2.0; do python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --repeats 1 --vmax $v > $out/bench_D_vmax$v.log 2>&1; done
 PMPC_XBOX_AS=0 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --repeats 1 --vmax 3.0 > $out/bench_D_vmax3.0_ipm.log 2>&1
 grep -h '^{' $out/bench_D_vmax3.0.log $out/bench_D_vmax2.0.log $out/bench_D_vmax3.0_ipm.log | cut -c1-160
+
+# r04: PMC traffic of the dominant kernel for the workloads whose bench lines carry their own alg_bytes_per_launch (config E's cone
+# sweeps in fp64 and fp32 storage, config D in fp32 storage): separate FETCH_SIZE / WRITE_SIZE passes each, as for config D above
+for wl in "E_soc:--soc --N 100" "D_fp32:--fp32" "E_soc_fp32:--soc --N 100 --fp32"; do
+  name=${wl%%:*}; flags=${wl#*:}
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$name -- python3 bench.py --steps 2 --warmup 1 --repeats 0 --no-cpu-baseline $flags > $out/bench_fetch_$name.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$name -- python3 bench.py --steps 2 --warmup 1 --repeats 0 --no-cpu-baseline $flags > $out/bench_write_$name.log 2>&1
+done
+# r04: the reference's default path with log-barrier smoothing at config D (full-space Newton, any tie pattern) and squareplus at B;
+# stage timeline of the two sweeps (diagnostic build, tools/micro/stage_timeline.py)
+python3 bench.py --steps 10 --warmup 2 --repeats 0 --no-cpu-baseline --cone --smooth-alpha 10 > $out/bench_D_cone_smooth.log 2>&1
+grep -h '^{' $out/bench_D_cone_smooth.log | cut -c1-160
+if [ -f libs_tmp/libpmpc_hip_tl.so ]; then python3 tools/micro/stage_timeline.py 512 4096 > $out/stage_timeline.txt 2>&1; fi

@@ -71,6 +71,31 @@ for prefixes, label in ((("k_bwd_fast<12, 4, true, false, true, false>",), "bwd_
     out[label] = {"kernels": fnames, "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb, "read_bytes_calibrated": fb * read_factor,
                   "launches_sampled": len(fv)}
     out[f"{label}_bytes_per_launch"] = fb * read_factor + wb
+# r04: workloads with PMC passes of their own (tools/profile_gpu.sh): dominant kernel = the first round's factor sweep of the timed region
+workloads = {}
+for name, prefixes in (("E_soc", ("k_bwd_as<12, 4, 1, false, true, 1, double>", "k_bwd_as<12, 4, 0, false, true, 1, double>")),
+                       ("D_fp32", ("k_bwd_as<12, 4, 1, false, true, 0, float>",)),
+                       ("E_soc_fp32", ("k_bwd_as<12, 4, 1, false, true, 1, float>",))):
+    try:
+        ff = glob.glob(str(src / f"pmc_fetch_{name}" / "*" / "*counter_collection.csv"))[0]
+        fw = glob.glob(str(src / f"pmc_write_{name}" / "*" / "*counter_collection.csv"))[0]
+    except IndexError:
+        continue
+    accf, accw = defaultdict(list), defaultdict(list)
+    for r in csv.DictReader(open(ff)):
+        accf[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for r in csv.DictReader(open(fw)):
+        accw[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    try:
+        fv, fnames = pooled(accf, prefixes)
+        wv, _ = pooled(accw, prefixes)
+    except StopIteration:
+        continue
+    fb, wb = sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024
+    workloads[name] = {"kernels": fnames, "FETCH_SIZE_bytes_raw": fb, "WRITE_SIZE_bytes": wb, "read_bytes_calibrated": fb * read_factor,
+                       "bytes_per_launch": fb * read_factor + wb, "launches_sampled": len(fv),
+                       "profile": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_gpu.sh {tag} on this workload; read factor calibrated on k_axpy in the config-D pass"}
+out["workloads"] = workloads
 (dst / "traffic.json").write_text(json.dumps(out, indent=1))
 (dst / f"{tag}_traffic.json").write_text(json.dumps(out, indent=1))
 print(json.dumps(out, indent=1))
@@ -85,14 +110,14 @@ for log, name in (("bench_full.log", f"{tag}_bench.json"), ("bench_stats.log", f
                   ("bench_D_fp32.log", f"{tag}_bench_D_fp32.json"), ("bench_D_cone.log", f"{tag}_bench_D_cone.json"),
                   ("bench_B_cone.log", f"{tag}_bench_B_cone.json"), ("bench_B_cone_smooth.log", f"{tag}_bench_B_cone_smooth.json"),
                   ("bench_D_vmax3.0.log", f"{tag}_bench_D_vmax3.json"), ("bench_D_vmax2.0.log", f"{tag}_bench_D_vmax2.json"),
-                  ("bench_D_vmax3.0_ipm.log", f"{tag}_bench_D_vmax3_ipm.json")):
+                  ("bench_D_vmax3.0_ipm.log", f"{tag}_bench_D_vmax3_ipm.json"), ("bench_D_cone_smooth.log", f"{tag}_bench_D_cone_smooth.json")):
     if not (src / log).exists():
         continue
     lines = [l for l in open(src / log) if l.startswith("{")]
     if lines:
         (dst / name).write_text(lines[-1])
 
-for extra in ("slew_paths.txt", "xbox_summary.txt"):
+for extra in ("slew_paths.txt", "xbox_summary.txt", "stage_timeline.txt"):
     if (src / extra).exists():
         (dst / f"{tag}_{extra}").write_text(open(src / extra).read())
 soc_stats = glob.glob(str(src / "stats_E_soc" / "*" / "*kernel_stats.csv"))
