@@ -106,6 +106,25 @@ def test_sharded_solve_matches_single_rank_and_oracle(case, world, oracle):
     assert len({(i["ipm_iters"], i["active_set_rounds"], i["structured_solves"]) for i in infos}) == 1  # every rank took the same decisions
 
 
+@pytest.mark.parametrize("world,Nc,dims", [(2, 1, (8, 10, 4, 2)), (4, 1, (8, 8, 12, 4)), (2, 2, (6, 8, 4, 2))])
+def test_sharded_binding_state_boxes_match_single_rank(world, Nc, dims, oracle):
+    """State boxes that BIND (rows of the active-set rounds, kernels_xbox.hip) on sharded particles with a consensus horizon: the open
+    rows of a round ride in the next round's merged exchange (tail[4]), so a round without status changes is not accepted while a held
+    row is still off its bound.  Same answer as one rank to 1e-9, the oracle to 1e-7, cold and warm."""
+    from tests.support.problems import xbox_problem
+
+    M, N, x, u = dims
+    args, kw = xbox_problem(np.random.default_rng(50 + world + Nc + x), oracle, M, N, x, u, Nc, 0.4, pull=0.8)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    assert np.sum((np.abs(Xo - kw["x_l"]) < 1e-8) | (np.abs(Xo - kw["x_u"]) < 1e-8)) > 0  # some state rows bind at the optimum
+    X1, U1, _ = _solve_sharded(args, kw, Nc, 1, repeats=2)
+    Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, repeats=2)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    assert rel(X1, Xo) < 1e-7 and rel(U1, Uo) < 1e-7, (rel(X1, Xo), rel(U1, Uo))
+    assert rel(Xw, X1) < 1e-9 and rel(Uw, U1) < 1e-9, (rel(Xw, X1), rel(Uw, U1))
+    assert np.all(Uw[:, :Nc] == Uw[0:1, :Nc])
+
+
 def test_eight_ranks_quadrotor_shape(oracle):
     """bench.py's 8-GPU layout in miniature: 8 ranks x 4 particles, quadrotor dimensions, Nc = 1, control boxes."""
     from pmpc_amd import dynamics as dyn
