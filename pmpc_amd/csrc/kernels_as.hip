@@ -53,6 +53,10 @@ __device__ unsigned long long pmpc_tl[3][128][PMPC_TL_STAMPS];  // [0 full facto
 #ifndef PMPC_AS_PINGPONG
 #define PMPC_AS_PINGPONG 0    // main loop: two stages per trip, the prefetch register sets swap roles (0: one stage + rotation moves)
 #endif
+#ifndef PMPC_AS_DEFECT_G
+#define PMPC_AS_DEFECT_G 0    // DEFECT sweeps: the defect term of the gradient as G'r from the product G = S F the stage forms anyway
+                              // (3 multiply-adds on a row-distributed copy of r) instead of S r by 3 row sums over DPP moves (39 instructions)
+#endif
 
 namespace {
 
@@ -285,18 +289,26 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     if (MODE != 2 && below) fetch_early(j - 1, nxt);  // (deep2: the caller's ring has requested stage j - 2 already)
     TL(2);  // next stage's loads issued
 
+    double d_row[KS];
     if (DEFECT) {  // x_j = F [x_{j-1}; u_j] + r_j: the cost-to-go gradient seen through the stage is s + S r
+      if (PMPC_AS_DEFECT_G) {
+        col_to_row<KS>(df_c, g, d_row);  // h = F'(s + S r) = F's + G'r with G = S F: the S r product is never formed
+      } else {
 #pragma unroll
-      for (int r = 0; r < KS; r++) s_row[r] += row_allsum(S[r] * df_c);
+        for (int r = 0; r < KS; r++) s_row[r] += row_allsum(S[r] * df_c);
+      }
     }
     // ---- h = F' s (+ control gradient) -----------------------------------------------------------------
     double hp = fma(Rc, um_g, gu_c);
 #pragma unroll
     for (int r = 0; r < KS; r++) hp = fma(Fr[r], s_row[r], hp);
-    const double h_col = grp_allsum(hp);
+    double h_col = 0.0;
     double hu[UD];
+    if (!(DEFECT && PMPC_AS_DEFECT_G)) {
+      h_col = grp_allsum(hp);
 #pragma unroll
-    for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
+      for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
+    }
 
     TL(3);  // gradient h = F' (s + S r) formed, control rows read out
     // ---- H = F' S F + blkdiag(Q~_{j-1}, R~_j) ------------------------------------------------------
@@ -317,6 +329,13 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     for (int r = 0; r < KS; r++) G = mfma(S[r], Fr[r], G);
 #pragma unroll
     for (int r = 0; r < KS; r++) H = mfma(Fr[r], G[r], H);
+    if (DEFECT && PMPC_AS_DEFECT_G) {
+#pragma unroll
+      for (int r = 0; r < KS; r++) hp = fma(G[r], d_row[r], hp);
+      h_col = grp_allsum(hp);
+#pragma unroll
+      for (int b = 0; b < UD; b++) hu[b] = readlane_d(h_col, XP + b);
+    }
 
     if (!DEEP && !MAIN) late_pf();
     if (!MAIN && cons) {

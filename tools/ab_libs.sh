@@ -1,15 +1,14 @@
 #!/bin/bash
-# A/B different builds of libpmpc_hip.so on the same box (same device, same process environment): libs_tmp/*.so in turn
+# A/B different builds of libpmpc_hip.so on the same box (same device, same process environment): libs_tmp/*.so in turn, through
+# PMPC_HIP_LIB (pmpc_amd/_lib.py).  AB_M: particle counts, AB_REPS: passes, AB_ARGS: further bench.py flags.
 cd $GRAFT_REPO_ROOT
-cp pmpc_amd/libpmpc_hip.so /tmp/orig.so
+mkdir -p gpurun_out/ab
 for rep in $(seq 1 ${AB_REPS:-2}); do
 for f in libs_tmp/*.so; do
-  cp $f pmpc_amd/libpmpc_hip.so
-  for m in ${AB_M:-256 4096}; do
-    python bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --ignore-status --M $m ${AB_ARGS} 2>&1 | grep -E "^\{" | tail -1 | python -c "
-import sys, json
-d=json.loads(sys.stdin.read()); print('$f', 'M=$m', 'it/s', round(d['value'],1), [round(v,1) for v in d['repeats']['values']], 'factor us', round(1e3*d['roofline']['avg_launch_ms'],1), {k: round(v,3) for k,v in d['roofline']['kernel_ms_per_step'].items()}, 'rounds', d['config']['active_set_rounds_per_step'])"
+  for m in ${AB_M:-512 4096}; do
+    tag=$(basename $f .so)_M${m}_r${rep}
+    PMPC_HIP_LIB=$f python bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --M $m ${AB_ARGS} > gpurun_out/ab/$tag.log 2>&1
+    python tools/bench_line.py gpurun_out/ab/$tag.log | cut -c1-420
   done
 done
 done
-cp /tmp/orig.so pmpc_amd/libpmpc_hip.so
