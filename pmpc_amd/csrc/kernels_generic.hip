@@ -473,6 +473,9 @@ __global__ void __launch_bounds__(256) k_cons_solve(const double *Hc, double *Lc
   for (int e = tid; e < nc; e += nth) duc[e] = y[e];
 }
 
+#ifndef PMPC_CONS_BLOCKED_THREADS
+#define PMPC_CONS_BLOCKED_THREADS 256  // (r04 A/B at config D with Nc = N, nc = 200: 1024 threads are SLOWER — consensus class 1.02 -> 1.57 ms per step: barrier-bound)
+#endif
 // ---- blocked variant (nc <= PMPC_CONS_BLOCKED_MAX): right-looking Cholesky with 16-column panels ----------------
 // Per panel: the 16 x 16 diagonal block is factored by ONE wave in registers (lane l = row l, pivots and
 // multipliers broadcast with v_readlane — no barriers), the rows below are solved one per thread against it, and
@@ -485,7 +488,7 @@ __device__ __forceinline__ double rl_d(double v, int l) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(256) k_cons_solve_blocked(const double *Hc, double *Lc, const double *gc, double *duc, int nc,
+__global__ void __launch_bounds__(PMPC_CONS_BLOCKED_THREADS) k_cons_solve_blocked(const double *Hc, double *Lc, const double *gc, double *duc, int nc,
                                                             int factor, int *fail) {
   extern __shared__ double sm[];
   double *P = sm;                      // panel, k-major: P[k * nc + r]
@@ -1021,7 +1024,10 @@ __global__ void __launch_bounds__(256) k_reduce_particles_hg(const double *srcH,
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int e = blockIdx.x * 64 + tx, E = EH + EG;
   double acc = 0.0;
-  if (e < E) {
+  // (H entries strictly below the diagonal are never read by the consensus solve — it takes the UPPER triangle, the only one the
+  //  condensing kernel fills —: skipping them halves this kernel's traffic, M (Nc u)^2 doubles at full consensus)
+  const bool lower = e < EH && EG > 0 && (e % EG) > (e / EG);
+  if (e < E && !lower) {
     const double *src = e < EH ? srcH + e : srcG + (e - EH);
     const int stride = e < EH ? EH : EG;
     for (int i = blockIdx.y * 4 + ty; i < M; i += 4 * gridDim.y) acc += src[(size_t)i * stride];
@@ -1067,7 +1073,7 @@ void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, in
   }
   const size_t lds = ((size_t)17 * nc + 16 * 17) * sizeof(double);
   if (nc > 16 && lds <= 64 * 1024)
-    hipLaunchKernelGGL(k_cons_solve_blocked, dim3(1), dim3(256), lds, s, (const double *)Hc, Lc, gc, duc, nc, factor ? 1 : 0, fail);
+    hipLaunchKernelGGL(k_cons_solve_blocked, dim3(1), dim3(PMPC_CONS_BLOCKED_THREADS), lds, s, (const double *)Hc, Lc, gc, duc, nc, factor ? 1 : 0, fail);
   else
     hipLaunchKernelGGL(k_cons_solve, dim3(1), dim3(256), nc * sizeof(double), s, (const double *)Hc, Lc, gc, duc, nc,
                        factor ? 1 : 0, fail);
