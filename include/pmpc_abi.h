@@ -214,6 +214,8 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *   host_reuse PMPC_HOST_REUSE 1       host ABI: unchanged 8 MB chunks are not uploaded again
  *   warn_slow_path PMPC_WARN_SLOW_PATH 1   one line on stderr when a context first leaves the register-resident path
  *   cone_rank_memory PMPC_CONE_RANK_MEMORY 1   cone objective: the weight assignment the previous solve of the shape settled on is tried first
+ *   cone_epigraph    PMPC_CONE_EPIGRAPH    1   cone objective: hard boxes through the epigraph problem in the shared-control space, smoothing through the
+ *                                             full-space Newton iteration (any tie pattern); 0: the rank-based weighted-QP iteration everywhere
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);

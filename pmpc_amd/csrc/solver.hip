@@ -500,7 +500,7 @@ int pmpc_set_option(pmpc_ctx *c, const char *key, double value) {
   for (int k = 0; k < OPT_COUNT; k++)
     if (!strcmp(key, kPmpcOptions[k].key)) {
       c->opt[k] = value;
-      c->ws.as_key = c->ws.warm_key = c->cone_rw_key = -1;  // (a remembered set / iterate / weight assignment was found under the old switches)
+      c->ws.as_key = c->ws.warm_key = c->cone_rw_key = c->cone_lam_key = c->ws.es_key = -1;  // (a remembered set / iterate / weight assignment was found under the old switches)
       return 0;
     }
   return -1;
