@@ -2165,8 +2165,9 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
   const int Nc = p->Nc < 0 ? N : (int)std::min<long long>(p->Nc, (long long)N), nc = Nc * u;
   const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
-  if (c->multi() || c->world != 1 || p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || Nc > 1 || M < 2 ||
-      !(has_xb || has_ub) || !(mu_b > 0.0))
+  // (several consensus stages: the condensed Hessians M (Nc u)^2 are gathered to the host every Newton step — bounded)
+  if (c->multi() || c->world != 1 || p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || M < 2 ||
+      !(has_xb || has_ub) || !(mu_b > 0.0) || (double)M * nc * nc > 2e7)
     return -1;
   const size_t nx = (size_t)M * N * x, nu = (size_t)M * N * u, D8 = sizeof(double);
   LQArgs a;
@@ -2192,7 +2193,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   w.es_dots.ensure((size_t)3 * M * D8); w.es_coef.ensure((size_t)M * D8); w.es_out2.ensure(2 * D8); w.pw.ensure((size_t)M * D8); w.Jc.ensure((size_t)M * D8);
   w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_max.ensure(2 * PMPC_RED_BLOCKS * D8);
   w.duc.ensure((size_t)std::max(nc, 1) * D8); w.fail.ensure(sizeof(int));
-  if (w.es_zero.ensure(64 * D8)) HIP_CHECK(hipMemsetAsync(w.es_zero.p, 0, 64 * D8, s));
+  if (w.es_zero.ensure((size_t)std::max(64, nc) * D8)) HIP_CHECK(hipMemsetAsync(w.es_zero.p, 0, w.es_zero.bytes, s));
   if (w.zeros.bytes == 0) {
     w.zeros.ensure(64 * D8);
     HIP_CHECK(hipMemsetAsync(w.zeros.p, 0, 64 * D8, s));
@@ -2338,6 +2339,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       // right-hand side b: gradient of sum m_i J_i + barrier (the barrier arrays were written by the last eval_at at this point)
       launch_grad_prep(a, s);
       launch_bwd_fast(a, true, s);
+      if (Nc > 1) launch_cond_fast(a, s);  // off-diagonal blocks of the condensed Hessians
       launch_fwd_fast(a, s);  // (duc = 0: the particles' own Newton steps p_b, in dX / dU)
       // right-hand side a_i = grad J_i (unweighted, no barrier shift), same Hessian
       LQArgs ag = a;
@@ -2388,7 +2390,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         rhs[nc] = 0.0;
         for (int r = 0; r < nc; r++) A[r + (size_t)n1 * nc] = A[nc + (size_t)n1 * r] = 0.0;
       }
-      {  // Gaussian elimination with partial pivoting (the matrix is positive definite; n1 <= 5 on this path)
+      {  // Gaussian elimination with partial pivoting (the matrix is positive definite; n1 = Nc u + 1)
         std::vector<double> Mx = A;
         sol = rhs;
         for (int k = 0; k < n1; k++) {

@@ -200,3 +200,19 @@ def test_squareplus_smoothing_matches_the_direct_program(co, alpha, beta, copies
     assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
     if beta >= 20.0:  # a steep hinge keeps the controls (nearly) inside the boxes it replaces
         assert np.max(np.abs(U)) <= 0.4 + 0.05
+
+
+@pytest.mark.parametrize("copies,others,alpha,Nc", [(3, 3, 10.0, 2), (4, 2, 10.0, -1), (1, 6, 1.0, 3)])
+def test_logbarrier_smoothing_with_several_consensus_stages(co, copies, others, alpha, Nc):
+    """The reference's DEFAULT consensus horizon is Nc = N (main.jl:127-128): smoothing, ties and several shared stages together (the
+    condensing kernel supplies the off-diagonal blocks of the per-particle condensed Hessians to the Newton system)."""
+    from pmpc_amd import backend
+
+    if copies > 1:
+        args, kw = tied_problem(np.random.default_rng(500 + copies + others), copies, others, 6, 4, 2, 0.4, Nc)
+    else:
+        args, kw = rand_problem(np.random.default_rng(501), others, 6, 4, 2, 0.4)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, smooth_alpha=alpha, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=alpha, solver="ecos")
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(U))
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
