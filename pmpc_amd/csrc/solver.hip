@@ -142,7 +142,7 @@ struct SlabBufs {
 
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
-  DevBuf Hc_w, gc_w, cons_w, epi_lam, epi_out;
+  DevBuf Hc_w, gc_w, cons_w, epi_lam, epi_out, epi_gath;
   DevBuf es_Dx, es_wx, es_Du, es_wu, es_xm, es_xd, es_um, es_ud, es_kff2, es_kff3, es_gc2, es_dots, es_coef, es_out2, es_Xt, es_Ut, es_U, es_zero;  // smoothed cone objective (lcone_smooth_body)
   long long es_key = -1;  // consensus weights of the cone objective and the scaled copies the reductions read
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
@@ -522,7 +522,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   if (c->comm && c->mock_comm) delete (MockRank *)c->comm;
   else if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   Workspace &w = c->ws;
-  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.epi_lam, &w.epi_out, &w.es_Dx, &w.es_wx, &w.es_Du, &w.es_wu, &w.es_xm, &w.es_xd, &w.es_um, &w.es_ud, &w.es_kff2, &w.es_kff3, &w.es_gc2, &w.es_dots, &w.es_coef, &w.es_out2, &w.es_Xt, &w.es_Ut, &w.es_U, &w.es_zero, &w.scratch,
+  DevBuf *all[] = {&w.X, &w.U, &w.dX, &w.dU, &w.dX2, &w.dU2, &w.xm, &w.xd, &w.um, &w.ud, &w.K, &w.Hinv, &w.kff, &w.gc_part, &w.Hc_part, &w.Hc_w, &w.gc_w, &w.cons_w, &w.epi_lam, &w.epi_out, &w.epi_gath, &w.es_Dx, &w.es_wx, &w.es_Du, &w.es_wu, &w.es_xm, &w.es_xd, &w.es_um, &w.es_ud, &w.es_kff2, &w.es_kff3, &w.es_gc2, &w.es_dots, &w.es_coef, &w.es_out2, &w.es_Xt, &w.es_Ut, &w.es_U, &w.es_zero, &w.scratch,
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
@@ -2654,38 +2654,42 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
   // the threshold cost, 0 below, anything on it), the host solves that problem on those quadratics — ties among any number of
   // particles are ordinary degenerate rows there — and the next solve applies the result: one more round if no box changes status.
   const int Ncc = p->Nc < 0 ? (int)p->N : (int)std::min<long long>(p->Nc, (long long)p->N), ncv = Ncc * (int)p->udim;
-  const bool epi_on = c->opt[OPT_CONE_EPIGRAPH] != 0.0 && !(q.barrier_mu > 0.0) && !c->multi() && c->world == 1 &&
-                      (double)M * ncv * ncv <= 2e7 && !(p->flags & PMPC_FORCE_GENERIC);
+  // (sharded: every rank holds the multipliers of ALL particles, checks the gathered costs on the host and solves the same epigraph problem
+  //  on the all-gathered quadratics: identical decisions everywhere, as for the rank-based iteration)
+  const bool epi_multi = c->multi();
+  const bool epi_on = c->opt[OPT_CONE_EPIGRAPH] != 0.0 && !(q.barrier_mu > 0.0) && (double)M * ncv * ncv <= 2e7 && !(p->flags & PMPC_FORCE_GENERIC);
   if (epi_on) {
     pmpc_problem qq = *p;
     qq.weights = nullptr;
     qq.barrier_mu = 0.0;
     const double Ksum = (1.0 - eps) * kk, cap = 1.0 + eps;
-    std::vector<double> lam(M, Ksum / (double)M), cw(M);
+    std::vector<double> lam(M, Ksum / (double)M), cw(Ml), lam_loc(Ml);
     // KKT check of the epigraph rows on the device (k_epi_check): costs of the accepted point, threshold cost, violation — 32 bytes back.
     // Inside pmpc_scp_loop_device both kernels go in BEHIND the first batch of rounds, ahead of the speculative follow-up work (residual,
     // next linearisation), so the answer is there when the host has seen the rounds end.
-    if (w.epi_lam.ensure(M * D8)) c->epi_lam_host.clear();  // (fresh allocations hold nothing of what the host mirrors remember)
-    if (w.cons_w.ensure(M * D8)) c->cons_w_host.clear();
+    if (w.epi_lam.ensure(Ml * D8)) c->epi_lam_host.clear();  // (fresh allocations hold nothing of what the host mirrors remember)
+    if (w.cons_w.ensure(Ml * D8)) c->cons_w_host.clear();
     w.epi_out.ensure(4 * D8);
     double chk[4] = {0.0, 0.0, 0.0, 0.0};
     auto enqueue_check = [&]() {
       pmpc_particle_costs_device(c, p, p->X_out, p->U_out, w.Jc.d());
-      launch_epi_check(w.epi_lam.d(), w.Jc.d(), p->weights, (int)M, cap, w.epi_out.d(), s, c->mirror_dev->epi, &c->mirror_dev->epi_seq, ++c->epi_seq);
+      if (!epi_multi) launch_epi_check(w.epi_lam.d(), w.Jc.d(), p->weights, (int)Ml, cap, w.epi_out.d(), s, c->mirror_dev->epi, &c->mirror_dev->epi_seq, ++c->epi_seq);
     };
     int n_solves = 0, hook_solve = -1;
+    bool costs_on_host = false;
     auto solve_cons = [&](bool weighted) -> int {
       bool need = p->weights != nullptr || weighted;
       if (need) {
-        for (size_t i = 0; i < M; i++) cw[i] = (weighted ? lam[i] : 1.0) * user[i];
+        for (size_t i = 0; i < Ml; i++) cw[i] = (weighted ? lam[off + i] : 1.0) * user[off + i];
         if (c->cons_w_host != cw) {  // (unchanged since the last upload — the steady state of an SCP loop: nothing to send)
-          HIP_CHECK(hipMemcpyAsync(w.cons_w.p, cw.data(), M * D8, hipMemcpyHostToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.cons_w.p, cw.data(), Ml * D8, hipMemcpyHostToDevice, s));
           c->cons_w_host = cw;
         }
       }
-      if (c->epi_lam_host != lam) {
-        HIP_CHECK(hipMemcpyAsync(w.epi_lam.p, lam.data(), M * D8, hipMemcpyHostToDevice, s));
-        c->epi_lam_host = lam;
+      for (size_t i = 0; i < Ml; i++) lam_loc[i] = lam[off + i];
+      if (!epi_multi && c->epi_lam_host != lam_loc) {
+        HIP_CHECK(hipMemcpyAsync(w.epi_lam.p, lam_loc.data(), Ml * D8, hipMemcpyHostToDevice, s));
+        c->epi_lam_host = lam_loc;
       }
       c->cons_w_active = (need && ncv > 0) ? w.cons_w.d() : nullptr;
       bool fired_here = false;
@@ -2720,16 +2724,40 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
       last = inf;
       if (st_ != 0) return st_;
       if (!(fired_here && c->spec_ok)) enqueue_check();  // (what the hook computed saw unfinished outputs, or there was no hook)
+      if (epi_multi) {
+        // sharded: all costs to every rank (one all-reduce of a zero-padded vector), the same check on the host everywhere
+        gather(w.Jc.d(), J);
+        for (size_t i = 0; i < M; i++) J[i] *= user[i];
+        costs_on_host = true;
+        double tsum = 0.0, jmin_full = 1e300, jmax_zero = -1e300, viol = 0.0;
+        size_t nfr = 0;
+        for (size_t i = 0; i < M; i++) {
+          if (lam[i] > 1e-12 && lam[i] < cap - 1e-12) { tsum += J[i]; nfr++; }
+          else if (lam[i] >= cap - 1e-12) jmin_full = std::min(jmin_full, J[i]);
+          else jmax_zero = std::max(jmax_zero, J[i]);
+        }
+        const double th = nfr ? tsum / (double)nfr : ((jmin_full < 1e300 && jmax_zero > -1e300) ? 0.5 * (jmin_full + jmax_zero) : (jmin_full < 1e300 ? jmin_full : jmax_zero));
+        for (size_t i = 0; i < M; i++) {
+          if (!(J[i] == J[i])) viol = 1e300;
+          else if (lam[i] > 1e-12 && lam[i] < cap - 1e-12) viol = std::max(viol, std::fabs(J[i] - th));
+          else if (lam[i] >= cap - 1e-12) viol = std::max(viol, th - J[i]);
+          else viol = std::max(viol, J[i] - th);
+        }
+        chk[0] = viol; chk[1] = th; chk[2] = (double)nfr;
+        return 0;
+      }
+      costs_on_host = false;
       // (polled from the host-coherent mirror: the stream — which may hold the next linearisation behind the check — is not drained)
       wait_published(c, &c->mirror->epi_seq, c->epi_seq);
       memcpy(chk, (const void *)c->mirror->epi, 4 * D8);
       return 0;
     };
     auto fetch_costs = [&]() {
+      if (costs_on_host) return;
       gather(w.Jc.d(), J);
       for (size_t i = 0; i < M; i++) J[i] *= user[i];
     };
-    const long long lkey = ((((((long long)M * 1000003 + (long long)p->N) * 131 + (long long)p->xdim) * 131 + (long long)p->udim) * 131 + p->Nc + 2) * 1000003 + (long long)kk);
+    const long long lkey = (((((((long long)M * 1000003 + (long long)p->N) * 131 + (long long)p->xdim) * 131 + (long long)p->udim) * 131 + p->Nc + 2) * 1000003 + (long long)kk)) * 64 + c->world;
     int st_ = 0;
     if (ncv == 0) return finish(solve_cons(false));  // no shared controls: every particle minimises its own cost, whatever its multiplier
     const bool remembered = c->opt[OPT_CONE_RANK_MEMORY] != 0.0 && !(p->flags & PMPC_COLD_START) && c->cone_lam_key == lkey && c->cone_lam.size() == M;
@@ -2759,8 +2787,19 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
         break;
       }
       Hh.resize(M * (size_t)ncv * ncv); gh.resize(M * (size_t)ncv);
-      HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, Hh.size() * D8, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipMemcpyAsync(gh.data(), w.gc_part.p, gh.size() * D8, hipMemcpyDeviceToHost, s));
+      if (!epi_multi) {
+        HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, Hh.size() * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(gh.data(), w.gc_part.p, gh.size() * D8, hipMemcpyDeviceToHost, s));
+      } else {  // all-gather through one all-reduce of a zero-padded buffer [H of every particle | g of every particle]
+        const size_t nH = (size_t)ncv * ncv, tot = M * (nH + ncv);
+        w.epi_gath.ensure(tot * D8);
+        HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tot * D8, s));
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + off * nH, w.Hc_part.p, Ml * nH * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + M * nH + off * ncv, w.gc_part.p, Ml * (size_t)ncv * D8, hipMemcpyDeviceToDevice, s));
+        allreduce(c, w.epi_gath.p, tot, ncclFloat64, ncclSum);
+        HIP_CHECK(hipMemcpyAsync(Hh.data(), w.epi_gath.p, M * nH * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(gh.data(), w.epi_gath.d() + M * nH, M * (size_t)ncv * D8, hipMemcpyDeviceToHost, s));
+      }
       HIP_CHECK(hipMemcpyAsync(dl.data(), w.as_delta.p, ncv * D8, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipMemcpyAsync(act0.data(), w.as_act.p, ncv * sizeof(int), hipMemcpyDeviceToHost, s));  // (particle 0's stages < Nc come first)
       HIP_CHECK(hipStreamSynchronize(s));

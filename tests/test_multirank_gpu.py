@@ -157,6 +157,24 @@ def test_sharded_cone_path_matches_cone_oracle(world, kink, oracle):
     assert len({i["outer_solves"] for i in infos}) == 1 and infos[0]["outer_solves"] >= 2
 
 
+@pytest.mark.parametrize("world,copies,others,Nc", [(2, 5, 3, 1), (4, 5, 3, 1), (2, 3, 3, 2)])
+def test_sharded_cone_path_with_ties_matches_single_rank(world, copies, others, Nc):
+    """The epigraph path on sharded particles: every rank holds all multipliers, checks the gathered costs and solves the same epigraph
+    problem on the all-gathered condensed quadratics — `copies` identical cheapest particles (a `copies`-way tie on the threshold)
+    spread over the ranks.  Same answer as one rank (1e-8) and as the direct cone program (1e-6)."""
+    from oracle import cone_oracle as co
+    from tests.test_cone_ties_gpu import tied_problem
+
+    args, kw = tied_problem(np.random.default_rng(700 + world + copies + Nc), copies, others, 6, 4, 2, 0.4, Nc)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, **kw)
+    X1, U1, _ = _solve_sharded(args, kw, Nc, 1, cone=True)
+    Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, repeats=2, cone=True)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    assert rel(X1, Xo) < 1e-6 and rel(U1, Uo) < 1e-6, (rel(X1, Xo), rel(U1, Uo))
+    assert rel(Xw, X1) < 1e-8 and rel(Uw, U1) < 1e-8, (rel(Xw, X1), rel(Uw, U1))
+    assert np.all(Uw[:, :Nc] == Uw[0:1, :Nc])
+
+
 @pytest.mark.parametrize("Nc", [0, 1, -1])
 def test_sharded_stage_cones_match_oracle(Nc, oracle):
     """`pmpc_lsoc_solve_device` on 2 ranks: the complementarity sums, step lengths and failure flag cross ranks."""
