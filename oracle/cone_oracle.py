@@ -261,7 +261,8 @@ def lcone_problem_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x
             raise ValueError(f"Unknown smoothing method: [{smooth_cstr}]")
         # ---- ad hoc constraints (main.jl:293-316; only inside `if size(F, 1) > 0`, as upstream) --------------------------
         for (l, q, e, G_left, G_right, hh, c_left, c_right) in extra_cstrs:
-            G_left, G_right = sp.csr_matrix(G_left), sp.csr_matrix(np.asarray(G_right, dtype=np.float64).reshape(G_left.shape[0], -1))
+            G_left = sp.csr_matrix(G_left)
+            G_right = sp.csr_matrix(G_right) if sp.issparse(G_right) else sp.csr_matrix(np.asarray(G_right, dtype=np.float64).reshape(G_left.shape[0], -1))
             hh = np.asarray(hh, dtype=np.float64).reshape(-1)
             q = [int(v) for v in q]
             if smooth_cstr == "logbarrier":  # :299-312
@@ -471,7 +472,14 @@ def lcone_direct_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x,
         # Newton steps away from it
         qkw = {k_: kw.get(k_) for k_ in ("x_l", "x_u", "u_l", "u_u", "slew_reg", "slew_reg0", "slew_um1")}
         has_box = any(qkw[k_] is not None for k_ in ("x_l", "x_u", "u_l", "u_u"))
-        _, U0 = orc.lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=reg_x, reg_u=reg_u, Nc=Nc, barrier_mu=1.0 if has_box else 0.0, **qkw)
+        # (linear rows of extra_cstrs tuples join the boxes behind the barrier, so that the start is strictly inside them too)
+        rws = [(sp.csr_matrix(t[3])[:int(t[0])], np.asarray(t[5], dtype=np.float64).reshape(-1)[:int(t[0])]) for t in kw.get("extra_cstrs", ()) if int(t[0]) > 0]
+        rows = None
+        if rws:
+            Gs = [sp.hstack([g, sp.csr_matrix((g.shape[0], prob.nz - g.shape[1]))]) if g.shape[1] < prob.nz else g[:, :prob.nz] for g, _ in rws]
+            rows = (sp.vstack(Gs).tocsr(), np.concatenate([h_ for _, h_ in rws]))
+        _, U0 = orc.lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=reg_x, reg_u=reg_u, Nc=Nc,
+                                 barrier_mu=1.0 if (has_box or rows is not None) else 0.0, rows=rows, **qkw)
     xi0 = strictly_feasible_start(prob, U0, exp_convention=exp_convention)
     xi, info = conic_solve_py(prob, xi0, mu_final=mu_final, exp_convention=exp_convention, verbose=verbose)
     qp = orc.JointQP()

@@ -433,13 +433,20 @@ def solve_barrier_exact(qp: JointQP, mu, tol=1e-11, max_iter=200, verbose=False)
 # -------------------------------------------------------------------------------------------------
 def lqp_solve_abi(xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
                   reg_x, reg_u, slew_reg, slew_reg0, slew_um1, verbose=False, return_info=False, weights=None,
-                  barrier_mu=0.0):
+                  barrier_mu=0.0, rows=None, c_left=None):
     """Same argument list as `c_lqp_solve` (PMPC.jl/src/c_interface.jl:77-141) minus the output
     pointers; ABI-layout buffers in, X (M,N,x) / U (M,N,u) out (== the (x,N,M) / (u,N,M) the
     reference copies into X_out / U_out, c_interface.jl:138-139).  x0 is accepted and ignored, as
     in the reference (lqp_utils.jl:293-296)."""
     qp = assemble_abi(xdim, udim, N, M, Nc, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, lx, ux, lu, uu,
                       reg_x, reg_u, slew_reg, slew_reg0, slew_um1, weights=weights)
+    if rows is not None:  # ad hoc linear rows  G z <= h  over z = [U_cons; U_free; X] (the `l` part of an extra_cstrs tuple, main.jl:293-316)
+        Gr, hr = sp.csc_matrix(rows[0]), _f64(rows[1]).reshape(-1)
+        assert Gr.shape == (hr.size, qp.P.shape[0])
+        qp.G = sp.vstack([qp.G, Gr], format="csc")
+        qp.l, qp.u = np.concatenate([qp.l, np.full(hr.size, -np.inf)]), np.concatenate([qp.u, hr])
+    if c_left is not None:  # linear cost on z (augment_cone_problem!'s c_left, cone_utils.jl:147-148)
+        qp.q = qp.q + _f64(c_left).reshape(-1)
     if barrier_mu > 0.0 and qp.G.shape[0] > 0:
         z, info = solve_barrier_exact(qp, barrier_mu, verbose=verbose)
     else:
@@ -450,7 +457,7 @@ def lqp_solve_abi(xdim, udim, N, M, Nc, x0, f, fx, fu, X_prev, U_prev, Q, R, X_r
 
 def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, reg_u, Nc=-1, x_l=None, x_u=None,
                  u_l=None, u_u=None, slew_reg=None, slew_reg0=None, slew_um1=None, return_info=False, weights=None,
-                 barrier_mu=0.0):
+                 barrier_mu=0.0, rows=None, c_left=None):
     """py-layout convenience wrapper (batched: x0 (M,x), fx (M,N,x,x) ...).  `weights` (M,): per-particle cost
     multipliers (cf. scale_probs_cost!, main.jl:96-112)."""
     f = _f64(f)
@@ -465,7 +472,7 @@ def lqp_solve_py(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, *, reg_x, re
         xdim, udim, N, M, Nc, _f64(x0), f, to_abi_mat(fx), to_abi_mat(fu), _f64(X_prev), _f64(U_prev),
         to_abi_mat(Q), to_abi_mat(R), _f64(X_ref), _f64(U_ref), bx(x_l, nanx), bx(x_u, nanx), bx(u_l, nanu),
         bx(u_u, nanu), float(reg_x), float(reg_u), sr, sr0, um1, return_info=return_info, weights=weights,
-        barrier_mu=barrier_mu)
+        barrier_mu=barrier_mu, rows=rows, c_left=c_left)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -220,6 +220,7 @@ def aff_solve(
     # user constraints in the reference's tuple format (pyjulia only upstream, PMPC.jl/src/main.jl:293-316): the cases this
     # back end implements are folded in here; anything else is REFUSED, never dropped silently
     soc = None
+    aux_from = None  # (set when rows on the states were restated as auxiliary state components: stripped from the result)
     if solver_settings.get("extra_cstrs"):
         from .extra_cstrs import linear_rows_to_boxes, stage_cones_from_extra_cstrs, stage_soc_from_extra_cstrs
 
@@ -247,6 +248,30 @@ def aff_solve(
             if (u_l is None or u_l.size == 0) != (u_u is None or u_u.size == 0):
                 u_l = np.full(U_prev.shape, -np.inf) if u_l is None or u_l.size == 0 else u_l
                 u_u = np.full(U_prev.shape, np.inf) if u_u is None or u_u.size == 0 else u_u
+        # linear rows that involve STATES (obstacle half-spaces, rows coupling x and u of a stage): restated as upper bounds on auxiliary
+        # states that the dynamics produce (extra_cstrs.aux_state_problem) — the solve below then sees state boxes only
+        from scipy.sparse import csr_matrix as sp_csr
+
+        ncu_b = (Nb if Ncb < 0 else min(int(Ncb), Nb))
+        ncu_b = ncu_b * ud + Mb * (Nb - ncu_b) * ud
+        on_states = lambda c_: int(c_[0]) > 0 and sp_csr(c_[3]).shape[1] > ncu_b and sp_csr(c_[3])[:, ncu_b:].count_nonzero() > 0
+        state_rows = [c_ for c_ in rest if on_states(c_)]
+        if state_rows:
+            from .extra_cstrs import aux_state_problem, stage_rows_from_extra_cstrs
+
+            if len(state_rows) != len(rest):
+                raise ValueError("extra_cstrs: rows on the states together with cones on the controls are not supported in one solve")
+            if slew_rate or u_slew is not None or "slew_reg" in solver_settings:
+                raise ValueError("extra_cstrs: rows on the states are not supported together with slew penalties")
+            try:
+                rows = stage_rows_from_extra_cstrs(state_rows, Mb, Nb, xd, ud, Ncb)
+            except ValueError as e_rows:
+                raise ValueError(f"extra_cstrs: rows on the states must be linear rows on the state and control of ONE stage of one "
+                                 f"particle; this is not ({e_rows})") from None
+            aug = aux_state_problem(rows, x0, f, fx, fu, X_prev, U_prev, Q, X_ref, reg_x, x_l, x_u)
+            x0, f, fx, fu, X_prev, Q, X_ref, x_l, x_u = (aug[k_] for k_ in ("x0", "f", "fx", "fu", "X_prev", "Q", "X_ref", "x_l", "x_u"))
+            aux_from = xd
+            rest = []
         if rest:
             # conic rows inside one stage's controls: ONE second-order cone with the same data on every stage keeps the
             # path-following fallback (soc); anything else stage-local goes to the general form (several cones / linear rows
@@ -300,4 +325,6 @@ def aff_solve(
             skw = dict(smooth_cstr=solver_settings["smooth_cstr"], smooth_beta=solver_settings.get("smooth_beta", 1.0))
         X, U = lcone_solve(*args, smooth_alpha, verbose=verbose, solver=solver_settings["solver"], k=solver_settings.get("k"), **skw)
     X_traj = np.concatenate([np.swapaxes(x0, -1, -2)[:, None, :], X], -2)  # static_backend.py:311
+    if aux_from is not None:
+        X_traj = np.ascontiguousarray(X_traj[..., :aux_from])
     return X_traj, U, dict()

@@ -2159,7 +2159,7 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
 // and Sherman-Morrison folds the term into the (Nc u + 1)-dimensional system of the shared controls and t, assembled on the host from
 // per-particle scalars.  Returns -1 when the problem is outside what this path covers (the caller takes the weighted-QP iteration).
 // -------------------------------------------------------------------------------------------------
-static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pmpc_info *info, int verbose, int smode = 0, double sbeta = 1.0) {
+static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pmpc_info *info, int verbose, int smode = 0, double sbeta = 1.0, bool phase1_start = false) {
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
   const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
@@ -2282,7 +2282,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   };
   // ---- starting point: the previous smoothed solution of this shape (strictly inside the same boxes), else the caller's U_prev pulled inside ----
   const long long skey = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0)) * 2 + smode;
-  bool warm = !(p->flags & PMPC_COLD_START) && w.es_key == skey && w.es_U.bytes >= nu * D8;
+  bool warm = (phase1_start || !(p->flags & PMPC_COLD_START)) && w.es_key == skey && w.es_U.bytes >= nu * D8;
   const bool lam_mem = c->opt[OPT_CONE_RANK_MEMORY] != 0.0 && !(p->flags & PMPC_COLD_START) && c->cone_lam_key == -(skey + 7) && (int)c->cone_lam.size() == M;
   if (lam_mem) lam = c->cone_lam;
   c->cone_lam_key = -1;
@@ -2298,6 +2298,23 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     eval_at(w.X.d(), w.U.d(), J);
     if (out2[1] > 0.0 && out2[0] == out2[0]) break;
     if (warm) { warm = false; continue; }
+    if (has_xb && !phase1_start) {
+      // the caller's controls roll out to states outside their boxes (nothing pulls a STATE inside): phase 1 = the plain-sum problem with
+      // the same barrier (the library's interior-point iteration starts anywhere); its controls are strictly inside everything
+      pmpc_problem q1 = *p;
+      q1.weights = nullptr;
+      q1.barrier_mu = mu_b;
+      q1.flags |= PMPC_COLD_START;
+      pmpc_info i1;
+      const int st1 = pmpc_lqp_solve_device(c, &q1, &i1, 0);
+      if (verbose) printf("pmpc_hip: smoothed cone objective: start outside the state boxes (smallest slack %.3e); phase 1 (barrier QP) status %d\n", out2[1], st1);
+      if (st1 == 0) {
+        w.es_U.ensure(nu * D8);
+        HIP_CHECK(hipMemcpyAsync(w.es_U.p, p->U_out, nu * D8, hipMemcpyDeviceToDevice, s));
+        w.es_key = skey;
+        return lcone_smooth_body(c, p, mu_b, info, verbose, smode, sbeta, true);  // (the QP solve may have moved workspace buffers: start over)
+      }
+    }
     if (verbose) printf("pmpc_hip: smoothed cone objective: no strictly feasible start (smallest slack %.3e)\n", out2[1]);
     return finish(1);
   }

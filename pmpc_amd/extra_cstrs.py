@@ -205,3 +205,132 @@ def stage_cones_from_extra_cstrs(cstrs: Sequence[Sequence[Any]], M: int, N: int,
             A[i, Ncc + j], c[i, Ncc + j] = Ab, cb
     return dict(sizes=sizes, A=A, c=c)
 
+
+
+def _decode_column(col: int, M: int, N: int, xdim: int, udim: int, Ncc: int):
+    """Column of z = [U_cons; U_free; X] (lqp_utils.jl:12-15, split_lqp_vars :395-423) -> (kind, particle or None, stage, component)."""
+    Nf = N - Ncc
+    ncu = Ncc * udim + M * Nf * udim
+    if col < Ncc * udim:
+        j, r = divmod(col, udim)
+        return "u", None, j, r
+    if col < ncu:
+        i, rest = divmod(col - Ncc * udim, Nf * udim)
+        j, r = divmod(rest, udim)
+        return "u", i, Ncc + j, r
+    i, rest = divmod(col - ncu, N * xdim)
+    j, r = divmod(rest, xdim)
+    return "x", i, j, r
+
+
+def stage_rows_from_extra_cstrs(cstrs: Sequence[Sequence[Any]], M: int, N: int, xdim: int, udim: int, Nc: int):
+    """Linear rows `G z <= h` (the `l` part of `extra_cstrs` tuples, cone_solver.jl:163-166) that couple the STATE and the CONTROL of one
+    stage of one particle:  a_x'X[i, t] + a_u'U[i, t] <= h  (array indices: x_{t+1} with u_t, the pair one step of the dynamics links), or
+    a_x'X[i, t-1] + a_u'U[i, t] <= h  (x_t with u_t, the pair of one stage of the optimal-control problem); either part may be absent.
+    Returns a list of `(i, t, form, a_x, a_u, h)`, form 0 / 1 as above, `t` the index of the state array at which `aux_state_problem`
+    bounds the row's value.  Raises `ValueError` with the reason for anything else: cones, new variables, cost terms, rows coupling
+    particles or stages further apart."""
+    Ncc = N if Nc < 0 else min(int(Nc), N)
+    n = Ncc * udim + M * (N - Ncc) * udim + M * N * xdim
+    out = []
+    for cstr in cstrs:
+        l, q, e, G_left, G_right, h, c_left, c_right = cstr
+        if (np.size(q) and sum(int(v) for v in np.atleast_1d(q)) > 0) or int(e) != 0:
+            raise ValueError("rows on the states are supported as linear rows only (no second-order or exponential cones on states)")
+        if G_right is not None and np.size(G_right) > 0 and sp.csr_matrix(G_right).shape[1] > 0:
+            raise ValueError("rows that introduce new variables (G_right) are not supported")
+        for cv in (c_left, c_right):
+            if cv is not None and np.size(cv) > 0 and np.any(np.asarray(cv, dtype=np.float64) != 0.0):
+                raise ValueError("cost augmentation (c_left / c_right) is not supported")
+        G = sp.csr_matrix(G_left, dtype=np.float64)
+        G.eliminate_zeros()
+        hv = np.asarray(h, dtype=np.float64).reshape(-1)
+        if G.shape[0] != int(l) or hv.size != int(l) or G.shape[1] > n:
+            raise ValueError(f"G_left must have {int(l)} rows over (a prefix of) z = [U_cons; U_free; X] ({n} columns), h ({int(l)},)")
+        for r in range(int(l)):
+            cols, vals = G.indices[G.indptr[r]:G.indptr[r + 1]], G.data[G.indptr[r]:G.indptr[r + 1]]
+            if cols.size == 0:
+                raise ValueError(f"row {r} touches no variable")
+            a_x, a_u = np.zeros(xdim), np.zeros(udim)
+            parts, sx, su = set(), set(), set()
+            for col, v in zip(cols, vals):
+                kind, i, j, comp = _decode_column(int(col), M, N, xdim, udim, Ncc)
+                if i is not None:
+                    parts.add(i)
+                if kind == "x":
+                    sx.add(j)
+                    a_x[comp] = v
+                else:
+                    su.add(j)
+                    a_u[comp] = v
+            if len(parts) > 1:
+                raise ValueError(f"row {r} couples several particles")
+            if len(sx) > 1 or len(su) > 1:
+                raise ValueError(f"row {r} couples several stages")
+            i = parts.pop() if parts else 0  # (a row on shared controls alone: one row of the joint problem, carried by particle 0)
+            if sx and su:
+                jx, ju = next(iter(sx)), next(iter(su))
+                if ju == jx:
+                    out.append((i, jx, 0, a_x, a_u, float(hv[r])))
+                elif ju == jx + 1:
+                    out.append((i, ju, 1, a_x, a_u, float(hv[r])))
+                else:
+                    raise ValueError(f"row {r} couples state stage {jx} with control stage {ju}: only the same array index (x_(t+1), u_t) "
+                                     "or the same stage (x_t, u_t) are supported")
+            elif sx:
+                out.append((i, next(iter(sx)), 0, a_x, a_u, float(hv[r])))
+            else:
+                out.append((i, next(iter(su)), 0, a_x, a_u, float(hv[r])))
+    return out
+
+
+def aux_state_problem(rows, x0, f, fx, fu, X_prev, U_prev, Q, X_ref, reg_x, x_l, x_u):
+    """The problem with every row of `stage_rows_from_extra_cstrs` restated as an UPPER BOUND ON AN AUXILIARY STATE (py layout, batched
+    arrays in and out): the state grows by `m` components (the largest number of rows any (particle, stage) carries), component `xdim + s`
+    of x~_(t+1) is the row's left-hand side as the linearised dynamics produce it,
+
+        form 0:  xi = a_x'x_(t+1) + a_u'u_t = a_x'f_t + a_u'up_t + (a_x'fx_t)(x_t - xp_t) + (a_x'fu_t + a_u')(u_t - up_t)
+        form 1:  xi = a_x'x_t + a_u'u_t     = a_x'xp_t + a_u'up_t + a_x'(x_t - xp_t) + a_u'(u_t - up_t)
+
+    (xp, up: the linearisation point, lqp_utils.jl:233-290), and the row is the box  xi <= h  on it — which the device solver holds with
+    the semismooth state rows of `kernels_xbox.hip` (hard boxes) or the barrier (smoothing: the reference smooths `extra_cstrs` rows with
+    the boxes too, main.jl:298-312).  The auxiliary components carry NO cost: their block of Q is -reg_x and their reference and previous
+    value 0, so that the cost term -reg_x/2 xi^2 and the reference's proximal term +reg_x/2 xi^2 cancel exactly (value, gradient, Hessian).
+    Returns dict(x0, f, fx, fu, X_prev, Q, X_ref, x_l, x_u, m)."""
+    M, N, xdim = f.shape
+    udim = fu.shape[-1]
+    slot = {}
+    for (i, t, form, a_x, a_u, h) in rows:
+        if form == 1 and t < 1:
+            raise ValueError("a row on (x_t, u_t) needs t >= 1 (x_0 is data)")
+        slot.setdefault((i, t), []).append((form, a_x, a_u, h))
+    m = max(len(v) for v in slot.values())
+    xd = xdim + m
+    F = np.zeros((M, N, xd)); F[..., :xdim] = f
+    FX = np.zeros((M, N, xd, xd)); FX[..., :xdim, :xdim] = fx
+    FU = np.zeros((M, N, xd, udim)); FU[..., :xdim, :] = fu
+    XP = np.zeros((M, N, xd)); XP[..., :xdim] = X_prev
+    XR = np.zeros((M, N, xd)); XR[..., :xdim] = X_ref
+    QQ = np.zeros((M, N, xd, xd)); QQ[..., :xdim, :xdim] = Q
+    QQ[..., np.arange(xdim, xd), np.arange(xdim, xd)] = -float(reg_x)
+    X0 = np.zeros((M, xd)); X0[:, :xdim] = x0
+    lo = np.full((M, N, xd), -np.inf); hi = np.full((M, N, xd), np.inf)
+    if x_l is not None and np.size(x_l):
+        lo[..., :xdim] = np.broadcast_to(x_l, (M, N, xdim))
+    if x_u is not None and np.size(x_u):
+        hi[..., :xdim] = np.broadcast_to(x_u, (M, N, xdim))
+    lo[np.isnan(lo)], hi[np.isnan(hi)] = -np.inf, np.inf
+    for (i, t), lst in slot.items():
+        up = U_prev[i, t]
+        for s, (form, a_x, a_u, h) in enumerate(lst):
+            c = xdim + s
+            if form == 0:
+                F[i, t, c] = a_x @ f[i, t] + a_u @ up
+                FX[i, t, c, :xdim] = a_x @ fx[i, t]
+                FU[i, t, c] = a_x @ fu[i, t] + a_u
+            else:
+                F[i, t, c] = a_x @ X_prev[i, t - 1] + a_u @ up
+                FX[i, t, c, :xdim] = a_x
+                FU[i, t, c] = a_u
+            hi[i, t, c] = h
+    return dict(x0=X0, f=F, fx=FX, fu=FU, X_prev=XP, Q=QQ, X_ref=XR, x_l=lo, x_u=hi, m=m)

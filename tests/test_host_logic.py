@@ -471,3 +471,50 @@ def test_cone_rounds_model_matches_the_cone_oracle_over_an_scp_sequence(oracle):
         rounds.append(r)
         state, Xp, Up = (U, z, act, apex), X, U
     assert max(rounds) <= 12, rounds
+
+
+def test_state_rows_restated_as_auxiliary_states_are_the_same_problem(oracle):
+    """`extra_cstrs` rows on the state and control of one stage (main.jl:293-316) -> upper bounds on auxiliary states the dynamics
+    produce (`pmpc_amd.extra_cstrs.aux_state_problem`): the oracle solves the joint QP with the rows as rows, and the restated problem
+    with state boxes only — the same minimiser to round-off (the auxiliary block's cost -reg_x cancels the proximal term exactly)."""
+    import scipy.sparse as sp
+
+    from pmpc_amd.extra_cstrs import aux_state_problem, stage_rows_from_extra_cstrs
+    from tests.support.problems import rand_problem
+
+    rng = np.random.default_rng(0)
+    M, N, x, u, Nc = 3, 6, 4, 2, 1
+    args, kw = rand_problem(rng, M, N, x, u, 1.0)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    X0, U0 = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    ncu = Nc * u + M * (N - Nc) * u
+    n = ncu + M * N * x
+    xcol = lambda i, j, r: ncu + (i * N + j) * x + r
+    ucol = lambda i, j, r: j * u + r if j < Nc else Nc * u + (i * (N - Nc) + (j - Nc)) * u + r
+    spec = [(0, 2, 0), (1, 3, 1), (2, 0, 0), (0, 2, 0), (1, 5, 0)]
+    G, h = np.zeros((len(spec), n)), np.zeros(len(spec))
+    for k, (i, t, form) in enumerate(spec):
+        a, b = rng.standard_normal(x), rng.standard_normal(u)
+        jx = t - 1 if form == 1 else t
+        for r in range(x):
+            G[k, xcol(i, jx, r)] = a[r]
+        for r in range(u):
+            G[k, ucol(i, t, r)] = b[r]
+        h[k] = a @ X0[i, jx] + b @ U0[i, t] - 0.3
+    cstr = (len(h), [], 0, sp.csr_matrix(G), sp.csr_matrix((len(h), 0)), h, np.zeros(n), np.zeros(0))
+    rows = stage_rows_from_extra_cstrs([cstr], M, N, x, u, Nc)
+    assert [(r[0], r[1], r[2]) for r in rows] == spec
+    aug = aux_state_problem(rows, x0, f, fx, fu, X_prev, U_prev, Q, X_ref, kw["reg_x"], None, None)
+    assert aug["m"] == 2 and aug["f"].shape == (M, N, x + 2)
+    Xa, Ua = oracle.lqp_solve_py(aug["x0"], aug["f"], aug["fx"], aug["fu"], aug["X_prev"], U_prev, aug["Q"], R, aug["X_ref"], U_ref, reg_x=kw["reg_x"],
+                                 reg_u=kw["reg_u"], Nc=Nc, u_l=kw["u_l"], u_u=kw["u_u"], x_l=aug["x_l"], x_u=aug["x_u"])
+    Xd, Ud = oracle.lqp_solve_py(*args, Nc=Nc, rows=(sp.csr_matrix(G), h), **kw)
+    assert np.abs(Xd - X0).max() > 1e-2
+    assert np.abs(Xa[..., :x] - Xd).max() < 1e-9 and np.abs(Ua - Ud).max() < 1e-9
+    # refusals name the reason
+    bad = np.zeros((1, n)); bad[0, xcol(0, 1, 0)] = 1.0; bad[0, xcol(1, 1, 0)] = 1.0
+    with pytest.raises(ValueError, match="several particles"):
+        stage_rows_from_extra_cstrs([(1, [], 0, bad, np.zeros((1, 0)), np.ones(1), np.zeros(n), np.zeros(0))], M, N, x, u, Nc)
+    bad = np.zeros((1, n)); bad[0, xcol(0, 0, 0)] = 1.0; bad[0, ucol(0, 3, 0)] = 1.0
+    with pytest.raises(ValueError, match="couples state stage"):
+        stage_rows_from_extra_cstrs([(1, [], 0, bad, np.zeros((1, 0)), np.ones(1), np.zeros(n), np.zeros(0))], M, N, x, u, Nc)
