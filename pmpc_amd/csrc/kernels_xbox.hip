@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
       if (nst != st || deferred) changed++;
       else if (nst != 0) {
         const double sv = nst == 1 ? sl : sh, bd = nst == 1 ? lo : hi;
-        if (fabs(sv) > a.tol * fmax(1.0, fabs(bd)) || fabs(zo - z) > 1e-6 * fmax(a.dual_scale, fabs(zo))) open++;
+        if (fabs(sv) > a.tol * fmax(1.0, fabs(bd)) || fabs(zo - z) > a.z_tol * fmax(a.dual_scale, fabs(zo))) open++;
       }
     }
     a.st[idx] = nst;

@@ -281,6 +281,7 @@ struct XboxArgs {
   const AsCtl *ctl;
   int finish;                // 0: prepare only (first round of an attempt)
   double tol, dual_scale;
+  double z_tol;              // a held row stays open while its multiplier still moves by more than this (relative)
   int keep_on_clamp;         // a sweep whose forward pass clamped a control of the particle keeps the old multipliers
   double act_frac;           // a round holds only the violated rows within this fraction of the particle's largest violation (0: all)
   int ctrl_from;             // state entries r >= ctrl_from are controls in disguise (slew increment form): always held when violated
