@@ -615,22 +615,20 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
 
   for (int j = jstart; j < Nc; j++) {
     // A operand of A~_j: lane (c, g), step r <-> fx_j[pi(c)][pi(g + 4r)];  of Y_j: record[(g + 4r) + 16 c], rows c < UD
-    double Aop[KS], Yop[KS];
+    static_assert(LT::XP + UD <= 16 && KS <= 3, "fused [A; Y] operand: the state rows and the control rows share one 16-row tile");
+  // ONE A operand for both products: rows c < XP are A~_j (kernel order), rows XP + b row b of Y_j (XP + UD <= 16 for every compiled
+    // pair) — the result's registers r < KS are A~_j Gamma (the next Gamma), register KS is Y_j Gamma in row XP + g: half the MFMAs
+    double Top[KS];
     const double *fx = a.fx + (pbase + j) * (XD * XD), *rec = a.K + (pbase + j) * 64;
 #pragma unroll
-    for (int r = 0; r < KS; r++) {
-      Aop[r] = (j > 0 && L.cxv && kv[r]) ? fx[(KS * g + r) * XD + L.oc] : 0.0;
-      Yop[r] = (j > 0 && c < UD) ? rec[(g + 4 * r) + 16 * c] : 0.0;
-    }
+    for (int r = 0; r < KS; r++) Top[r] = j > 0 ? ((L.cxv && kv[r]) ? fx[(KS * g + r) * XD + L.oc] : (L.cu ? rec[(g + 4 * r) + 16 * L.cb] : 0.0)) : 0.0;
     const double *fu = a.fu + (pbase + j) * (XD * UD);
     if (dd) {
-      v4d o = {0.0, 0.0, 0.0, 0.0}, n = {0.0, 0.0, 0.0, 0.0};
+      v4d n = {0.0, 0.0, 0.0, 0.0};
       if (j > 0) {
 #pragma unroll
-        for (int r = 0; r < KS; r++) o = mfma(Yop[r], Dm[r], o);
-#pragma unroll
-        for (int r = 0; r < KS; r++) n = mfma(Aop[r], Dm[r], n);
-        if (c == 0 && g < UD) a.gc_part[(size_t)i * nc + j * UD + g] += o[0];
+        for (int r = 0; r < KS; r++) n = mfma(Top[r], Dm[r], n);
+        if (c == 0 && g < UD) a.gc_part[(size_t)i * nc + j * UD + g] += n[KS];
       }
 #pragma unroll
       for (int r = 0; r < KS; r++) {
@@ -645,12 +643,10 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
       if (qt >= nc) continue;  // wave-uniform
       const int q = qt + c;
       if (qt < j * UD) {  // some column of this tile started before stage j (wave-uniform)
-        v4d o = {0.0, 0.0, 0.0, 0.0}, n = {0.0, 0.0, 0.0, 0.0};
+        v4d n = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < KS; r++) o = mfma(Yop[r], Gm[k][r], o);
-#pragma unroll
-        for (int r = 0; r < KS; r++) n = mfma(Aop[r], Gm[k][r], n);
-        if (g < UD && q < j * UD) Hc[(size_t)q + (size_t)nc * (j * UD + g)] = o[0];
+        for (int r = 0; r < KS; r++) n = mfma(Top[r], Gm[k][r], n);
+        if (g < UD && q < j * UD) Hc[(size_t)q + (size_t)nc * (j * UD + g)] = n[KS];
 #pragma unroll
         for (int r = 0; r < KS; r++) Gm[k][r] = n[r];
       }
@@ -658,6 +654,104 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
         const int b = q - j * UD;
 #pragma unroll
         for (int r = 0; r < KS; r++) Gm[k][r] = kv[r] ? fu[b * XD + KS * g + r] : 0.0;
+      }
+    }
+  }
+}
+
+// The same walk with the particles' blocks SUMMED before they leave the chip (a.Hc_grp): COND_GRP waves = COND_GRP particles per
+// workgroup, every stage's blocks reduced across the waves through LDS, one slab of partial sums per workgroup instead of one per
+// particle.  At full consensus (Nc = N = 50, u = 4, M = 4096) the per-particle Hessians are 1.3 GB written here and read again by the
+// reduction — the two largest kernels of that workload —; the group sums are 1/COND_GRP of that.  The diagonal blocks (written into
+// Hc_part by the factor sweep) are folded in on the way, so the slab is the complete upper triangle.  For solves that never look at
+// one particle's H_i again (no settled-particle refresh, no consensus weights, no epigraph problem on the host).
+constexpr int COND_GRP = 8;
+template <int XD, int UD>
+__global__ void __launch_bounds__(64 * COND_GRP) k_cond_fast_grouped(LQArgs a) {
+  typedef Lane<XD, UD> LT;
+  constexpr int KS = LT::KS;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const LT L(lane);
+  const int N = a.N, Nc = a.Nc, nc = Nc * UD, g = L.g, c = L.c;
+  if (a.done && *a.done) return;
+  const int ip = blockIdx.x * COND_GRP + wv;
+  const bool live = ip < a.M;
+  const int i = live ? ip : 0;  // (a wave beyond the last particle walks particle 0's data and contributes zeros: it must reach the barriers)
+  const size_t pbase = (size_t)i * N;
+  const int t0 = blockIdx.y * COND_TPW;
+  const int jstart = (16 * t0) / UD;
+  const double *Hd = a.Hc_part + (size_t)i * nc * nc;
+  double *Hg = a.Hc_grp + (size_t)blockIdx.x * nc * nc;
+  __shared__ double red[2][COND_TPW][COND_GRP][64];
+  double Gm[COND_TPW][KS];
+#pragma unroll
+  for (int k = 0; k < COND_TPW; k++)
+#pragma unroll
+    for (int r = 0; r < KS; r++) Gm[k][r] = 0.0;
+  bool kv[KS];
+#pragma unroll
+  for (int r = 0; r < KS; r++) kv[r] = (KS * g + r) < XD;
+  const bool dd = a.defect != nullptr && blockIdx.y == 0;
+  double Dm[KS];
+#pragma unroll
+  for (int r = 0; r < KS; r++) Dm[r] = 0.0;
+
+  for (int j = jstart; j < Nc; j++) {
+    static_assert(LT::XP + UD <= 16 && KS <= 3, "fused [A; Y] operand: the state rows and the control rows share one 16-row tile");
+  // ONE A operand for both products: rows c < XP are A~_j (kernel order), rows XP + b row b of Y_j (XP + UD <= 16 for every compiled
+    // pair) — the result's registers r < KS are A~_j Gamma (the next Gamma), register KS is Y_j Gamma in row XP + g: half the MFMAs
+    double Top[KS];
+    const double *fx = a.fx + (pbase + j) * (XD * XD), *rec = a.K + (pbase + j) * 64;
+#pragma unroll
+    for (int r = 0; r < KS; r++) Top[r] = j > 0 ? ((L.cxv && kv[r]) ? fx[(KS * g + r) * XD + L.oc] : (L.cu ? rec[(g + 4 * r) + 16 * L.cb] : 0.0)) : 0.0;
+    const double *fu = a.fu + (pbase + j) * (XD * UD);
+    if (dd) {
+      v4d n = {0.0, 0.0, 0.0, 0.0};
+      if (j > 0) {
+#pragma unroll
+        for (int r = 0; r < KS; r++) n = mfma(Top[r], Dm[r], n);
+        if (live && c == 0 && g < UD) a.gc_part[(size_t)i * nc + j * UD + g] += n[KS];
+      }
+#pragma unroll
+      for (int r = 0; r < KS; r++) {
+        const bool mine = c == 0 && kv[r];
+        const size_t e = (pbase + j) * XD + KS * g + r;
+        Dm[r] = mine ? n[r] + (a.defect[mine ? e : 0] - a.X_prev[mine ? e : 0]) : 0.0;
+      }
+    }
+    const int buf = j & 1;
+#pragma unroll
+    for (int k = 0; k < COND_TPW; k++) {
+      const int qt = 16 * (t0 + k);
+      if (qt >= nc) continue;  // block-uniform
+      const int q = qt + c;
+      double out = 0.0;
+      if (qt < j * UD) {
+        v4d n = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < KS; r++) n = mfma(Top[r], Gm[k][r], n);
+        if (g < UD && q < j * UD) out = n[KS];
+#pragma unroll
+        for (int r = 0; r < KS; r++) Gm[k][r] = n[r];
+      }
+      // diagonal block of stage j, upper triangle (the factor sweep left H_uu there)
+      if (g < UD && q < nc && q / UD == j && q <= j * UD + g) out = Hd[(size_t)q + (size_t)nc * (j * UD + g)];
+      if (qt < (j + 1) * UD) red[buf][k][wv][lane] = live ? out : 0.0;
+      if (q < nc && q / UD == j) {  // Gamma_{j,j} = B_j
+        const int b = q - j * UD;
+#pragma unroll
+        for (int r = 0; r < KS; r++) Gm[k][r] = kv[r] ? fu[b * XD + KS * g + r] : 0.0;
+      }
+    }
+    __syncthreads();
+    // wave k sums tile k over the particles of the group (the next stage writes the other buffer: one barrier per stage)
+    if (wv < COND_TPW) {
+      const int qt = 16 * (t0 + wv), q = qt + c;
+      if (qt < nc && qt < (j + 1) * UD && g < UD && q < nc && q <= j * UD + g) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < COND_GRP; w++) acc += red[buf][wv][w][lane];
+        Hg[(size_t)q + (size_t)nc * (j * UD + g)] = acc;
       }
     }
   }
@@ -688,7 +782,8 @@ void launch_bwd_t(const LQArgs &a, bool factor, hipStream_t s) {
 template <int XD, int UD>
 void launch_cond_t(const LQArgs &a, hipStream_t s) {
   const int ntiles = (a.Nc * UD + 15) / 16;
-  hipLaunchKernelGGL((k_cond_fast<XD, UD>), dim3(a.M, (ntiles + COND_TPW - 1) / COND_TPW), dim3(64), 0, s, a);
+  if (a.Hc_grp) hipLaunchKernelGGL((k_cond_fast_grouped<XD, UD>), dim3((a.M + COND_GRP - 1) / COND_GRP, (ntiles + COND_TPW - 1) / COND_TPW), dim3(64 * COND_GRP), 0, s, a);
+  else hipLaunchKernelGGL((k_cond_fast<XD, UD>), dim3(a.M, (ntiles + COND_TPW - 1) / COND_TPW), dim3(64), 0, s, a);
 }
 template <int XD, int UD>
 void launch_fwd_t(const LQArgs &a, hipStream_t s) {
@@ -718,6 +813,7 @@ void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s) {
   abort();
 }
 
+int cond_fast_groups(int M) { return (M + COND_GRP - 1) / COND_GRP; }
 void launch_cond_fast(const LQArgs &a, hipStream_t s) {
   if (a.Nc <= 1) return;
 #define X(xd, ud) if (a.x == xd && a.u == ud) { launch_cond_t<xd, ud>(a, s); return; }

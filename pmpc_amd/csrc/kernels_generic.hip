@@ -1019,7 +1019,7 @@ void launch_fwd_generic(const LQArgs &a, hipStream_t s) {
 }
 
 // [Hc | gc] in one pass: entries e < EH come from srcH (stride EH), the rest from srcG (stride EG); dst = [G][EH + EG]
-__global__ void __launch_bounds__(256) k_reduce_particles_hg(const double *srcH, const double *srcG, double *dst, int M, int EH, int EG) {
+__global__ void __launch_bounds__(256) k_reduce_particles_hg(const double *srcH, const double *srcG, double *dst, int MH, int M, int EH, int EG) {
   __shared__ double red[4][64];
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int e = blockIdx.x * 64 + tx, E = EH + EG;
@@ -1030,22 +1030,24 @@ __global__ void __launch_bounds__(256) k_reduce_particles_hg(const double *srcH,
   if (e < E && !lower) {
     const double *src = e < EH ? srcH + e : srcG + (e - EH);
     const int stride = e < EH ? EH : EG;
-    for (int i = blockIdx.y * 4 + ty; i < M; i += 4 * gridDim.y) acc += src[(size_t)i * stride];
+    const int Mi = e < EH ? MH : M;  // (the H slabs may be group sums: fewer of them than particles)
+    for (int i = blockIdx.y * 4 + ty; i < Mi; i += 4 * gridDim.y) acc += src[(size_t)i * stride];
   }
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && e < E) dst[(size_t)blockIdx.y * E + e] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 // Hg = [Hc | gc] (contiguous, as the all-reduce wants it) from the particle partials: two launches instead of four
-void launch_reduce_particles_hg(const double *Hc_part, const double *gc_part, double *tmp, double *Hg, int M, int nc, hipStream_t s) {
+void launch_reduce_particles_hg(const double *Hc_part, const double *gc_part, double *tmp, double *Hg, int M, int nc, hipStream_t s, int MH) {
+  if (MH < 0) MH = M;
   const int EH = nc * nc, E = EH + nc;
   int gy = (M + 3) / 4;
   if (gy > 64) gy = 64;
   dim3 blk(64, 4), grd((E + 63) / 64, gy);
   if (gy == 1) {
-    hipLaunchKernelGGL(k_reduce_particles_hg, grd, blk, 0, s, Hc_part, gc_part, Hg, M, EH, nc);
+    hipLaunchKernelGGL(k_reduce_particles_hg, grd, blk, 0, s, Hc_part, gc_part, Hg, MH, M, EH, nc);
   } else {
-    hipLaunchKernelGGL(k_reduce_particles_hg, grd, blk, 0, s, Hc_part, gc_part, tmp, M, EH, nc);
+    hipLaunchKernelGGL(k_reduce_particles_hg, grd, blk, 0, s, Hc_part, gc_part, tmp, MH, M, EH, nc);
     hipLaunchKernelGGL(k_reduce_particles, dim3((E + 63) / 64, 1), blk, 0, s, (const double *)tmp, Hg, gy, E);
   }
 }

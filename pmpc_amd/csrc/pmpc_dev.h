@@ -82,6 +82,7 @@ struct LQArgs {
   // consensus condensing
   double *gc_part;  // [M][nc]
   double *Hc_part;  // [M][nc*nc]
+  double *Hc_grp;   // [groups][nc*nc] or null: the condensing kernel sums the particles of a workgroup before storing (k_cond_fast_grouped)
   double *scratch;  // [M][3*n*nc]
   const double *duc;  // [nc] consensus step
   // outputs of the forward sweep
@@ -181,7 +182,7 @@ size_t lq_generic_lds_bytes(const LQArgs &a);
 void launch_rollout(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_bwd_generic(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_generic(const LQArgs &a, hipStream_t s);
-void launch_reduce_particles_hg(const double *Hc_part, const double *gc_part, double *tmp, double *Hg, int M, int nc, hipStream_t s);
+void launch_reduce_particles_hg(const double *Hc_part, const double *gc_part, double *tmp, double *Hg, int M, int nc, hipStream_t s, int MH = -1);  // MH: slabs of H (default M)
 void launch_reduce_particles(const double *src, double *tmp, double *dst, int M, int E, hipStream_t s);
 // a round-control call (k_as_ctl's arguments) that rides in the next consensus-partials launch instead of a launch of its own
 struct AsCtlCall {
@@ -212,6 +213,7 @@ void launch_cons_scale(const double *Hc_part, const double *gc_part, const doubl
 bool lq_fast_supported(const LQArgs &a);
 void launch_bwd_fast(const LQArgs &a, bool factor, hipStream_t s);
 void launch_fwd_fast(const LQArgs &a, hipStream_t s);
+int cond_fast_groups(int M);  // slabs of LQArgs::Hc_grp
 void launch_cond_fast(const LQArgs &a, hipStream_t s);  // off-diagonal blocks of the condensed consensus Hessian (Nc > 1)
 void launch_rollout_fast(const LQArgs &a, const double *U, double *X, hipStream_t s);
 void launch_grad_prep(const LQArgs &a, hipStream_t s);

@@ -143,6 +143,7 @@ struct SlabBufs {
 struct Workspace {
   DevBuf X, U, dX, dU, dX2, dU2, xm, xd, um, ud, K, Hinv, kff, gc_part, Hc_part, scratch, red_tmp, Hg /* [Hc | gc] */, Lc, duc;
   DevBuf Hc_w, gc_w, cons_w, epi_lam, epi_out, epi_gath;
+  DevBuf Hc_grp;
   DevBuf es_Dx, es_wx, es_Du, es_wu, es_xm, es_xd, es_um, es_ud, es_kff2, es_kff3, es_gc2, es_dots, es_coef, es_out2, es_Xt, es_Ut, es_U, es_zero;  // smoothed cone objective (lcone_smooth_body)
   long long es_key = -1;  // consensus weights of the cone objective and the scaled copies the reductions read
   DevBuf xch, zeros, zslew, zslew0, zum1, part_sum, part_cnt, part_max, sc, fail;
@@ -190,7 +191,7 @@ struct ProfCat {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_COUNT
 };
 static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COUNT] = {
     {"as_warm", "PMPC_AS_WARM", 1},                // warm start of the active-set rounds from the previous solve's set
@@ -209,6 +210,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"warn_slow_path", "PMPC_WARN_SLOW_PATH", 1},  // one line on stderr when a context first leaves the register-resident path
     {"cone_rank_memory", "PMPC_CONE_RANK_MEMORY", 1},  // cone objective: the weight assignment the previous solve of the shape settled on is tried first
     {"cone_epigraph", "PMPC_CONE_EPIGRAPH", 1},    // cone objective with hard boxes: epigraph problem in the shared-control space (any tie pattern); 0: weighted-QP fixed point
+    {"cond_grouped", "PMPC_COND_GROUPED", 1},      // Nc > 1: condensed Hessians summed over groups of particles inside the condensing kernel
 };
 
 struct pmpc_ctx {
@@ -365,6 +367,14 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
   if (nc > 0) {
     ProfScope ps(c, 3);
     double *Hc = w.Hg.d(), *gc = w.Hg.d() + (size_t)nc * nc;
+    // condensed Hessians summed over groups of particles inside the condensing kernel: when nothing downstream looks at ONE particle's
+    // H_i again (settled particles of the rounds refresh g_i += H_i delta; consensus weights scale H_i; the cone path's host reads them)
+    const bool grouped = fast && factor && a.Nc > 1 && nc * nc + nc > 32 && !a.as_act && !a.as_settled_in && !a.cons_w && c->opt[OPT_COND_GROUPED] != 0.0;
+    a.Hc_grp = nullptr;
+    if (grouped) {
+      w.Hc_grp.ensure((size_t)cond_fast_groups(a.M) * nc * nc * sizeof(double));
+      a.Hc_grp = w.Hc_grp.d();
+    }
     if (fast && factor) launch_cond_fast(a, s);
     // sharded active-set rounds: the previous round's change counters travel behind [Hc | gc] (one collective per round
     // instead of two); the decision about that round is taken right behind the all-reduce, before this round's forward sweep
@@ -409,7 +419,8 @@ void structured_solve(pmpc_ctx *c, LQArgs &a, bool factor, bool fast, bool prep_
         }
       }
     } else {
-      if (factor) launch_reduce_particles_hg(HcP, gcP, w.red_tmp.d(), Hc, a.M, nc, s);  // (gc sits right behind Hc)
+      if (factor && grouped) launch_reduce_particles_hg(a.Hc_grp, gcP, w.red_tmp.d(), Hc, a.M, nc, s, cond_fast_groups(a.M));
+      else if (factor) launch_reduce_particles_hg(HcP, gcP, w.red_tmp.d(), Hc, a.M, nc, s);  // (gc sits right behind Hc)
       else launch_reduce_particles(gcP, w.red_tmp.d(), gc, a.M, nc, s);
       merged_exchange();
       launch_cons_solve(Hc, w.Lc.d(), gc, w.duc.d(), nc, factor, (int *)w.fail.p, s);
