@@ -438,16 +438,25 @@ def main():
             rounds_ps = max(1.0, float(np.mean(as_rounds))) if np.mean(as_rounds) > 0 else 1.0
             solves_ps = max(rounds_ps, float(np.mean(solves)))
             cond_flops = (x * x + x * u) * u * Nc * Nc * M_loc  # off-diagonal blocks: Y_j Gamma_{j-1,l} walked forward, 2 (x^2 + x u) flops per column and stage pair
-            hbytes = 2.0 * M_loc * ncv * ncv * 8  # written once by k_cond_fast / the factor sweep, read once by the reduction
+            # bytes of the class as built (r04): the condensing kernel walks the consensus stages once per group of 4 column tiles (64 consensus
+            # variables), reading fx, fu and the 64-double factor record of every stage from the tile group's first stage on; it writes ONE slab
+            # of upper-triangle sums per 8 particles (k_cond_fast_grouped), which the reduction reads once.  (r03: every particle's (Nc u)^2
+            # block went out and came back — 2.6 GB at config D with Nc = N; the same workload now moves 0.8 GB.)
+            ntile = (ncv + 15) // 16
+            stage_bytes = (x * x + x * u + 64) * 8
+            walk = sum(max(0, Nc - (16 * t0) // u) for t0 in range(0, ntile, 4))
+            hbytes = float(M_loc * walk * stage_bytes + 2 * ((M_loc + 7) // 8) * (ncv * (ncv + 1) // 2) * 8)
             t_one = ms_cons * 1e-3 / solves_ps
-            cons_roof = {"bound": "hbm", "kernel": "consensus launch class: k_cond_fast (off-diagonal blocks of the per-particle condensed Hessians) + particle reduction + dense Cholesky",
+            cons_roof = {"bound": "hbm", "kernel": "consensus launch class: k_cond_fast_grouped (off-diagonal blocks of the condensed Hessians, summed over groups of 8 particles "
+                                                   "before they leave the chip) + reduction of the group slabs + dense Cholesky (one workgroup)",
                          "avg_ms_per_solve": 1e3 * t_one, "solves_per_step": solves_ps, "bytes_per_solve": hbytes, "achieved": hbytes / t_one / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbytes / t_one / 1e9 / HBM_PEAK_GBS,
                          "flops": {"flop_per_solve": cond_flops, "achieved": cond_flops / t_one / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": cond_flops / t_one / 1e12 / FP64_PEAK_TFLOPS},
                          "note": "SURVEY.md section 8(d) prices full-consensus condensing as a dense (N x) x (N u) contraction per particle against the fp64 MFMA "
-                                 "peak; the structured form walks the stages (O(Nc^2) small tile products, ~8 GFLOP at config D) and what it costs is the "
-                                 "round trip of M (Nc u)^2 doubles through HBM"}
+                                 "peak; the structured form walks the stages (O(Nc^2) small tile products, ~8 GFLOP at config D).  Neither roof binds: the "
+                                 "condensing kernel is a dependent chain of 3 fp64 MFMAs per tile and stage behind a per-stage barrier (0.31 ms), the "
+                                 "(Nc u)^2 Cholesky runs on ONE workgroup (0.35 ms in situ — a latency chain of 13 panel steps)"}
         rates = [args.steps / t_ for t_ in rep_s]
         w0, w1 = args.warmup + 1, args.warmup + args.steps
         out = {

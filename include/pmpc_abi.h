@@ -216,6 +216,8 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *   cone_rank_memory PMPC_CONE_RANK_MEMORY 1   cone objective: the weight assignment the previous solve of the shape settled on is tried first
  *   cone_epigraph    PMPC_CONE_EPIGRAPH    1   cone objective: hard boxes through the epigraph problem in the shared-control space, smoothing through the
  *                                             full-space Newton iteration (any tie pattern); 0: the rank-based weighted-QP iteration everywhere
+ *   cond_grouped     PMPC_COND_GROUPED     1   Nc > 1: the condensed consensus Hessians are summed over groups of 8 particles inside the condensing
+ *                                             kernel (no per-particle block travels through HBM) whenever nothing downstream needs one particle's block
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);
