@@ -41,3 +41,9 @@ def test_fuzz_binding_state_boxes(mode):
     out = _run("fuzz_xbox.py", 60, 14, *(["cone"] if mode == "cone" else []))
     m = re.search(r"worst ([0-9.e+-]+)", out[-1])
     assert m and float(m.group(1)) <= 1e-6, out[-1]
+
+
+def test_fuzz_state_rows_of_extra_cstrs():
+    last = _run("fuzz_state_rows.py", 15, 80)[-1]
+    m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(3)) == 0 and int(m.group(2)) < 40 and float(m.group(4)) <= 1e-6, last
