@@ -665,7 +665,10 @@ __global__ void __launch_bounds__(64) k_cond_fast(LQArgs a) {
 // reduction — the two largest kernels of that workload —; the group sums are 1/COND_GRP of that.  The diagonal blocks (written into
 // Hc_part by the factor sweep) are folded in on the way, so the slab is the complete upper triangle.  For solves that never look at
 // one particle's H_i again (no settled-particle refresh, no consensus weights, no epigraph problem on the host).
-constexpr int COND_GRP = 8;
+#ifndef PMPC_COND_GRP
+#define PMPC_COND_GRP 8
+#endif
+constexpr int COND_GRP = PMPC_COND_GRP;
 template <int XD, int UD>
 __global__ void __launch_bounds__(64 * COND_GRP) k_cond_fast_grouped(LQArgs a) {
   typedef Lane<XD, UD> LT;
