@@ -1439,6 +1439,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     }
     int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
     if (verbose > 1 && xbox) depth = 1;  // (the debugging dump below wants every round)
+    static const bool duc_trace = getenv("PMPC_DUC_TRACE") != nullptr;
+    if (duc_trace) depth = 1;
     int n_batches_at_hook = -1000;  // batches waited for since the speculation hook fired (in THIS attempt)
     AsCtl h;
     memset(&h, 0, sizeof(h));
@@ -1520,6 +1522,15 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           printf("pmpc_hip: active set (%s) round %d: %d released, %d activated (largest violation behind a change %.2e)\n",
                  mode == 5 ? "finish" : (mode == 4 ? "state rows" : (mode >= 2 ? "cold" : (mode ? "finish" : "warm"))), r + 1, h.hist[r][0], h.hist[r][1], h.worst[r]);
       if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
+      if (duc_trace && nc > 0 && !a.cons_G) {
+        std::vector<double> hd(nc);
+        HIP_CHECK(hipMemcpy(hd.data(), w.duc.p, nc * D8, hipMemcpyDeviceToHost));
+        double m = 0.0;
+        for (double v : hd) m = std::max(m, std::fabs(v));
+        int nset = 0;
+        { std::vector<int> hs(M); HIP_CHECK(hipMemcpy(hs.data(), w.as_settled.p, M * sizeof(int), hipMemcpyDeviceToHost)); for (int v : hs) nset += v; }
+        printf("pmpc_hip: trace: round %d max |du_c| %.3e, %d of %d particles settled\n", h.round, m, nset, M);
+      }
       if (verbose > 1 && xbox) {  // debugging aid: the state rows after this batch — held rows, largest multiplier, largest |x|, per worst particle
         HIP_CHECK(hipStreamSynchronize(s));
         std::vector<double> hz(nx), hX(nx), hU(nu);
