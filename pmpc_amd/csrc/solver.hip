@@ -2494,7 +2494,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       // backtracking: strictly inside the boxes, no increase of F beyond its round-off (t re-optimised at every trial point); a step
       // that is already tiny is taken in full as soon as it is feasible — F cannot resolve it
       const double f_noise = 1e-13 * std::max(1.0, std::fabs(Fcur)) * std::sqrt((double)M);
-      double al = 1.0, Ft = 0.0, tt = t, bt = 0.0;
+      double al = 1.0, Ft = 0.0, tt = t, bt = 0.0, al_feas = 0.0;  // al_feas: the first trial step strictly inside the boxes
       bool accepted = false;
       for (int ls = 0; ls < 30; ls++) {
         if (ls > 0) {
@@ -2503,6 +2503,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         }
         bar_at(w.es_Xt.d(), w.es_Ut.d());
         if (out2[1] > 0.0 && out2[0] == out2[0]) {
+          if (al_feas == 0.0) al_feas = al;
           for (int i = 0; i < M; i++) Jt[i] = J[i] + al * (dots[3 * i] + 0.5 * al * dots[3 * i + 2]);
           bt = out2[0];
           tt = solve_t(Jt);
@@ -2528,7 +2529,9 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       // a hinge too narrow for this start shows at once: step after step cut to a few per cent (every Newton step crosses kinks).  Four of
       // those in a row end the attempt — the remaining twenty would be spent the same way (measured at config D: 50 such steps before the
       // width was right) — and the hinge widens from where the iterate is now
-      n_cut = al < 0.1 ? n_cut + 1 : 0;
+      // (a step cut by the BOXES — the first feasible trial accepted, or nearly — is the barrier doing its work from a start near a
+      //  bound, and recovers; only cuts the decrease test demanded beyond feasibility count)
+      n_cut = (al < 0.1 && al <= 0.25 * al_feas) ? n_cut + 1 : 0;
       if (n_cut >= 4 && rho < rho_max) break;
     }
     if (!inner_ok) {  // the inner problem was not solved: the multipliers stay, the hinge widens (a smoother inner problem from the same point)

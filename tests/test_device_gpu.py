@@ -471,3 +471,11 @@ def test_every_documented_option_exists_with_its_documented_default():
         s.set_option(k, dflt + 1.0)
         assert s.get_option(k) == dflt + 1.0
     s.close()
+
+
+def test_graft_entry_smoke_passes():
+    """The driver's smoke entry (one small invocation of every part of the hot path against the oracle) as a test: a change that breaks
+    it must not get past `pytest -m gpu` (r04: a line-search heuristic of the smoothed cone path did, on exactly its case)."""
+    import __graft_entry__ as entry
+
+    entry.smoke()
