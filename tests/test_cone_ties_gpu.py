@@ -216,3 +216,33 @@ def test_logbarrier_smoothing_with_several_consensus_stages(co, copies, others, 
     X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=alpha, solver="ecos")
     assert np.all(np.isfinite(X)) and np.all(np.isfinite(U))
     assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+
+
+@pytest.mark.parametrize("case", [37, 41, 74])
+def test_worst_k_with_several_costs_on_the_threshold(case):
+    """k < M puts several particle costs on the threshold (here 2, 4 and 3 of 8 / 8 / 7 random particles) with boxes that do not bind:
+    no active-set state for the epigraph path to start from, more ties than the ranking iteration knows — the free-particles path
+    (`lcone_free_particles_body`: every cost an exact quadratic of the shared controls, one host epigraph solve) answers.  Fixture:
+    tests/golden/cone_worst_k.npz = problems found by tools/fuzz/fuzz_cone.py + the restated reference program's optimum
+    (tools/make_cone_worstk_golden.py).  The particles BELOW the threshold carry no multiplier (not unique upstream): compared are
+    the shared controls, the particles on or above the threshold and the objective."""
+    from pathlib import Path
+
+    from oracle import lqp_oracle as orc
+    from pmpc_amd import backend
+
+    g = np.load(Path(__file__).parent / "golden" / "cone_worst_k.npz")
+    names = ["x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref"]
+    args = tuple(g[f"c{case}_{n}"] for n in names)
+    kw = {k_[len(f"c{case}_kw_"):]: (float(g[k_]) if g[k_].ndim == 0 else g[k_]) for k_ in g.files if k_.startswith(f"c{case}_kw_")}
+    Nc, k = (int(v) for v in g[f"c{case}_meta"])
+    Xo, Uo = g[f"c{case}_X"], g[f"c{case}_U"]
+    X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=float("nan"), solver="ecos", k=k)
+    assert np.all(np.isfinite(U)), "solver failed"
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    Jg, Jo = (orc.particle_costs_py(X_, U_, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x=kw["reg_x"], reg_u=kw["reg_u"]) for X_, U_ in ((X, U), (Xo, Uo)))
+    obj = lambda Jv: min((1 + 1e-3) * np.sum(np.maximum(Jv - t_, 0.0)) + (1 - 1e-3) * k * t_ for t_ in Jv)
+    top = Jo >= np.sort(Jo)[::-1][k - 1] - 1e-9 * np.abs(Jo).max()
+    Ncc = U.shape[1] if Nc < 0 else Nc
+    assert abs(obj(Jg) - obj(Jo)) <= 1e-9 * abs(obj(Jo))
+    assert _rel(U[:, :Ncc], Uo[:, :Ncc]) <= TOL and _rel(X[top], Xo[top]) <= TOL and _rel(U[top], Uo[top]) <= TOL
