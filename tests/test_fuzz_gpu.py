@@ -53,3 +53,9 @@ def test_fuzz_cone_objective_hard_and_smoothed():
     last = _run("fuzz_cone.py", 22, 100)[-1]
     m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
     assert m and int(m.group(3)) == 0 and int(m.group(2)) < 20 and float(m.group(4)) <= 1e-6, last
+
+
+def test_fuzz_sharded_equals_one_rank():
+    last = _run("fuzz_sharded.py", 31, 300)[-1]
+    m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(3)) == 0 and int(m.group(2)) < 60 and float(m.group(4)) <= 1e-8, last
