@@ -59,3 +59,9 @@ def test_fuzz_sharded_equals_one_rank():
     last = _run("fuzz_sharded.py", 31, 300)[-1]
     m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
     assert m and int(m.group(3)) == 0 and int(m.group(2)) < 60 and float(m.group(4)) <= 1e-8, last
+
+
+def test_fuzz_sequence_of_unrelated_problems_on_one_context():
+    last = _run("fuzz_sequence.py", 41, 150)[-1]
+    m = re.search(r"(\d+) calls \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(3)) == 0 and int(m.group(2)) < 30 and float(m.group(4)) <= 1e-6, last
