@@ -2347,6 +2347,20 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     return finish(1);
   }
   w.es_key = -1;
+  if (lam_mem) {
+    // remembered logits may belong to ANOTHER problem of this shape.  A multiplier saturated at the wrong end of [0, cap] takes
+    // |l| rho / |J - t| updates to come back: where the costs at the start rank a particle clearly on the other side of the threshold
+    // than its remembered multiplier says, the logit is pulled back to +-12 (inside an SCP loop the sides agree and nothing changes)
+    std::vector<int> idx(M);
+    for (int i = 0; i < M; i++) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a_, int b_) { return J[a_] > J[b_]; });
+    const int n_top = (int)(K / cap);  // about this many rows carry the full multiplier
+    for (int r = 0; r < M; r++) {
+      const int i = idx[r];
+      if (lam[i] > 12.0 && r >= n_top + 2) lam[i] = 12.0;
+      if (lam[i] < -12.0 && r < n_top - 1) lam[i] = -12.0;
+    }
+  }
   {
     double jlo = 1e300, jhi = -1e300;
     for (int i = 0; i < M; i++) { jlo = std::min(jlo, J[i]); jhi = std::max(jhi, J[i]); }
@@ -2587,7 +2601,16 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     }
     if (verbose) printf("pmpc_hip: smoothed cone objective: outer %d done (%d Newton steps so far), multiplier change %.3e%s\n", outer + 1, newton, dl, inner_ok ? "" : " (inner limit)");
     (void)last_stage;
-    if (inner_ok && step_tol <= 1e-9 * 1.0000001 && dl <= 1e-7 * cap) converged = true;
+    // converged: the multipliers stand still AND they are the multipliers of these costs — complementarity of every epigraph row at the
+    // threshold t (a multiplier saturated at the wrong end of [0, cap] also "stands still": its logit moves, its value does not; found
+    // by tools/fuzz/fuzz_sequence.py with multipliers remembered from another problem of the same shape)
+    double comp = 0.0;
+    for (int i = 0; i < M; i++) {
+      const double m_i = cap * sigm(lam[i]), v = J[i] - t;
+      comp = std::max(comp, v > 0.0 ? v * (cap - m_i) : -v * m_i);
+    }
+    const bool kkt_ok = comp <= 1e-8 * cap * std::max(1.0, std::fabs(t));
+    if (inner_ok && step_tol <= 1e-9 * 1.0000001 && dl <= 1e-7 * cap && kkt_ok) converged = true;
     dl_prev = dl;
     // (a sharper hinge makes the multiplier updates contract faster — wanted while they are far off or contracting slowly; never below a
     //  width whose inner problem this solve has already failed to solve)

@@ -13,6 +13,7 @@ from pmpc_amd import backend
 from tests.support.problems import abi_args, rand_problem
 
 seed, calls = int(sys.argv[1]), int(sys.argv[2])
+verbose_at = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # (debugging: this call runs verbose)
 
 
 class OracleTimeout(Exception):
@@ -49,7 +50,7 @@ for call in range(calls):
     if kind == "qp":
         X, U = backend.lqp_solve(*abi_args(args, kw, Nc))
     else:
-        X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=alpha, solver="ecos")
+        X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=alpha, solver="ecos", verbose=call == verbose_at)
     tag = f"call {call}: {kind} M{M} N{N} x{x} u{u} Nc{Nc} bu{bu} bx{bx} alpha {alpha}"
     if np.isnan(U).any():
         fails += 1
