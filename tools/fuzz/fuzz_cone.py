@@ -5,7 +5,7 @@ have no ties) for hard boxes and the log barrier; the line-cited restatement of 
 squareplus and for the worst-k objective (k < M puts many costs on the threshold; the ranking oracle knows two-way ties only) at small M.
 With k < M the particles below the threshold carry no multiplier and the reference's minimiser is not unique in their free variables: there
 the comparison is the shared controls, the particles on or above the threshold and the value of the objective.
-usage: fuzz_cone.py SEED CASES"""
+usage: fuzz_cone.py SEED CASES [MAX_M = 24]"""
 import signal
 import sys
 
@@ -18,6 +18,7 @@ from pmpc_amd import backend
 from tests.support.problems import abi_args, rand_problem
 
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
+max_M = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 
 
 class OracleTimeout(Exception):
@@ -32,7 +33,7 @@ signal.signal(signal.SIGALRM, _alarm)
 rng = np.random.default_rng(seed)
 worst, fails, skipped, by_kind = 0.0, 0, 0, {}
 for case in range(cases):
-    M, N = int(rng.integers(2, 25)), int(rng.integers(3, 9))
+    M, N = int(rng.integers(2, max_M + 1)), int(rng.integers(3, 9))
     x, u = [(4, 2), (3, 2), (6, 3), (5, 2), (4, 3), (6, 2)][int(rng.integers(0, 6))]
     Nc = int(rng.choice([0, 1, 1, 2, -1]))
     bu = float(rng.choice([0.4, 1.0, 2.5]))
