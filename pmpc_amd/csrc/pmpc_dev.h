@@ -82,6 +82,7 @@ struct LQArgs {
   // consensus condensing
   double *gc_part;  // [M][nc]
   double *Hc_part;  // [M][nc*nc]
+  int cost_lds;     // k_particle_cost: doubles of dynamic LDS the launch was given (0: none)
   double *Hc_grp;   // [groups][nc*nc] or null: the condensing kernel sums the particles of a workgroup before storing (k_cond_fast_grouped)
   double *scratch;  // [M][3*n*nc]
   const double *duc;  // [nc] consensus step
