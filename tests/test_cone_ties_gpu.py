@@ -223,7 +223,7 @@ def test_worst_k_with_several_costs_on_the_threshold(case):
     """k < M puts several particle costs on the threshold (here 2, 4 and 3 of 8 / 8 / 7 random particles) with boxes that do not bind:
     no active-set state for the epigraph path to start from, more ties than the ranking iteration knows — the free-particles path
     (`lcone_free_particles_body`: every cost an exact quadratic of the shared controls, one host epigraph solve) answers.  Fixture:
-    tests/golden/cone_worst_k.npz = problems found by tools/fuzz/fuzz_cone.py + the restated reference program's optimum
+    tests/golden/worstk_ties.npz = problems found by tools/fuzz/fuzz_cone.py + the restated reference program's optimum
     (tools/make_cone_worstk_golden.py).  The particles BELOW the threshold carry no multiplier (not unique upstream): compared are
     the shared controls, the particles on or above the threshold and the objective."""
     from pathlib import Path
@@ -231,7 +231,7 @@ def test_worst_k_with_several_costs_on_the_threshold(case):
     from oracle import lqp_oracle as orc
     from pmpc_amd import backend
 
-    g = np.load(Path(__file__).parent / "golden" / "cone_worst_k.npz")
+    g = np.load(Path(__file__).parent / "golden" / "worstk_ties.npz")
     names = ["x0", "f", "fx", "fu", "X_prev", "U_prev", "Q", "R", "X_ref", "U_ref"]
     args = tuple(g[f"c{case}_{n}"] for n in names)
     kw = {k_[len(f"c{case}_kw_"):]: (float(g[k_]) if g[k_].ndim == 0 else g[k_]) for k_ in g.files if k_.startswith(f"c{case}_kw_")}

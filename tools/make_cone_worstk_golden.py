@@ -1,7 +1,7 @@
 """Golden cases for the worst-k cone objective with several costs on the threshold: the three problems of tools/fuzz/fuzz_cone.py
 (seed 22, cases 37, 41, 74 — random problems, loose boxes, k < M) on which the ranking iteration failed or, before its acceptance
 test was tightened, returned a non-optimal point.  Expected outputs: the line-cited restatement of the reference's cone program
-(oracle/cone_oracle.py lcone_direct_py), computed here on the CPU.  Writes tests/golden/cone_worst_k.npz.
+(oracle/cone_oracle.py lcone_direct_py), computed here on the CPU.  Writes tests/golden/worstk_ties.npz.
 usage: python tools/make_cone_worstk_golden.py   (regenerates the problems by replaying the fuzzer's random stream)"""
 import sys
 
@@ -42,4 +42,4 @@ for case in range(80):  # the parameter draws of tools/fuzz/fuzz_cone.py, in its
     out[f"c{case}_meta"] = np.array([Nc, k])
     out[f"c{case}_X"], out[f"c{case}_U"] = Xo, Uo
     print("case", case, "M", M, "N", N, "x", x, "u", u, "Nc", Nc, "k", k, flush=True)
-np.savez_compressed("tests/golden/cone_worst_k.npz", **out)
+np.savez_compressed("tests/golden/worstk_ties.npz", **out)
