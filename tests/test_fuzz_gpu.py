@@ -71,3 +71,9 @@ def test_fuzz_state_rows_inside_the_cone_objective():
     last = _run("fuzz_state_rows_cone.py", 81, 40)[-1]
     m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
     assert m and int(m.group(3)) == 0 and int(m.group(2)) < 15 and float(m.group(4)) <= 1e-6, last
+
+
+def test_fuzz_library_scp_loop_against_python_driven_loop():
+    last = _run("fuzz_scp_loop.py", 102, 150)[-1]
+    m = re.search(r"(\d+) cases, (\d+) failures, worst difference ([0-9.e+-]+)", last)
+    assert m and int(m.group(2)) == 0, last
