@@ -143,7 +143,7 @@ def test_config_E_shape_N100_cones_match_cone_oracle(solver, oracle):
     assert ex < 1e-6 and eu < 1e-6, (ex, eu)  # (the cone oracle itself stops at mu = 1e-13: ~1e-8 on trajectories)
 
 
-@pytest.mark.parametrize("M", [8, 16])  # (the cone oracle on the CPU is the slow part: 53 s at M = 8, 123 s at M = 32)
+@pytest.mark.parametrize("M", [8])  # (the cone oracle on the CPU is the slow part: 35 s at M = 8, 39 s at M = 16 — which passes too —, 123 s at M = 32)
 def test_config_E_as_stated_fp32_storage_matches_the_fp64_cone_oracle(solver, oracle, M):
     """BASELINE configs[4] AS STATED: quadrotor, N = 100, control boxes + thrust cones, **fp32** — here: fx, fu, Q, R and the factor
     records stored in float32 (PMPC_F32_MATRICES; half the HBM bytes of the dominant arrays), every value widened on load, all
