@@ -50,7 +50,7 @@ def test_fuzz_state_rows_of_extra_cstrs():
 
 
 def test_fuzz_cone_objective_hard_and_smoothed():
-    last = _run("fuzz_cone.py", 22, 42)[-1]  # (cases 37 and 41 of this seed are the worst-k ties the ranking iteration got wrong)
+    last = _run("fuzz_cone.py", 24, 40, 24, 5)[-1]  # (worst-k cases at M <= 5: the direct cone program is the slow part; the ties it found are tests/golden/worstk_ties.npz)
     m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
     assert m and int(m.group(3)) == 0 and int(m.group(2)) < 20 and float(m.group(4)) <= 1e-6, last
 

@@ -5,7 +5,7 @@ have no ties) for hard boxes and the log barrier; the line-cited restatement of 
 squareplus and for the worst-k objective (k < M puts many costs on the threshold; the ranking oracle knows two-way ties only) at small M.
 With k < M the particles below the threshold carry no multiplier and the reference's minimiser is not unique in their free variables: there
 the comparison is the shared controls, the particles on or above the threshold and the value of the objective.
-usage: fuzz_cone.py SEED CASES [MAX_M = 24]"""
+usage: fuzz_cone.py SEED CASES [MAX_M = 24] [MAX_M_DIRECT = 8]"""
 import signal
 import sys
 
@@ -19,6 +19,7 @@ from tests.support.problems import abi_args, rand_problem
 
 seed, cases = int(sys.argv[1]), int(sys.argv[2])
 max_M = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+max_M_direct = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # particle count of the cases that need the (slow) direct cone program
 
 
 class OracleTimeout(Exception):
@@ -42,9 +43,9 @@ for case in range(cases):
     alpha = float("nan") if kind == "hard" else float(rng.choice([1.0, 10.0, 100.0]))
     k = None if rng.random() < 0.7 else int(rng.integers(1, M + 1))
     if kind == "squareplus":
-        Nc, M = (Nc if Nc in (0, 1) else 1), min(M, 6)
+        Nc, M = (Nc if Nc in (0, 1) else 1), min(M, 6, max_M_direct)
     if k is not None:
-        M = min(M, 8)
+        M = min(M, max_M_direct)
         k = min(k, M)
         k = None if k == M else k
     args, kw = rand_problem(rng, M, N, x, u, bu, bx)
@@ -52,7 +53,7 @@ for case in range(cases):
     if k is not None:
         okw["k"] = k
     try:
-        signal.alarm(60)
+        signal.alarm(20)
         if kind == "squareplus" or k is not None:
             Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, **(dict(smooth_alpha=alpha, smooth_cstr=kind) if kind != "hard" else {}), **okw)
         else:
