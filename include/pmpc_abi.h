@@ -218,6 +218,8 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *                                             full-space Newton iteration (any tie pattern); 0: the rank-based weighted-QP iteration everywhere
  *   cond_grouped     PMPC_COND_GROUPED     1   Nc > 1: the condensed consensus Hessians are summed over groups of 8 particles inside the condensing
  *                                             kernel (no per-particle block travels through HBM) whenever nothing downstream needs one particle's block
+ *   as_freeze_tol    PMPC_AS_FREEZE_TOL    1e-9  stage-cone rounds with one consensus stage: a step of the free shared controls below this (relative)
+ *                                             is taken as zero by every particle, and the settled particles leave the forward sweep at once (0: off)
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);

@@ -583,6 +583,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   // sums entry e of [H | g] in block order — the same operations in every wave, so every particle applies the same step —,
   // then a Cholesky solve on lane-uniform values (arithmetic of k_cons_small's single-thread solve)
   double dcons = 0.0;
+  bool frozen = false;
   if (a.cons_G) {
     constexpr int nH = UD * UD, E = nH + UD;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -631,8 +632,36 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       for (int k = p + 1; k < UD; k++) v -= Lm[k][p] * y[k];
       y[p] = v / Lm[p][p];
     }
+    if (CONE && a.as_freeze_tol > 0.0) {
+      // (a HELD shared control's entry is its multiplier over the 1e30 penalty: left alone.  Statuses and base value: this particle's own
+      //  copy of the consensus stage — identical in every particle, and not yet rewritten by this wave)
+      const int *act0 = a.as_act + pbase * UD;
+      const double *ub0 = Ub + pbase * UD;
+      double ym = 0.0;
+#pragma unroll
+      for (int p = 0; p < UD; p++)
+        if (act0[p] == 0) ym = fmax(ym, fabs(y[p]) / fmax(1.0, fabs(ub0[p])));
+      frozen = ym <= a.as_freeze_tol;
+      if (frozen) {
+#pragma unroll
+        for (int p = 0; p < UD; p++)
+          if (act0[p] == 0) y[p] = 0.0;
+      }
+    }
     dcons = gu ? pick<UD>(y, g) : 0.0;
     if (cbad && i == 0 && lane == 0) *a.fail = 2;
+  }
+  if (CONE && frozen && a.as_settled_in && a.as_settled_in[i]) {
+    // nothing of this particle changed in the last round (no factor sweep for it in this one) and the shared step is zero: its forward
+    // sweep would write back what is there.  The counters say "no change".
+    if (lane == 0) {
+      a.as_cnt[3 * i + 0] = 0; a.as_cnt[3 * i + 1] = 0; a.as_cnt[3 * i + 2] = 0;
+      if (a.as_settled_out) a.as_settled_out[i] = 1;
+      a.as_open[i] = 0;
+      if (a.as_viol) a.as_viol[i] = 0.0;
+    }
+    if (i == 0 && lane < UD) a.as_delta[lane] = 0.0;
+    return;
   }
   const double inv_dual = 1.0 / ((a.as_ctl ? a.as_ctl->dual_scale : 1.0) * pwi);
   auto stage = [&](auto main_tag, const int j, const Pipe &cur) {

@@ -103,6 +103,10 @@ struct LQArgs {
   const int *as_settled_in;
   int *as_settled_out;
   double as_big, as_tol_p, as_tol_l;
+  // stage-cone rounds with one consensus stage: once the step of every FREE shared control is below as_freeze_tol (relative), it is taken
+  // as zero by every particle — a convergence tolerance on the shared controls — and the settled particles leave the forward sweep at
+  // once (measured at config E: the last 2-3 rounds of 7 serve 4-25 particles while moving the shared control by 1e-9 .. 1e-14)
+  double as_freeze_tol;
   // active-set sweeps of kernels_as.hip: base point in (Xb, Ub) — ignored in the first round of a no-rollout warm start, whose
   // base is (X_prev, U_prev) —, new base point out (Xo, Uo: may alias Xb, Ub), the consensus step as applied (as_delta, nc
   // doubles, written by particle 0), the control block (tolerance of the round; null = as_tol_l) and the early-exit flag

@@ -191,7 +191,7 @@ struct ProfCat {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_COUNT
 };
 static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COUNT] = {
     {"as_warm", "PMPC_AS_WARM", 1},                // warm start of the active-set rounds from the previous solve's set
@@ -211,6 +211,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"cone_rank_memory", "PMPC_CONE_RANK_MEMORY", 1},  // cone objective: the weight assignment the previous solve of the shape settled on is tried first
     {"cone_epigraph", "PMPC_CONE_EPIGRAPH", 1},    // cone objective with hard boxes: epigraph problem in the shared-control space (any tie pattern); 0: weighted-QP fixed point
     {"cond_grouped", "PMPC_COND_GROUPED", 1},      // Nc > 1: condensed Hessians summed over groups of particles inside the condensing kernel
+    {"as_freeze_tol", "PMPC_AS_FREEZE_TOL", 1e-9}, // stage-cone rounds: a shared-control step below this (relative) is zero for every particle; settled ones skip the forward sweep
 };
 
 struct pmpc_ctx {
@@ -1332,6 +1333,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     w.as_key = -1;
     // stage cones (mode 0 warm / 3 cold): Newton terms per round from kernels_cone.hip, see the header there
     const bool cone = cone_as && (mode == 0 || mode == 3 || mode == 5);
+    b.as_freeze_tol = (cone && Nc == 1) ? c->opt[OPT_AS_FREEZE_TOL] : 0.0;
     ConeArgs ca;
     memset(&ca, 0, sizeof(ca));
     if (cone) {
