@@ -220,6 +220,8 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *                                             kernel (no per-particle block travels through HBM) whenever nothing downstream needs one particle's block
  *   as_freeze_tol    PMPC_AS_FREEZE_TOL    1e-9  stage-cone rounds with one consensus stage: a step of the free shared controls below this (relative)
  *                                             is taken as zero by every particle, and the settled particles leave the forward sweep at once (0: off)
+ *   as_ckpt          PMPC_AS_CKPT          1   the factor sweeps leave their cost-to-go at stages 8, 16, 32, ..; an unsettled particle's factor sweep of a
+ *                                             later round starts at the lowest of them at or above its highest changed stage (0: from the terminal cost)
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);
@@ -303,6 +305,11 @@ void pmpc_profile_read_partial(pmpc_ctx *ctx, double *ms, long long *n);
 /* every launch class as of the last pmpc_profile_read: 0 full factor sweep, 1 vector sweep, 2 forward sweep, 3 consensus
  * reduce + solve, 4 factor sweeps that skip settled particles, 5 active-set bookkeeping, 6 linearisation, 7 SCP residual */
 void pmpc_profile_read_all(pmpc_ctx *ctx, double *ms, long long *launches, int count);
+
+/* Checkpointed restart of the later rounds' factor sweeps (option as_ckpt), counted since the last reset: out4 = {sweeps that
+ * started from a checkpoint, stages they ran, sweeps of unsettled particles that started from the terminal cost, stages they ran}.
+ * Synchronises the solver's stream.  For tests and bench.py (how much of the horizon the later rounds re-factorise). */
+void pmpc_restart_stats(pmpc_ctx *ctx, unsigned long long *out4, int reset);
 
 /* version / build probe used by the loader and the tests */
 const char *pmpc_version(void);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "pmpc_comm_unique_id", "pmpc_comm_init", "pmpc_comm_rank", "pmpc_comm_world", "pmpc_linearize_device",
     "pmpc_profile_enable", "pmpc_profile_read", "pmpc_version", "pmpc_lcone_solve_device", "pmpc_particle_costs_device", "pmpc_lsoc_solve_device", "pmpc_comm_init_mock",
     "pmpc_scp_residual_device", "pmpc_profile_read_partial", "pmpc_profile_read_all", "pmpc_scp_loop_device", "pmpc_linearize_device_f32",
-    "pmpc_set_option", "pmpc_get_option", "pmpc_abi_struct_sizes", "pmpc_lcone_solve_host_ex",
+    "pmpc_set_option", "pmpc_get_option", "pmpc_abi_struct_sizes", "pmpc_lcone_solve_host_ex", "pmpc_restart_stats",
 ]
 
 
@@ -111,6 +111,8 @@ def load():
     lib.pmpc_profile_read.restype = None
     lib.pmpc_profile_read_partial.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]
     lib.pmpc_profile_read_partial.restype = None
+    lib.pmpc_restart_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    lib.pmpc_restart_stats.restype = None
     lib.pmpc_profile_read_all.argtypes = [vp, c_dp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
     lib.pmpc_profile_read_all.restype = None
     lib.pmpc_scp_loop_device.argtypes = [vp, ctypes.c_int, vp, ctypes.POINTER(PmpcProblem), vp, vp, vp, ctypes.c_int, ctypes.c_int, vp,

@@ -113,11 +113,28 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   const double regx = pwt * a.reg_x, regu = pwt * a.reg_u;
   // base point of the round
   const double *Xb = DEFECT ? a.X_prev : a.Xb, *Ub = DEFECT ? a.U_prev : a.Ub;
+  // Checkpointed restart (SKIP sweeps): nothing above the highest stage whose status (or Newton term) changed is different from
+  // the last sweep of this particle — the sweep starts at the lowest checkpoint at or above it, jtop = PMPC_AS_CK_FIRST << k, from the
+  // recorded cost-to-go; jtop = N - 1: the whole horizon from the terminal cost.  Checkpoints sit on free stages only.
+  constexpr int CKS = 64 * KS + 32;  // doubles per checkpoint: the S tile as the lanes hold it, s and the base state by state index
+  int jtop = N - 1, ck_k = 0;  // ck_k: slot + 1 of the checkpoint the sweep starts from (0: from the terminal cost)
+  if (SKIP && a.as_ck) {
+    const int jh = a.as_jhi[i];
+    const int lo = jh > Nc ? jh : (Nc > 1 ? Nc : 1);
+    const int k = lo <= PMPC_AS_CK_FIRST ? 0 : 32 - __builtin_clz((unsigned)(lo - 1) >> PMPC_AS_CK_LOG);  // lowest k with FIRST << k >= lo
+    if (k < a.ck_slots) { ck_k = __builtin_amdgcn_readfirstlane(k + 1); jtop = PMPC_AS_CK_FIRST << (ck_k - 1); }
+    if (lane == 0 && a.ck_stat) {
+      atomicAdd(a.ck_stat + (ck_k ? 0 : 2), 1ull);
+      atomicAdd(a.ck_stat + (ck_k ? 1 : 3), (unsigned long long)(jtop + 1));
+    }
+  }
+  // (null when off: the stages test this pointer alone — the sweeps run at the limit of the scalar register file)
+  const double *ck_ = a.as_ck ? ubase(a.as_ck, (long long)i * a.ck_slots * (long long)(CKS * sizeof(double))) : nullptr;
 
-  // F = [fx | fu]: per-lane pointer at stage N-1 and per-lane byte stride (0 for lanes that read the zero buffer)
+  // F = [fx | fu]: per-lane pointer at stage jtop and per-lane byte stride (0 for lanes that read the zero buffer)
   const bool fF = L.cxv || L.cu;
-  const MT *pF = L.cxv ? (const MT *)a.fx + (pbase + N - 1) * (XD * XD) + XD * L.oc + L.row0
-                       : (L.cu ? (const MT *)a.fu + (pbase + N - 1) * (XD * UD) + XD * L.cb + L.row0 : (const MT *)Z);
+  const MT *pF = L.cxv ? (const MT *)a.fx + (pbase + jtop) * (XD * XD) + XD * L.oc + L.row0
+                       : (L.cu ? (const MT *)a.fu + (pbase + jtop) * (XD * UD) + XD * L.cb + L.row0 : (const MT *)Z);
   const int sF = fF ? -(int)MB * (L.cxv ? XD * XD : XD * UD) : 0;
   // everything else: UNIFORM stage base (scalar registers, advanced by the scalar unit) + a per-lane constant byte offset.
   // Lanes without an entry read entry 0 of the stage block (finite data) and are masked by a zero factor or a select.
@@ -170,12 +187,12 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   // and lane 15 - XP - b of k-groups 0 / 1 reads u base[b] / u_prev[b] (a row mirror takes them to the control column XP + b).
   const char *pC = (const char *)Z;
   int sC = 0;
-  if (gu && c == XP) { pC = (const char *)(Ub + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
-  else if (gu && c == XP + 1) { pC = (const char *)(a.U_ref + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
-  else if (gu && c == XP + 2) { pC = (const char *)(a.as_act + (pbase + N - 1) * UD + g); sC = -UD * (int)sizeof(int); }  // (read as 8 bytes: spare bytes behind the buffer)
-  else if (CONE && gu && c == XP + 3) { pC = (const char *)(a.cone_g + (pbase + N - 1) * UD + g); sC = -UD * (int)D8; }
+  if (gu && c == XP) { pC = (const char *)(Ub + (pbase + jtop) * UD + g); sC = -UD * (int)D8; }
+  else if (gu && c == XP + 1) { pC = (const char *)(a.U_ref + (pbase + jtop) * UD + g); sC = -UD * (int)D8; }
+  else if (gu && c == XP + 2) { pC = (const char *)(a.as_act + (pbase + jtop) * UD + g); sC = -UD * (int)sizeof(int); }  // (read as 8 bytes: spare bytes behind the buffer)
+  else if (CONE && gu && c == XP + 3) { pC = (const char *)(a.cone_g + (pbase + jtop) * UD + g); sC = -UD * (int)D8; }
   else if (!DEFECT && g < 2 && 15 - XP - c >= 0 && 15 - XP - c < UD) {
-    pC = (const char *)((g == 0 ? Ub : a.U_prev) + (pbase + N - 1) * UD + (15 - XP - c));
+    pC = (const char *)((g == 0 ? Ub : a.U_prev) + (pbase + jtop) * UD + (15 - XP - c));
     sC = -UD * (int)D8;
   }
   const double regu_s = (L.cu && g < 2) ? (g == 0 ? regu : -regu) : 0.0;  // reg_u (u - u_prev): the two terms summed over the k-groups
@@ -201,7 +218,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   struct PipeNone {};
   struct Pipe : std::conditional_t<CONE, PipeCone, std::conditional_t<XBOX, PipeXbox, PipeNone>> { double F[KS], R, ctl, f, Q[KS], xb, xr, xp; };
   const double *XD_ = XBOX ? ubase(a.xb_D, px) : Z, *XG_ = XBOX ? ubase(a.xb_g, px) : Z;
-  int jF = N - 1;  // stage pF / pC point at
+  int jF = jtop;  // stage pF / pC point at
   auto fetch_early = [&](int jj, Pipe &q) {  // called in descending stage order (a clamped repeat of stage 0 leaves the pointers alone)
     if (jj < jF) { pF = (const MT *)((const char *)pF + sF); pC += sC; jF = jj; }
 #pragma unroll
@@ -227,6 +244,21 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   double S[KS], s_row[KS], s_col;
   bool bad = false;  // a pivot of some Huu was not positive
   TL_DECL(SKIP ? 1 : 0);
+  if (SKIP && ck_k > 0) {
+    // ---- restart: (S, s) of the checkpoint at the top of stage jtop, s moved to today's base state: s + S (x_now - x_then) ----
+    const double *ck = ubase(ck_, (long long)(ck_k - 1) * (long long)(CKS * D8));
+#pragma unroll
+    for (int r = 0; r < KS; r++) S[r] = ldo(ck, (unsigned)((lane + 64 * r) * D8));
+    const double s_ck = ldo(ck, (unsigned)(64 * KS * D8) + lxc), x_ck = ldo(ck, (unsigned)((64 * KS + 16) * D8) + lxc);  // (by ORIGINAL state index)
+    const double dx_col = L.cxv ? ldo(ubase(Xb_, xoff(jtop)), lxc) - x_ck : 0.0;
+    double dx_row[KS], part = 0.0;
+    col_to_row<KS>(dx_col, g, dx_row);
+#pragma unroll
+    for (int r = 0; r < KS; r++) part = fma(S[r], dx_row[r], part);
+    part = grp_allsum(part);
+    s_col = L.cxv ? s_ck + part : 0.0;
+    col_to_row<KS>(s_col, g, s_row);
+  } else
   // ---- terminal: S = Q~_{N-1}, s = g_x,N-1 ---------------------------------------------------------------------
   {
     double Q0[KS], xm0[KS], part = 0.0;
@@ -254,6 +286,19 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   auto stage = [&](auto main_tag, const int j, const Pipe &cur, Pipe &nxt) {
     constexpr bool MAIN = decltype(main_tag)::value;
     TL(0);  // stage entry
+    // checkpoint at the top of a free stage j = FIRST << k: the cost-to-go as it stands and the base state it is expanded around
+    // (ONE uniform branch per stage, ahead of everything else; DEFECT sweeps carry the base state of the stage anyway, the others
+    // — cold starts and restarts from the second rung up — fetch it again: it was read one stage ago)
+    if (MAIN && ck_ && (j & (j - 1)) == 0 && j >= PMPC_AS_CK_FIRST) {
+      const double *ck = ubase(ck_, (long long)(__builtin_ctz((unsigned)j) - PMPC_AS_CK_LOG) * (long long)(CKS * D8));
+#pragma unroll
+      for (int r = 0; r < KS; r++) gsto(ck, (unsigned)((lane + 64 * r) * D8), S[r]);
+      const double xj = DEFECT ? xb_carry : ldo(ubase(Xb_, xoff(j)), lxc);
+      if (g == 0 && L.cxv) {
+        gsto(ck, (unsigned)(64 * KS * D8) + lxc, s_col);
+        gsto(ck, (unsigned)((64 * KS + 16) * D8) + lxc, xj);
+      }
+    }
     const bool cons = MAIN ? false : j < Nc;
     const bool below = MAIN ? true : j > 0;  // a stage j - 1 exists
     double Fr[KS], Qc[KS], xm_row[KS], gx_c, Du_c;
@@ -413,7 +458,7 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   };
 
   const int jmin = Nc > 1 ? Nc : 1;  // the MAIN body covers the free stages N-1 .. jmin
-  int j = N - 1;
+  int j = jtop;
   if (MODE == 2) {
     // three register sets in a ring, three stages per trip (static roles: no moves)
     Pipe P0, P1, P2;
@@ -422,8 +467,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
       fetch_early(k, q);
       fetch_late(k, k >= 1 ? k - 1 : 0, q);
     };
-    fetch(N - 1, P0);
-    fetch(N - 2, P1);
+    fetch(jtop, P0);
+    fetch(jtop - 1, P1);
     for (; j - 2 >= jmin; j -= 3) {
       fetch(j - 2, P2);
       stage(std::true_type{}, j, P0, P0);
@@ -444,8 +489,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
     }
   } else {
     Pipe A, B;
-    fetch_early(N - 1, A);
-    fetch_late(N - 1, N >= 2 ? N - 2 : 0, A);
+    fetch_early(jtop, A);
+    fetch_late(jtop, jtop >= 1 ? jtop - 1 : 0, A);
 #if PMPC_AS_PINGPONG
     for (; j - 1 >= jmin; j -= 2) {
       stage(std::true_type{}, j, A, B);
@@ -577,6 +622,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
 #pragma unroll
   for (int r = 0; r < KS; r++) V[r] = 0.0;
   int nrel = 0, nadd = 0, nbad = 0;
+  int jh = -1;  // highest stage with a status change that counts (stages ascend: the last one seen)
   double vworst = 0.0;
   TL_DECL(2);
   // consensus step of k-group g when this wave solves the consensus system itself (a.cons_G block partials; Nc == 1): lane e
@@ -657,6 +703,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     if (lane == 0) {
       a.as_cnt[3 * i + 0] = 0; a.as_cnt[3 * i + 1] = 0; a.as_cnt[3 * i + 2] = 0;
       if (a.as_settled_out) a.as_settled_out[i] = 1;
+      if (a.as_jhi) a.as_jhi[i] = -1;
       a.as_open[i] = 0;
       if (a.as_viol) a.as_viol[i] = 0.0;
     }
@@ -712,6 +759,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     nbad |= (store_u && !(draw == draw)) ? 1 : 0;
     nrel += (cnt_here && release) ? 1 : 0;
     nadd += (cnt_here && (vlo || vhi)) ? 1 : 0;
+    jh = (cnt_here && (release || vlo || vhi)) ? j : jh;
     {  // size of the violation behind a change (diagnostic / acceptance of changes at round-off level)
       // (a diagnostic: the hardware reciprocal will do — two IEEE divisions per stage were 30 of the sweep's ~ 260 instructions)
       const double pv = (vlo ? loc - zt : (vhi ? zt - hic : 0.0)) * __builtin_amdgcn_rcp(fmax(1.0, fabs(vlo ? loc : hic)));
@@ -806,6 +854,12 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     const double m = fmax(p01, p23);
     swap16_d(m, q0, q1);
     if (lane == 0) a.as_viol[i] = fmax(q0, q1);
+  }
+  if (a.as_jhi) {  // max over the k-groups' counting lanes (c == 0: lanes 0, 16, 32, 48)
+    int m = jh;
+#pragma unroll
+    for (int k = 1; k < 4; k++) { const int o = __builtin_amdgcn_readlane(jh, 16 * k); m = o > m ? o : m; }
+    if (lane == 0) a.as_jhi[i] = m;
   }
   if (lane == 0) {
     a.as_cnt[3 * i + 0] = (int)r;

@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(256) k_cone_step(ConeArgs a) {
     if (changed) atomicAdd(&a.cnt[3 * i + 1], 1);
     if (open) atomicAdd(&a.open[i], 1);
     if (changed || open) a.settled[i] = 0;
+    if ((changed || open) && a.jhi) atomicMax(&a.jhi[i], j);
     if (bad) a.cnt[3 * i + 2] = 1;
   }
 }
@@ -453,6 +454,7 @@ __global__ void __launch_bounds__(256) k_cone_step_multi(ConeArgs a) {
     if (changed) atomicAdd(&a.cnt[3 * i + 1], changed);
     if (open) atomicAdd(&a.open[i], open);
     if (changed || open) a.settled[i] = 0;
+    if ((changed || open) && a.jhi) atomicMax(&a.jhi[i], j);
     if (bad) a.cnt[3 * i + 2] = 1;
   }
 }

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
   double rho = a.rho_scale * pws * (redd[0] + a.reg_x);
   if (!(rho > 0.0)) rho = a.rho_scale * pws;
   const double margin0 = 10.0 * (a.ctl ? a.ctl->tol_l : 1e-11 * a.dual_scale);
-  int changed = 0, open = 0;
+  int changed = 0, open = 0, jm = -1;  // jm: 1 + the highest stage with a changed / open row of this thread
   const bool clamped = a.keep_on_clamp && a.finish && a.cnt[3 * i + 1] > 0;  // (read by every thread before thread 0 adds to it, two barriers further down)
   // pass 1: the largest violation among the rows that would be newly held (a round holds only those within act_frac of it: holding
   // every violated row of a window at once over-constrains the stage — the rows behind the first usually clear once it is held)
@@ -79,10 +79,10 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
     if (st == 0 && nst != 0 && k % xd < a.ctrl_from && fmax(-sl, -sh) < vthr) { nst = 0; deferred = true; }  // violated, but not among the worst: next round
     const double zo = (nst != 0 && nst == st) ? zn : 0.0;  // (a newly held side starts without an estimate)
     if (a.finish) {
-      if (nst != st || deferred) changed++;
+      if (nst != st || deferred) { changed++; jm = k / xd + 1; }  // (k ascends)
       else if (nst != 0) {
         const double sv = nst == 1 ? sl : sh, bd = nst == 1 ? lo : hi;
-        if (fabs(sv) > a.tol * fmax(1.0, fabs(bd)) || fabs(zo - z) > a.z_tol * fmax(a.dual_scale, fabs(zo))) open++;
+        if (fabs(sv) > a.tol * fmax(1.0, fabs(bd)) || fabs(zo - z) > a.z_tol * fmax(a.dual_scale, fabs(zo))) { open++; jm = k / xd + 1; }
       }
     }
     a.st[idx] = nst;
@@ -100,11 +100,22 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
     if (t < w) { redi[0][t] += redi[0][t + w]; redi[1][t] += redi[1][t + w]; }
     __syncthreads();
   }
+  const int nchanged = redi[0][0], nopen = redi[1][0];
+  if (a.jhi && a.finish) {  // (uniform)
+    __syncthreads();
+    redi[0][t] = jm;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) redi[0][t] = redi[0][t] > redi[0][t + w] ? redi[0][t] : redi[0][t + w];
+      __syncthreads();
+    }
+    if (t == 0 && redi[0][0] > a.jhi[i]) a.jhi[i] = redi[0][0];
+  }
   if (t == 0) {
-    a.open[i] = redi[1][0];
+    a.open[i] = nopen;
     if (a.finish) {
-      a.cnt[3 * i + 1] += redi[0][0];
-      if (redi[0][0] || redi[1][0]) a.settled[i] = 0;
+      a.cnt[3 * i + 1] += nchanged;
+      if (nchanged || nopen) a.settled[i] = 0;
     }
   }
 }

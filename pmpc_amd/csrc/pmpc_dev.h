@@ -54,6 +54,14 @@ struct AsCtl {
                      // clamped stood (relative to max(1, |bound|)), how negative a released multiplier was (relative to dual_scale)
 };
 
+// the factor sweeps of the active-set rounds checkpoint their cost-to-go at the top of the stages FIRST << k, k = 0, 1, .. (LQArgs::as_ck):
+// a geometric ladder — status changes sit near the start of the horizon (config D: none above stage 7), each checkpoint costs the
+// sweep five stores, and a restart anywhere on the ladder redoes at most twice the stages an ideal one would
+#ifndef PMPC_AS_CK_LOG
+#define PMPC_AS_CK_LOG 3
+#endif
+#define PMPC_AS_CK_FIRST (1 << PMPC_AS_CK_LOG)
+
 // Arguments of the structured LQ kernels (Riccati factor / vector sweeps / forward sweep).
 struct LQArgs {
   int x, u, N, M, Nc;
@@ -102,6 +110,15 @@ struct LQArgs {
   // still valid): the factor sweep / condensing skip them (as_settled_in), the forward sweep marks them (as_settled_out)
   const int *as_settled_in;
   int *as_settled_out;
+  // checkpointed restart of the later rounds' factor sweeps (kernels_as.hip): every factor sweep leaves the cost-to-go (S, s) and
+  // the base state it was expanded around at the top of the stages j = PMPC_AS_CK_FIRST << k, k = 0 .. ck_slots - 1; the forward sweep records
+  // the highest stage whose status changed (as_jhi, -1: none; the cone / state-row passes raise it to the highest stage whose
+  // Newton terms changed); an unsettled particle's next factor sweep starts at the lowest checkpoint at or above that stage
+  // — the recursion above it is unchanged, s follows the base point exactly: s + S (x_base_now - x_base_then).  Null = off.
+  double *as_ck;
+  int *as_jhi;
+  int ck_slots;
+  unsigned long long *ck_stat;  // {restarted sweeps, stages they ran, sweeps of unsettled particles from the terminal cost, stages they ran} (pmpc_restart_stats)
   double as_big, as_tol_p, as_tol_l;
   // stage-cone rounds with one consensus stage: once the step of every FREE shared control is below as_freeze_tol (relative), it is taken
   // as zero by every particle — a convergence tolerance on the shared controls — and the settled particles leave the forward sweep at
@@ -258,6 +275,7 @@ struct ConeArgs {
   double *z, *rec;            // multipliers (M,N,rows) and the per-cone record of the prepared round (M,N,ncones,PMPC_CONE_REC)
   double *H, *g;              // outputs: Newton terms (M,N,u,u) column-major blocks, (M,N,u)
   int *cnt, *settled, *open;  // per particle: as_cnt (3 ints: case changes are added to [1]), settled flag (cleared), open cones
+  int *jhi;                   // per particle or null: raised to the highest stage with a changed / open cone (LQArgs::as_jhi)
   const int *done;
   const AsCtl *ctl;           // round control block (tolerance of the round); null: 1e-11 dual_scale
   int finish;                 // 0: prepare only (first round of an attempt)
@@ -284,6 +302,8 @@ struct XboxArgs {
   int *st;                   // 0 free, 1 lower side held, 2 upper side held
   double *D, *g;             // outputs (M,N,x)
   int *cnt, *settled, *open; // per particle: as_cnt (status changes are added to [1]), settled flag (cleared), rows not yet on their bound
+  int *jhi;                  // per particle or null: raised to 1 + the highest stage with a changed / open state row (LQArgs::as_jhi: the row's penalty
+                             // sits in the cost-to-go at the top of ITS stage, so the factor sweep has to start above it)
   const int *done;
   const AsCtl *ctl;
   int finish;                // 0: prepare only (first round of an attempt)

@@ -161,6 +161,7 @@ struct Workspace {
   DevBuf lateX, lateU;  // last interior-point iterate with mu <= 1e-10 mu_peak and small residuals (kept against a numerical breakdown at mu ~ 1e-12)
   long long warm_key = -1;
   double warm_mu = 0.0;  // barrier parameter the remembered iterate belongs to (0: the early iterate of a hard-constrained solve)
+  DevBuf as_ck, as_jhi, ck_stat;  // checkpoints of the factor sweeps' cost-to-go + highest changed stage per particle (restart of the later rounds' sweeps)
   DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta, as_viol;  // active-set iteration: status per bounded control (int), counters,
                                                                  // per-particle counters, settled flags, control block, applied consensus step
   long long su_key = -1;  // shape / source arrays the working copy of the control boxes (w.su.lo, w.su.hi) was made for
@@ -191,7 +192,7 @@ struct ProfCat {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_AS_CKPT, OPT_COUNT
 };
 static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COUNT] = {
     {"as_warm", "PMPC_AS_WARM", 1},                // warm start of the active-set rounds from the previous solve's set
@@ -212,6 +213,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"cone_epigraph", "PMPC_CONE_EPIGRAPH", 1},    // cone objective with hard boxes: epigraph problem in the shared-control space (any tie pattern); 0: weighted-QP fixed point
     {"cond_grouped", "PMPC_COND_GROUPED", 1},      // Nc > 1: condensed Hessians summed over groups of particles inside the condensing kernel
     {"as_freeze_tol", "PMPC_AS_FREEZE_TOL", 1e-9}, // stage-cone rounds: a shared-control step below this (relative) is zero for every particle; settled ones skip the forward sweep
+    {"as_ckpt", "PMPC_AS_CKPT", 1},                // factor sweeps checkpoint their cost-to-go at stages 8, 16, 32, ..; the later rounds' sweeps restart at the lowest checkpoint above the highest changed stage
 };
 
 struct pmpc_ctx {
@@ -541,7 +543,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol,
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol, &w.as_ck, &w.as_jhi, &w.ck_stat, &w.Hc_grp,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
                    &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.xb_z, &w.xb_st, &w.xb_D, &w.xb_g, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
   for (DevBuf *b : all) b->release();
@@ -594,6 +596,15 @@ void pmpc_profile_read_all(pmpc_ctx *c, double *ms, long long *n, int count) {
 void pmpc_profile_read_partial(pmpc_ctx *c, double *ms, long long *n) {
   *ms = c->partial_ms;
   *n = c->partial_n;
+}
+
+void pmpc_restart_stats(pmpc_ctx *c, unsigned long long *out4, int reset) {
+  for (int k = 0; k < 4; k++) out4[k] = 0;
+  if (!c || !c->ws.ck_stat.p) return;
+  (void)hipSetDevice(c->device);
+  HIP_WARN(hipStreamSynchronize(c->stream));
+  HIP_WARN(hipMemcpy(out4, c->ws.ck_stat.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) HIP_WARN(hipMemset(c->ws.ck_stat.p, 0, 4 * sizeof(unsigned long long)));
 }
 
 int pmpc_comm_unique_id(void *out128) {
@@ -1330,6 +1341,18 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     w.as_viol.ensure((size_t)M * D8);
     b.as_viol = w.as_viol.d();
     b.Xb = p->X_out; b.Ub = p->U_out; b.Xo = p->X_out; b.Uo = p->U_out;
+    {  // checkpointed restart of the later rounds' factor sweeps (kernels_as.hip)
+      int slots = 0;  // stages FIRST << k <= N - 1
+      if (c->opt[OPT_AS_CKPT] != 0.0 && as_skip_on && nc <= 32)
+        while ((PMPC_AS_CK_FIRST << slots) <= N - 1) slots++;
+      if (slots > 0) {
+        const int ks = (x + 3) / 4;
+        w.as_ck.ensure((size_t)M * slots * (64 * ks + 32) * D8);
+        w.as_jhi.ensure((size_t)M * sizeof(int));
+        if (w.ck_stat.ensure(4 * sizeof(unsigned long long))) HIP_CHECK(hipMemsetAsync(w.ck_stat.p, 0, 4 * sizeof(unsigned long long), s));
+        b.as_ck = w.as_ck.d(); b.as_jhi = (int *)w.as_jhi.p; b.ck_slots = slots; b.ck_stat = (unsigned long long *)w.ck_stat.p;
+      }
+    }
     w.as_key = -1;
     // stage cones (mode 0 warm / 3 cold): Newton terms per round from kernels_cone.hip, see the header there
     const bool cone = cone_as && (mode == 0 || mode == 3 || mode == 5);
@@ -1356,6 +1379,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       ca.R = p->R; ca.r32 = a.mat32; ca.reg_u = p->reg_u; ca.rho_scale = 1e7;
       ca.z = w.cone_z.d(); ca.rec = w.cone_rec.d(); ca.H = w.Hadd.d(); ca.g = w.wu_soc.d();
       ca.cnt = (int *)w.as_cntp.p; ca.settled = (int *)w.as_settled.p; ca.open = (int *)w.as_open.p; ca.done = &ctl->done; ca.ctl = ctl;
+      ca.jhi = b.as_jhi;
       // (measured at config E: 1e-6 .. 1e-3 changes the round count by 7.25 -> 6.75 only — the rounds behind the last status change are the Newton iteration itself)
       ca.tol_step = 1e-6; ca.tol_phi = 1e-9;
       ca.dual_scale = dual_scale;
@@ -1378,6 +1402,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       xa.M = M; xa.N = N; xa.x = x; xa.lo = p->lx; xa.hi = p->ux; xa.Q = p->Q; xa.pw = p->weights; xa.reg_x = p->reg_x; xa.rho_scale = 1e7;  // (measured, bench.py --vmax: 1e5 .. 1e2 only add rounds)
       xa.z = w.xb_z.d(); xa.st = (int *)w.xb_st.p; xa.D = w.xb_D.d(); xa.g = w.xb_g.d();
       xa.cnt = (int *)w.as_cntp.p; xa.settled = (int *)w.as_settled.p; xa.open = (int *)w.as_open.p; xa.done = &ctl->done; xa.ctl = ctl;
+      xa.jhi = b.as_jhi;
       xa.tol = 1e-9; xa.dual_scale = dual_scale;
       // (a held row stays open while |s| > tol; its multiplier moves by rho s, so the second test only matters for rows with a small multiplier.
       //  Measured, bench.py --vmax 3 / 2: 1e-6 costs one more round per solve than 1e-3 (709 -> 777 it/s, 267 -> 295), same answers to 1e-9)
@@ -1535,6 +1560,15 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         int nset = 0;
         { std::vector<int> hs(M); HIP_CHECK(hipMemcpy(hs.data(), w.as_settled.p, M * sizeof(int), hipMemcpyDeviceToHost)); for (int v : hs) nset += v; }
         printf("pmpc_hip: trace: round %d max |du_c| %.3e, %d of %d particles settled\n", h.round, m, nset, M);
+        if (b.as_jhi) {  // histogram of the highest changed stage among the unsettled particles
+          std::vector<int> hj(M), hs(M), hist(N + 1, 0);
+          HIP_CHECK(hipMemcpy(hj.data(), w.as_jhi.p, M * sizeof(int), hipMemcpyDeviceToHost));
+          HIP_CHECK(hipMemcpy(hs.data(), w.as_settled.p, M * sizeof(int), hipMemcpyDeviceToHost));
+          for (int q = 0; q < M; q++) if (!hs[q]) hist[hj[q] < 0 ? N : hj[q]]++;
+          printf("pmpc_hip: trace:   highest changed stage:");
+          for (int q = 0; q <= N; q++) if (hist[q]) printf(" %d:%d", q == N ? -1 : q, hist[q]);
+          printf("\n");
+        }
       }
       if (verbose > 1 && xbox) {  // debugging aid: the state rows after this batch — held rows, largest multiplier, largest |x|, per worst particle
         HIP_CHECK(hipStreamSynchronize(s));

@@ -275,6 +275,14 @@ class DeviceSolver:
             out[name] = (ms8[k], n8[k])
         return out
 
+    def restart_stats(self, reset: bool = True):
+        """Factor sweeps of unsettled particles in the later rounds since the last reset (option ``as_ckpt``):
+        ``dict(restarted=, restarted_stages=, full=, full_stages=)`` — sweeps that started from a checkpoint / from the
+        terminal cost, and the stages they ran."""
+        out = (ctypes.c_ulonglong * 4)()
+        self.lib.pmpc_restart_stats(self.h, out, 1 if reset else 0)
+        return dict(restarted=int(out[0]), restarted_stages=int(out[1]), full=int(out[2]), full_stages=int(out[3]))
+
 
 def to_device_problem(prob: dict, device="cuda"):
     """py-layout numpy problem (pmpc_amd.dynamics.make_*_problem) -> ABI-layout CUDA tensors."""

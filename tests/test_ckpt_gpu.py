@@ -1,0 +1,100 @@
+"""Checkpointed restart of the later rounds' factor sweeps (kernels_as.hip, option `as_ckpt`): an unsettled particle's sweep
+starts at the lowest checkpoint at or above its highest changed stage instead of at the terminal cost.  The answers must not
+depend on it: the same SCP loop with the option on and off, iteration by iteration, and the restarts must actually happen —
+also from the higher rungs of the ladder (a reference that jumps in mid-horizon saturates controls there)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _loop(model, prob, steps, ck, Nc, xb=None):
+    import torch
+
+    from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, DeviceSolver, to_device_problem
+
+    d = to_device_problem(prob)
+    s = DeviceSolver(0)
+    s.set_option("as_ckpt", ck)
+    mid = MODEL_QUADROTOR if model == "quadrotor" else MODEL_UNICYCLE
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    out, rounds = [], 0
+    kw = {} if xb is None else dict(lx=-xb, ux=xb)
+    for it in range(steps):
+        f, fx, fu = s.linearize(mid, d["x0"], Xa, Ua, d["params"])
+        _, _, status = s.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"],
+                                   reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=Nc, x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"), X_out=Xb, U_out=Ub,
+                                   symmetric_cost=True, static_cons_bounds=True, prev_is_last_solution=it > 0, **kw)
+        s.sync()
+        assert status == 0
+        rounds += s.last_info["active_set_rounds"]
+        out.append((Xb.cpu().numpy().copy(), Ub.cpu().numpy().copy()))
+        Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+    st = s.restart_stats()
+    s.close()
+    return out, rounds, st
+
+
+def _compare(a, b):
+    worst = 0.0
+    for (Xa, Ua), (Xb, Ub) in zip(a, b):
+        worst = max(worst, np.abs(Xa - Xb).max() / max(1.0, np.abs(Xa).max()), np.abs(Ua - Ub).max() / max(1.0, np.abs(Ua).max()))
+    return worst
+
+
+@pytest.mark.parametrize("N,Nc,jump", [(50, 1, False), (50, 1, True), (20, 1, False), (100, 2, True), (40, 0, True)])
+def test_restart_leaves_the_answers_alone_quadrotor(N, Nc, jump):
+    from pmpc_amd import dynamics as dyn
+
+    prob = dyn.make_quadrotor_problem(M=192, N=N, Nc=Nc)
+    if jump:  # the position reference jumps at two thirds of the horizon: torques saturate around that stage
+        prob["X_ref"][:, (2 * N) // 3:, 0] += 1.5
+        prob["u_u"][..., 1:] = 0.2
+        prob["u_l"][..., 1:] = -0.2
+    off, r0, s0 = _loop("quadrotor", prob, 5, 0, Nc)
+    on, r1, s1 = _loop("quadrotor", prob, 5, 1, Nc)
+    assert r0 == r1 and r0 > 5, (r0, r1)  # several rounds per solve: there is something to restart
+    assert s0["restarted"] == 0
+    assert s1["restarted"] > 0, s1
+    if jump:  # changes in mid-horizon: restarts from the higher rungs (more than the 9 stages of the first one), or none possible
+        assert s1["restarted_stages"] > 9 * s1["restarted"] or s1["full"] > 0, s1
+    assert _compare(off, on) < 1e-10
+
+
+def test_restart_leaves_the_answers_alone_unicycle():
+    """x4 u2 (one MFMA k-step per tile).  The unicycle's closed-form Jacobians amplify last-bit differences of the iterate by many
+    orders (tests/test_device_gpu.py: n / u2^3 cancellations), so two independent loops drift apart whatever the solver does: here
+    both contexts solve the SAME sub-problems in lock-step (the iterate of the context without restarts is handed to both)."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_UNICYCLE, DeviceSolver, to_device_problem
+
+    prob = dyn.make_unicycle_problem(M=64, N=30, Nc=1)
+    d = to_device_problem(prob)
+    sa, sb = DeviceSolver(0), DeviceSolver(0)
+    sa.set_option("as_ckpt", 0)
+    sb.set_option("as_ckpt", 1)
+    Xp, Up = d["X_prev"].clone(), d["U_prev"].clone()
+    worst, rounds = 0.0, 0
+    for it in range(6):
+        f, fx, fu = sa.linearize(MODEL_UNICYCLE, d["x0"], Xp, Up, d["params"])
+        sa.sync()
+        outs = []
+        for s in (sa, sb):
+            X, U, status = s.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"],
+                                       reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"),
+                                       symmetric_cost=True, static_cons_bounds=True, prev_is_last_solution=it > 0)
+            s.sync()
+            assert status == 0
+            outs.append((X.cpu().numpy(), U.cpu().numpy()))
+        assert sa.last_info["active_set_rounds"] == sb.last_info["active_set_rounds"]
+        rounds += sb.last_info["active_set_rounds"]
+        worst = max(worst, _compare([outs[0]], [outs[1]]))
+        Xp, Up = X_a, U_a = torch.as_tensor(outs[0][0], device=Xp.device), torch.as_tensor(outs[0][1], device=Up.device)
+    st = sb.restart_stats()
+    sa.close()
+    sb.close()
+    assert rounds > 6 and st["restarted"] > 0, (rounds, st)
+    assert worst < 1e-12, worst
