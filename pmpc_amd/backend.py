@@ -263,6 +263,11 @@ def aff_solve(
                 raise ValueError("extra_cstrs: rows on the states together with cones on the controls are not supported in one solve")
             if slew_rate or u_slew is not None or "slew_reg" in solver_settings:
                 raise ValueError("extra_cstrs: rows on the states are not supported together with slew penalties")
+            if str(solver_settings.get("smooth_cstr", "")).lower() == "squareplus" and np.isfinite(float(solver_settings.get("smooth_alpha", np.nan))):
+                # the reference smooths extra_cstrs' linear rows only under "logbarrier" (main.jl:298-312); under "squareplus" they stay HARD
+                # rows next to softened boxes — restated as state boxes they would be softened with them: refused, not solved differently
+                raise ValueError('extra_cstrs: rows on the states together with smooth_cstr="squareplus" are not supported '
+                                 "(the reference keeps them hard there; this path would soften them with the boxes)")
             try:
                 rows = stage_rows_from_extra_cstrs(state_rows, Mb, Nb, xd, ud, Ncb)
             except ValueError as e_rows:

@@ -684,10 +684,13 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       const int *act0 = a.as_act + pbase * UD;
       const double *ub0 = Ub + pbase * UD;
       double ym = 0.0;
+      bool asks_release = false;  // a HELD shared control whose multiplier has the wrong sign: the consensus stage has a decision to take
 #pragma unroll
-      for (int p = 0; p < UD; p++)
+      for (int p = 0; p < UD; p++) {
         if (act0[p] == 0) ym = fmax(ym, fabs(y[p]) / fmax(1.0, fabs(ub0[p])));
-      frozen = ym <= a.as_freeze_tol;
+        else asks_release |= (act0[p] == 1 ? -a.as_big * y[p] : a.as_big * y[p]) < -tol_l;
+      }
+      frozen = ym <= a.as_freeze_tol && !asks_release;
       if (frozen) {
 #pragma unroll
         for (int p = 0; p < UD; p++)

@@ -2843,6 +2843,10 @@ static int lcone_free_particles_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
       if (verbose) printf("pmpc_hip: cone objective, free particles: shared control %d leaves its bound (multiplier %.3e of the wrong sign)\n", worst, wv);
       continue;
     }
+    if (est != 0) {  // never an unverified iterate: the epigraph rows of THIS answer are only as good as the host solve that produced it
+      if (verbose) printf("pmpc_hip: cone objective, free particles: the last host solve did not converge: no answer from this path\n");
+      return -1;
+    }
     done = true;
   }
   if (!done) {
@@ -2941,7 +2945,7 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
     // full-space Newton path has it (mu carries 1/alpha)
     const int st_s = M > 1 ? lcone_smooth_body(c, p, q.barrier_mu, info, verbose, 1, p->smooth_beta > 0.0 ? p->smooth_beta : 1.0) : -1;
     if (st_s >= 0) return st_s;
-    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs M > 1 particles on one rank, Nc <= 1, no slew penalties / particle weights and a compiled (xdim, udim) pair\n");
+    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs M > 1 particles on one rank, boxes to smooth, M (Nc u)^2 <= 2e7, no slew penalties / particle weights / fp32 storage and a compiled (xdim, udim) pair\n");
     fill_nan_outputs(c, p);
     if (info) { memset(info, 0, sizeof(*info)); info->status = 2; }
     return 2;

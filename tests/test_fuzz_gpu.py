@@ -77,3 +77,11 @@ def test_fuzz_library_scp_loop_against_python_driven_loop():
     last = _run("fuzz_scp_loop.py", 102, 150)[-1]
     m = re.search(r"(\d+) cases, (\d+) failures, worst difference ([0-9.e+-]+)", last)
     assert m and int(m.group(2)) == 0, last
+
+
+def test_fuzz_freeze_of_the_shared_step_changes_no_answer():
+    # (seed 7, sequence 36: a held shared control released in a late round while the free ones stand still — the ADVICE r04 case,
+    #  4e-2 off with status 0 before the fix)
+    last = _run("fuzz_freeze.py", 7, 45, 5)[-1]
+    m = re.search(r"(\d+) solves, (\d+) failures, worst freeze on/off ([0-9.e+-]+), worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(1)) > 150 and int(m.group(2)) == 0 and float(m.group(3)) <= 1e-7 and float(m.group(4)) <= 1e-6, last
