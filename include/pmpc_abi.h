@@ -222,6 +222,9 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *                                             is taken as zero by every particle, and the settled particles leave the forward sweep at once (0: off)
  *   as_ckpt          PMPC_AS_CKPT          1   the factor sweeps leave their cost-to-go at stages 8, 16, 32, ..; an unsettled particle's factor sweep of a
  *                                             later round starts at the lowest of them at or above its highest changed stage (0: from the terminal cost)
+ *   as_sens_min_m    PMPC_AS_SENS_MIN_M    3072  one consensus stage, at least this many particles on the rank: the forward sweep records the sensitivity
+ *                                             of every stage to the shared-control step, and settled particles of the later rounds are updated elementwise
+ *                                             from it instead of being swept again (0: never)
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);

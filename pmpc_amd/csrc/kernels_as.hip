@@ -542,7 +542,19 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
 // other twelve stay zero.
 // CONE: also records each stage's own Newton step u_b + du BEFORE clamping (a.as_uraw: the cone multiplier updates of
 // kernels_cone.hip are valid for that step only) — a third lane of the per-control store, no further instruction.
-template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false, class MT = double>
+// SENS (one consensus stage; a.as_T): the sweep also carries the SENSITIVITY of the particle's closed-loop trajectory to the step of
+// the shared controls — UD more columns of the same tile products (the tile has 16 columns, the state uses 4: the arithmetic is there
+// anyway) — and leaves it as one 64-double record per stage, as_T[j] = d(x_j, du_j) / d delta.  A SETTLED particle of a later round
+// (no status change, no factor sweep) then does not walk the horizon again: its wave takes the consensus stage as usual and updates
+// the other stages elementwise, four stages per instruction — X += T_x delta, U += T_u delta on the free controls, the multipliers of
+// the held ones by the same rule, with the sweep's own box / sign tests.  A violation un-settles the particle (it counts as a change:
+// the round is not accepted, the next one sweeps the particle), so an accepted set is exactly as exact as before.  Why it pays: at
+// 4096 particles the sweeps are bound by instruction issue (profiles/r05_pmc_sq_D.txt), a sweep stage costs ~260 instructions, an
+// elementwise stage ~10, and from the second round on 50 - 99 % of the particles are settled: a later round's launch takes 43 - 65 us
+// instead of 113 (bound by the 0.9 KB per stage the elementwise update moves).  Measured same-box: 4096 particles +9 %, 2048 and fewer
+// -4 .. -6 % (two waves per SIMD: the launch waits for the few sweeping waves either way, and the records cost the first round
+// 25 us) — solver.hip switches it on from 3072 particles per rank (option as_sens_min_m).
+template <int XD, int UD, bool DEFECT, bool PF2, bool CONE = false, class MT = double, bool SENS = false>
 __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   typedef Lane<XD, UD> LT;
   constexpr int KS = LT::KS;
@@ -585,6 +597,8 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   const long long px = (long long)(pbase * XD) * D8, pu = (long long)(pbase * UD) * D8;
   const double *Xb_ = ubase(Xb, px), *f_ = ubase(a.f, px), *Xo_ = ubase(a.Xo, px);
   const double *act_ = ubase((const double *)a.as_act, pu >> 1);
+  const double *T_ = SENS ? ubase(a.as_T, (long long)(pbase * 64) * D8) : Z;
+  const unsigned lT = (unsigned)((((c - 4) & 3) * 16 + 4 * g) * D8);  // this lane's 32 bytes of a stage's sensitivity record (lanes c = 4 .. 4 + UD - 1)
   auto xoff = [&](int jj) { return (long long)(jj * (int)(XD * D8)); };
   auto uoff = [&](int jj) { return (long long)(jj * (int)(UD * D8)); };
   // per-control inputs of control g: lanes c = 0..3 of the k-group read {U base, feed-forward, lower, upper}[c], lane 7 the status
@@ -624,6 +638,9 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   int nrel = 0, nadd = 0, nbad = 0;
   int jh = -1;  // highest stage with a status change that counts (stages ascend: the last one seen)
   double vworst = 0.0;
+  double dcap = 0.0;  // SENS: the step of shared control g as applied (lane c = 0 of k-group g)
+  // settled: the stages behind the consensus stage elementwise (never in a DEFECT sweep: the first round of an attempt sweeps every particle)
+  const bool elem = SENS && !DEFECT && a.as_settled_in && a.as_settled_in[i];
   TL_DECL(2);
   // consensus step of k-group g when this wave solves the consensus system itself (a.cons_G block partials; Nc == 1): lane e
   // sums entry e of [H | g] in block order — the same operations in every wave, so every particle applies the same step —,
@@ -771,6 +788,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     }
     TL(3);  // decisions taken (the first use of `raw` waited for the MFMA chain)
     const double du_q = dpp_d<0x00>(dug);  // the decision of lane 0, in the four lanes of the k-group whose columns are kept
+    if (SENS && !MAIN && j < Nc) dcap = dug;
     // feed-forward of the NEXT round if this particle stays settled (no factor sweep then): at base + step every free
     // control is stationary (k = 0) and a held one keeps its multiplier, k_b = -du_b
     const double knew = actc ? -draw : 0.0;
@@ -789,7 +807,22 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
     TL(4);  // control / status stores issued
     // second pass: + B du.  The C layout of the result IS the B layout of the next stage's state: nothing moves.
     D[KS] = 0.0;
-    D = mfma(cur.T[KS], (c < 4 && gu) ? du_q : 0.0, D);
+    double bop = (c < 4 && gu) ? du_q : 0.0;
+    if (SENS) {  // sensitivity columns c = 4 .. 4 + UD - 1: unit steps of the shared controls on the consensus stage, the feedback law behind it
+      const bool sc = c >= 4 && c < 4 + UD && gu;
+      const double bs = (!MAIN && j < Nc) ? ((g == c - 4) ? 1.0 : 0.0) : -raw;
+      bop = sc ? bs : bop;
+    }
+    D = mfma(cur.T[KS], bop, D);
+    if (SENS) {  // the stage's record: lane (4 + k, g) owns slots 4 g .. 4 g + 3 of column k (KS state rows, then control g): 32 bytes per lane
+      if (c >= 4 && c < 4 + UD) {
+        typedef double v2dd __attribute__((ext_vector_type(2)));
+        const v2dd lo2 = {D[0], KS > 1 ? D[KS > 1 ? 1 : 0] : 0.0}, hi2 = {KS > 2 ? D[KS > 2 ? 2 : 0] : 0.0, gu ? bop : 0.0};
+        __attribute__((address_space(1))) char *t = (__attribute__((address_space(1))) char *)(unsigned long long)ubase(T_, (long long)(j * (int)(64 * D8))) + lT;
+        *(v2dd __attribute__((address_space(1))) *)t = lo2;
+        *(v2dd __attribute__((address_space(1))) *)(t + 16) = hi2;
+      }
+    }
     if (DEFECT) {  // the defect r = f - x_prev of row KS g + r sits in lane c = r of the k-group: quad broadcasts
       const double dfo = own_x ? cur.f - cur.xb : 0.0;
       D[0] += dpp_d<0x00>(dfo);
@@ -803,14 +836,114 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       gsto(ubase(Xo_, xoff(j)), lx1, cur.xb + mine);
     }
 #pragma unroll
-    for (int r = 0; r < KS; r++) V[r] = (c < 4) ? D[r] : 0.0;  // (the other columns of the tile carry nothing: kept at zero)
+    for (int r = 0; r < KS; r++) V[r] = (c < (SENS ? 4 + UD : 4)) ? D[r] : 0.0;  // (the other columns of the tile carry nothing: kept at zero)
     TL(5);  // new state stored and in place
     TL_FLUSH(j);
+  };
+
+  // SENS: a settled particle's stages behind the consensus stage, elementwise from the sensitivity records (see the kernel's header
+  // comment).  Lane (q4, s16) = stage q4 of a group of four x slot s16 of the record (slot 4 gs + rs: state row KS gs + rs for
+  // rs < KS, control gs for rs = 3); SB groups per trip, every load of the trip issued before anything is stored.
+  int nrel_e = 0, nadd_e = 0, nbad_e = 0, jh_e = -1;
+  auto settled_update = [&](int j0) {
+    double dl[UD];
+#pragma unroll
+    for (int k = 0; k < UD; k++) dl[k] = readlane_d(dcap, 16 * k);
+    const int s16 = lane & 15, q4 = lane >> 4, gs = s16 >> 2, rs = s16 & 3;
+    const bool is_x = rs < KS && KS * gs + rs < XD, is_u = rs == 3 && gs < UD;
+    const size_t xo = (size_t)(is_x ? KS * gs + rs : 0), uo = (size_t)(is_u ? gs : 0);
+    constexpr int SB = 4;
+    for (int j4 = j0; j4 < N; j4 += 4 * SB) {
+      double dv[SB], xv[SB], ub[SB], kf[SB], lo[SB], hi[SB];
+      int act[SB];
+#pragma unroll
+      for (int q = 0; q < SB; q++) {
+        const int jj = j4 + 4 * q + q4, jc = jj < N ? jj : N - 1;  // (clamped: the tail re-reads the last stage, its results are dropped)
+        const double *t = a.as_T + (pbase + jc) * 64 + s16;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < UD; k++) acc = fma(gld(t + 16 * k), dl[k], acc);
+        dv[q] = acc;
+        xv[q] = is_x ? gld(Xb + (pbase + jc) * XD + xo) : 0.0;
+        const size_t e = (pbase + jc) * UD + uo;
+        ub[q] = is_u ? gld(Ub + e) : 0.0;
+        kf[q] = is_u ? gld(a.kff + e) : 0.0;
+        lo[q] = is_u ? gld(a.as_lo + e) : 0.0;
+        hi[q] = is_u ? gld(a.as_hi + e) : 0.0;
+        act[q] = is_u ? a.as_act[e] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < SB; q++) {
+        const int jj = j4 + 4 * q + q4;
+        const bool live = jj < N;
+        if (is_x && live) gst(a.Xo + (pbase + jj) * XD + xo, xv[q] + dv[q]);
+        if (is_u && live) {
+          const size_t e = (pbase + jj) * UD + uo;
+          if (act[q] == 0) {
+            const double zt = ub[q] + dv[q];
+            const bool vlo = zt < lo[q] - a.as_tol_p * fmax(1.0, fabs(lo[q])), vhi = !vlo && zt > hi[q] + a.as_tol_p * fmax(1.0, fabs(hi[q]));
+            nadd_e += (vlo || vhi) ? 1 : 0;  // (outside its box and still free: the next round sweeps this particle and clamps it)
+            nbad_e |= !(zt == zt) ? 1 : 0;
+            gst(a.Uo + e, zt);
+          } else {
+            const double kn = kf[q] - dv[q];  // kff holds -du_b of the held control: its multiplier is -/+ big du_b
+            const double lam = act[q] == 1 ? a.as_big * kn : -a.as_big * kn;
+            const bool release = lam < -tol_l;
+            nrel_e += release ? 1 : 0;
+            jh_e = (release && jj > jh_e) ? jj : jh_e;
+            nbad_e |= !(kn == kn) ? 1 : 0;
+            gst(a.kff + e, kn);
+            if (release) a.as_act[e] = 0;
+            if (a.Uo != Ub) gst(a.Uo + e, ub[q]);
+          }
+        }
+      }
+    }
+  };
+
+  auto finish = [&]() {
+    // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
+    double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
+    if (SENS && elem) {  // the elementwise path counted in the control slots of every stage group: sum over the wave
+      r += grp_allsum(row_allsum((double)nrel_e)); d += grp_allsum(row_allsum((double)nadd_e)); b += grp_allsum(row_allsum((double)nbad_e));
+      int m = jh_e;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(m, o, 64); m = v > m ? v : m; }
+      jh = m > jh ? m : jh;  // (every lane holds the maximum: lane 0's copy is the one written below)
+    }
+    if (a.as_viol) {  // max over the k-groups (the counting lanes are c == 0)
+      double p01, p23, q0, q1;
+      swap32_d(vworst, p01, p23);
+      const double m = fmax(p01, p23);
+      swap16_d(m, q0, q1);
+      if (lane == 0) a.as_viol[i] = fmax(q0, q1);
+    }
+    if (a.as_jhi) {  // max over the k-groups' counting lanes (c == 0: lanes 0, 16, 32, 48)
+      int m = jh;
+#pragma unroll
+      for (int k = 1; k < 4; k++) { const int o = __builtin_amdgcn_readlane(jh, 16 * k); m = o > m ? o : m; }
+      if (lane == 0) a.as_jhi[i] = m;
+    }
+    if (lane == 0) {
+      a.as_cnt[3 * i + 0] = (int)r;
+      a.as_cnt[3 * i + 1] = (int)d;
+      a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
+      if (a.as_settled_out) a.as_settled_out[i] = (r == 0.0 && d == 0.0 && !(b > 0.0)) ? 1 : 0;
+      if (CONE) a.as_open[i] = 0;  // (counted by the cone pass that follows)
+    }
   };
 
   const int jmin = Nc > 1 ? Nc : 1;  // MAIN covers the free stages jmin .. N-1
   auto clampN = [&](int jj) { return jj < N ? jj : N - 1; };  // (the last stages re-read the last one: no branch)
   int j = 0;
+  if constexpr (SENS && !DEFECT) if (elem) {  // (a path of its own, ahead of the sweep's register sets: nothing of the sweep is live beside the elementwise loads)
+    Pipe P;
+    fetch(0, P);
+    stage(std::false_type{}, 0, P);  // the consensus stage (Nc == 1): decisions of the shared controls, the step as applied
+    settled_update(1);
+    finish();
+    return;
+  }
   if (PF2) {
     // Prefetch distance: TWO stages.  With one wave per SIMD (small shards, the later rounds' few unsettled particles) a stage
     // of this sweep is shorter than the HBM latency, so data requested one stage ahead would still pin every stage to that
@@ -849,28 +982,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
       A = B;
     }
   }
-  // counters of this particle: the store_u lanes (c == 0, g < udim) counted; sum / or over the k-groups
-  const double r = grp_allsum((double)nrel), d = grp_allsum((double)nadd), b = grp_allsum((double)nbad);
-  if (a.as_viol) {  // max over the k-groups (the counting lanes are c == 0)
-    double p01, p23, q0, q1;
-    swap32_d(vworst, p01, p23);
-    const double m = fmax(p01, p23);
-    swap16_d(m, q0, q1);
-    if (lane == 0) a.as_viol[i] = fmax(q0, q1);
-  }
-  if (a.as_jhi) {  // max over the k-groups' counting lanes (c == 0: lanes 0, 16, 32, 48)
-    int m = jh;
-#pragma unroll
-    for (int k = 1; k < 4; k++) { const int o = __builtin_amdgcn_readlane(jh, 16 * k); m = o > m ? o : m; }
-    if (lane == 0) a.as_jhi[i] = m;
-  }
-  if (lane == 0) {
-    a.as_cnt[3 * i + 0] = (int)r;
-    a.as_cnt[3 * i + 1] = (int)d;
-    a.as_cnt[3 * i + 2] = b > 0.0 ? 1 : 0;
-    if (a.as_settled_out) a.as_settled_out[i] = (r == 0.0 && d == 0.0 && !(b > 0.0)) ? 1 : 0;
-    if (CONE) a.as_open[i] = 0;  // (counted by the cone pass that follows)
-  }
+  finish();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -993,6 +1105,9 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
       if (a.as_uraw) {
         if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true, float>), grd, blk, 0, s, a);
         else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true, float>), grd, blk, 0, s, a);
+      } else if (a.as_T && a.Nc == 1) {
+        if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, float, true>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, float, true>), grd, blk, 0, s, a);
       } else {
         if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, float>), grd, blk, 0, s, a);
         else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, float>), grd, blk, 0, s, a);
@@ -1010,6 +1125,12 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
     } else {
       abort();
     }
+  }
+  if (a.as_T && a.Nc == 1) {  // sensitivity records + elementwise update of the settled particles (solver.hip decides when)
+    // (x12 u4, DEFECT: 128 registers + 2 spilled dwords outside the stage loop; the one-stage ring, 93 registers, measured 1 - 2 % slower)
+    if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, false, double, true>), grd, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, false, double, true>), grd, blk, 0, s, a);
+    return;
   }
   if (a.M <= m2) {
     if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true>), grd, blk, 0, s, a);

@@ -146,6 +146,7 @@ struct LQArgs {
   const double *cone_H, *cone_g;
   double *as_uraw;
   int *as_open;    // per particle: open stage cones (zeroed by the forward sweep, counted by the cone pass)
+  double *as_T;    // forward sweep, one consensus stage: sensitivity records [M][N][64] (null: off) — see k_fwd_as<.., SENS>; solver.hip never sets it together with as_uraw
   // state boxes on the active-set sweeps (kernels_xbox.hip prepares them per round): a penalty on the diagonal of the stage's state
   // cost and a gradient term, per state entry (M,N,x).  Null = none (the XBOX instantiations are not launched).
   const double *xb_D, *xb_g;

@@ -98,3 +98,44 @@ def test_restart_leaves_the_answers_alone_unicycle():
     sb.close()
     assert rounds > 6 and st["restarted"] > 0, (rounds, st)
     assert worst < 1e-12, worst
+
+
+@pytest.mark.parametrize("model,M,N,f32", [("quadrotor", 192, 50, False), ("quadrotor", 96, 20, True), ("unicycle", 64, 30, False)])
+def test_elementwise_update_of_settled_particles_leaves_the_answers_alone(model, M, N, f32):
+    """Option as_sens_min_m (k_fwd_as<.., SENS>): settled particles of the later rounds take the shared-control step elementwise from the
+    forward sweep's sensitivity records.  Lock-step on identical sub-problems (see the unicycle test above), with the records on for
+    any particle count against off; fp32-storage variant included."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, MODEL_UNICYCLE, DeviceSolver, to_device_problem
+
+    prob = dyn.make_quadrotor_problem(M=M, N=N, Nc=1) if model == "quadrotor" else dyn.make_unicycle_problem(M=M, N=N, Nc=1)
+    mid = MODEL_QUADROTOR if model == "quadrotor" else MODEL_UNICYCLE
+    d = to_device_problem(prob)
+    sa, sb = DeviceSolver(0), DeviceSolver(0)
+    sa.set_option("as_sens_min_m", 0)
+    sb.set_option("as_sens_min_m", 1)
+    Q, R = (d["Q"].float().contiguous(), d["R"].float().contiguous()) if f32 else (d["Q"], d["R"])
+    Xp, Up = d["X_prev"].clone(), d["U_prev"].clone()
+    worst, rounds = 0.0, 0
+    for it in range(6):
+        f, fx, fu = sa.linearize(mid, d["x0"], Xp, Up, d["params"])
+        if f32:
+            fx, fu = fx.float().contiguous(), fu.float().contiguous()
+        sa.sync()
+        outs = []
+        for s in (sa, sb):
+            X, U, status = s.lqp_solve(f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=Q, R=R, X_ref=d["X_ref"], U_ref=d["U_ref"],
+                                       reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"),
+                                       symmetric_cost=True, static_cons_bounds=True, prev_is_last_solution=it > 0)
+            s.sync()
+            assert status == 0
+            outs.append((X.cpu().numpy(), U.cpu().numpy()))
+        rounds += sb.last_info["active_set_rounds"]
+        worst = max(worst, _compare([outs[0]], [outs[1]]))
+        Xp, Up = torch.as_tensor(outs[0][0], device=Xp.device), torch.as_tensor(outs[0][1], device=Up.device)
+    sa.close()
+    sb.close()
+    assert rounds > 6, rounds  # later rounds ran: settled particles went through the elementwise path
+    assert worst < (1e-9 if f32 else 1e-12), worst

@@ -1,6 +1,8 @@
-"""Checkpointed restart of the later rounds' factor sweeps (option as_ckpt) against full partial sweeps: the same SCP loop twice
-on one box, outputs compared iteration by iteration.  usage: ckpt_check.py [M] [N] [steps] [soc|vmax=<v>]
+"""An option of the active-set rounds off (0) against on (1) — default as_ckpt, the checkpointed restart of the later rounds' factor
+sweeps; OPT=as_sens_min_m: the elementwise update of settled particles from the forward sweep's sensitivity records — : the same SCP
+loop twice on one box, outputs compared iteration by iteration.  usage: [OPT=<option>] ckpt_check.py [M] [N] [steps] [soc|vmax=<v>]
 PMPC_DUC_TRACE=1 prints, per round, the histogram of the highest changed stage among the unsettled particles."""
+import os
 import sys
 
 import numpy as np
@@ -30,7 +32,7 @@ elif extra.startswith("vmax="):
 
 def loop(ck):
     s = DeviceSolver(0)
-    s.set_option("as_ckpt", ck)
+    s.set_option(os.environ.get("OPT", "as_ckpt"), ck)
     Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
     Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
     f = torch.empty((M, N, 12), dtype=torch.float64, device=dev)

@@ -1,6 +1,6 @@
 # usage: bash tools/debug/prof_any.sh <tag> <bench flags...>   -> top kernels of one profiled bench run
 tag=$1; shift
-out=gpurun_out/r4p/prof_$tag
+out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$out -- python3 /root/repo/bench.py --steps 10 --warmup 2 --repeats 0 --no-cpu-baseline "$@" > /root/repo/$out/out.log 2>&1 || exit 1
