@@ -226,8 +226,41 @@ def aff_solve(
 
         Mb, Nb, xd, ud = f.shape[0], f.shape[1], f.shape[2], fu.shape[-1]
         Ncb = solver_settings.get("Nc", -1)
-        rest = []
+        # ---- cost terms and exponential cones of the tuples, normalised first ---------------------------------------------------------
+        from .extra_cstrs import split_linear_cost
+
+        cone_method = str(solver_settings.get("solver", "ecos")).lower() != "osqp" or "smooth_cstr" in solver_settings or "smooth_alpha" in solver_settings
+        tuples = []
         for cstr in solver_settings["extra_cstrs"]:
+            cu_, cx_, cstr = split_linear_cost(cstr, Mb, Nb, xd, ud, Ncb)
+            if cu_ is not None:
+                # c_left sits OUTSIDE the epigraph rows (cone_utils.jl:152-154).  One particle: the epigraph row is degenerate, the program is
+                # min (1 - eps) J + c'z (+ smoothing), i.e. J with its references shifted by Q^-1 c / (1 - eps) — the reference's own device for
+                # linear cost terms (pmpc/scp_mpc.py:171-185).  Several particles: a particle whose epigraph multiplier is zero would be left
+                # with c'z alone — a linear program the Riccati structure cannot carry: refused.
+                if not cone_method:
+                    raise ValueError("extra_cstrs act in the cone program only (solver 'ecos' / 'mosek' / 'gurobi' / 'cosmo'); c_left with solver 'osqp' has no meaning upstream")
+                if Mb != 1:
+                    raise ValueError("extra_cstrs: c_left (a linear cost outside the epigraph rows) is supported for one particle only: with several, the "
+                                     "particles of multiplier zero are left with a linear program in their own variables")
+                if solver_settings.get("weights") is not None:
+                    raise ValueError("extra_cstrs: c_left together with `weights` is not supported")
+                COST_ANCHOR_EPS = 1e-3  # main.jl:223
+                X_ref = X_ref - np.linalg.solve(Q, cx_[..., None])[..., 0] / (1.0 - COST_ANCHOR_EPS)
+                U_ref = U_ref - np.linalg.solve(R, cu_[..., None])[..., 0] / (1.0 - COST_ANCHOR_EPS)
+            if int(cstr[2]) > 0:
+                # Exponential cones (cone_solver.jl:178-188).  Upstream they appear as the log-barrier triples of `make_logbarrier_constraint`
+                # (cone_utils.jl:173-200), each with a new epigraph variable in G_right.  Under smooth_cstr = "logbarrier" the reference itself
+                # refuses any tuple with G_right (main.jl:300, "We only support left matrix reformulation") and smooths a tuple's LINEAR rows
+                # instead — which is supported here; with hard or squareplus boxes such rows would be barrier terms NEXT TO hard / hinged rows:
+                # a barrier weight per row, which neither the active-set rounds nor the single-mu barrier iteration carries.
+                raise ValueError("extra_cstrs: exponential cones are not supported (under smooth_cstr='logbarrier' hand the rows over as LINEAR rows: "
+                                 "the reference smooths them into exactly those cones, main.jl:298-312, and refuses G_right there itself; with hard or "
+                                 "squareplus boxes a log-barrier row next to them needs a barrier weight of its own)")
+            if int(cstr[0]) + (sum(int(v) for v in np.atleast_1d(cstr[1])) if np.size(cstr[1]) else 0) > 0:
+                tuples.append(cstr)
+        rest = []
+        for cstr in tuples:
             try:  # single-variable linear rows: boxes
                 bx = linear_rows_to_boxes(cstr, Mb, Nb, xd, ud, Ncb)
             except ValueError:

@@ -763,7 +763,8 @@ static bool slew_increment_form_applies(const pmpc_ctx *c, const pmpc_problem *p
   return lq_fast_supported(t);
 }
 
-static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
+// the restated problem `q` (state [x; u], control increments; outputs in the workspace) and the augmentation record `g` the split needs
+static void build_slew_increment_problem(pmpc_ctx *c, const pmpc_problem *p, pmpc_problem &q, SlewAug &g) {
   HIP_CHECK(hipSetDevice(c->device));
   hipStream_t s = c->stream;
   Workspace &w = c->ws;
@@ -783,7 +784,6 @@ static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
     HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, (size_t)M * D8, s));
     HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, (size_t)M * u * D8, s));
   }
-  SlewAug g;
   memset(&g, 0, sizeof(g));
   g.x = x; g.u = u; g.N = N; g.M = M; g.Nc = Nc; g.has_xb = has_xb; g.has_ub = has_ub;
   g.has_um1 = (has_slew0 && Nc >= 1) ? 1 : 0;  // the linear term -s0 u_0'u_{-1} exists only with consensus stages (lqp_utils.jl:165)
@@ -810,7 +810,7 @@ static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
   g.alo = boxes ? w.sa_lo.d() : nullptr; g.ahi = boxes ? w.sa_hi.d() : nullptr;
   launch_slew_augment(g, s);
 
-  pmpc_problem q = *p;
+  q = *p;
   q.xdim = (size_t)n;
   q.flags &= ~(PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_HAS_UBOUNDS | PMPC_HAS_XBOUNDS | PMPC_PREV_IS_LAST_SOLUTION | PMPC_STATIC_CONS_BOUNDS);
   if (boxes) q.flags |= PMPC_HAS_XBOUNDS;
@@ -820,6 +820,17 @@ static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_in
   q.lx = g.alo; q.ux = g.ahi; q.lu = q.uu = nullptr;
   q.slew_reg = q.slew_reg0 = q.slew_um1 = nullptr;
   q.X_out = w.sa_Xo.d(); q.U_out = w.sa_Uo.d();
+}
+
+static int solve_slew_increment_form(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, int verbose) {
+  hipStream_t s = c->stream;
+  Workspace &w = c->ws;
+  const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
+  const int Nc = p->Nc < 0 ? N : (int)p->Nc;
+  const size_t rows = (size_t)M * N;
+  pmpc_problem q;
+  SlewAug g;
+  build_slew_increment_problem(c, p, q, g);
   pmpc_info inf;
   memset(&inf, 0, sizeof(inf));
   c->xb_ctrl_from = x;
@@ -2240,7 +2251,9 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   const int Nc = p->Nc < 0 ? N : (int)std::min<long long>(p->Nc, (long long)N), nc = Nc * u;
   const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
   // (several consensus stages: the condensed Hessians M (Nc u)^2 are gathered to the host every Newton step — bounded)
-  if (c->multi() || c->world != 1 || p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || M < 2 ||
+  // (M = 1: the epigraph row is degenerate — its multiplier is (1 - eps) k whatever t does — and the iteration is plain damped Newton on
+  //  (1 - eps) J + the smoothing terms; taken for the squareplus hinge, which the interior-point iteration of the QP path does not know)
+  if (c->multi() || c->world != 1 || p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || M < (smode == 1 ? 1 : 2) ||
       !(has_xb || has_ub) || !(mu_b > 0.0) || (double)M * nc * nc > 2e7)
     return -1;
   const size_t nx = (size_t)M * N * x, nu = (size_t)M * N * u, D8 = sizeof(double);
@@ -2953,9 +2966,49 @@ static int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, 
   if (p->smooth_cstr == 1 && q.barrier_mu > 0.0) {
     // smooth_cstr = "squareplus" (main.jl:265-279): soft boxes, tau(v) = beta/2 (v + sqrt(v^2 + 1/alpha^2)) per side; only the
     // full-space Newton path has it (mu carries 1/alpha)
-    const int st_s = M > 1 ? lcone_smooth_body(c, p, q.barrier_mu, info, verbose, 1, p->smooth_beta > 0.0 ? p->smooth_beta : 1.0) : -1;
+    const double sbeta = p->smooth_beta > 0.0 ? p->smooth_beta : 1.0;
+    int st_s = -1;
+    if (M == 1 && !c->multi() && (p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0)))) {
+      // ONE particle (the shape of nearly every reference example): the epigraph row is degenerate, the problem is
+      //   min (1 - eps) w J(z) + sum of hinges   <=>   min (1 - eps) J(z) + sum of hinges of slope beta / w      (scale_probs_cost!, main.jl:96-112)
+      // and slew penalties go through the increment form of the QP path (state [x; u], control increments: the control boxes — and with
+      // them their hinges — become state boxes; one particle, so no shared control is counted twice).
+      double wgt = 1.0;
+      if (p->weights) {
+        HIP_CHECK(hipMemcpyAsync(&wgt, p->weights, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+      }
+      if (wgt > 0.0) {
+        pmpc_problem p1 = *p;
+        p1.weights = nullptr;
+        // (the cone program takes each particle's cost from qp_repr_Pq, cone_utils.jl:64-95, which keeps the first-step slew term
+        //  slew_reg0 |u_0 - u_{-1}|^2 whatever Nc is — the joint QP assembly loses it at Nc = 0, lqp_utils.jl:165; with ONE particle a
+        //  consensus horizon of one stage is the same problem and carries the term)
+        if (p1.Nc == 0) p1.Nc = 1;
+        if (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0)) {
+          LQArgs t;
+          memset(&t, 0, sizeof(t));
+          t.x = (int)(p->xdim + p->udim); t.u = (int)p->udim; t.N = (int)p->N; t.M = 1; t.sym_cost = 1;
+          if (p->N >= 2 && (p->flags & PMPC_SYMMETRIC_COST) && !(p->flags & PMPC_FORCE_GENERIC) && lq_fast_supported(t)) {
+            pmpc_problem qa;
+            SlewAug g;
+            build_slew_increment_problem(c, &p1, qa, g);
+            qa.weights = nullptr;
+            st_s = lcone_smooth_body(c, &qa, q.barrier_mu, info, verbose, 1, sbeta / wgt);
+            const int Nc1 = p->Nc < 0 ? (int)p->N : (int)p->Nc;
+            if (st_s == 0) launch_slew_split(w.sa_Xo.d(), w.sa_Uo.d(), p->X_out, p->U_out, (long long)p->N, (int)p->xdim, (int)p->udim, (int)p->N, 0, g.cons_lo, g.cons_hi, s);
+            else if (st_s > 0) fill_nan_outputs(c, p);
+            (void)Nc1;
+          }
+        } else {
+          st_s = lcone_smooth_body(c, &p1, q.barrier_mu, info, verbose, 1, sbeta / wgt);
+        }
+      }
+    } else {
+      st_s = lcone_smooth_body(c, p, q.barrier_mu, info, verbose, 1, sbeta);
+    }
     if (st_s >= 0) return st_s;
-    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs M > 1 particles on one rank, boxes to smooth, M (Nc u)^2 <= 2e7, no slew penalties / particle weights / fp32 storage and a compiled (xdim, udim) pair\n");
+    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs one rank, boxes to smooth, M (Nc u)^2 <= 2e7, no fp32 storage, a compiled (xdim, udim) pair and — with slew penalties or particle weights — M = 1 (slew: symmetric costs, N >= 2, a compiled (xdim + udim, udim) pair)\n");
     fill_nan_outputs(c, p);
     if (info) { memset(info, 0, sizeof(*info)); info->status = 2; }
     return 2;

@@ -334,3 +334,29 @@ def aux_state_problem(rows, x0, f, fx, fu, X_prev, U_prev, Q, X_ref, reg_x, x_l,
                 FU[i, t, c] = a_u
             hi[i, t, c] = h
     return dict(x0=X0, f=F, fx=FX, fu=FU, X_prev=XP, Q=QQ, X_ref=XR, x_l=lo, x_u=hi, m=m)
+
+
+def split_linear_cost(cstr: Sequence[Any], M: int, N: int, xdim: int, udim: int, Nc: int):
+    """`c_left` of a tuple (PMPC.jl/src/cone_utils.jl:152-154: added to the cost vector of the cone program, OUTSIDE the epigraph rows) as
+    per-stage arrays `cu (M, N, udim)`, `cx (M, N, xdim)` over z = [U_cons; U_free; X] (a shared control's entry lands in particle 0's
+    block), plus the tuple with `c_left` zeroed.  Returns `(None, None, cstr)` when there is no cost term.  Entries beyond the trajectory
+    variables (the y / t columns of the cone program) are refused."""
+    l, q, e, G_left, G_right, h, c_left, c_right = cstr
+    cl = np.zeros(0) if c_left is None else np.asarray(c_left, dtype=np.float64).reshape(-1)
+    if cl.size == 0 or not np.any(cl != 0.0):
+        return None, None, cstr
+    Ncc = N if Nc < 0 else min(int(Nc), N)
+    Nf = N - Ncc
+    ncu = Ncc * udim + M * Nf * udim
+    n = ncu + M * N * xdim
+    if cl.size > n and np.any(cl[n:] != 0.0):
+        raise ValueError("c_left on the epigraph variables (y, t) of the cone program is not supported")
+    full = np.zeros(n)
+    full[:min(cl.size, n)] = cl[:n]
+    cu = np.zeros((M, N, udim))
+    cu[0, :Ncc] = full[:Ncc * udim].reshape(Ncc, udim)
+    if Nf:
+        cu[:, Ncc:] = full[Ncc * udim:ncu].reshape(M, Nf, udim)
+    cx = full[ncu:].reshape(M, N, xdim)
+    return cu, cx, (l, q, e, G_left, G_right, h, np.zeros(cl.size), c_right)
+

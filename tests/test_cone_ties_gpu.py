@@ -246,3 +246,41 @@ def test_worst_k_with_several_costs_on_the_threshold(case):
     Ncc = U.shape[1] if Nc < 0 else Nc
     assert abs(obj(Jg) - obj(Jo)) <= 1e-9 * abs(obj(Jo))
     assert _rel(U[:, :Ncc], Uo[:, :Ncc]) <= TOL and _rel(X[top], Xo[top]) <= TOL and _rel(U[top], Uo[top]) <= TOL
+
+
+@pytest.mark.parametrize("Nc,slew,slew0", [(1, None, None), (-1, None, None), (0, None, None), (1, 0.5, None), (-1, 0.3, 0.4), (0, 0.7, 0.2), (2, 0.7, 0.2)])
+def test_squareplus_with_one_particle_and_slew_matches_the_direct_program(co, Nc, slew, slew0):
+    """M = 1 is the shape of nearly every reference example, and `lcone_solve` takes the squareplus branch for any M, with slew penalties
+    (main.jl:265-279).  One particle: the epigraph row is degenerate and the solve is damped Newton on (1 - eps) J + the hinges; slew
+    penalties through the increment form (control boxes and their hinges become boxes on the u-part of the state)."""
+    from pmpc_amd import backend
+
+    args, kw = rand_problem(np.random.default_rng(70 + abs(Nc) + (3 if slew else 0)), 1, 6, 4, 2, 0.4, None, slew, slew0)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, smooth_alpha=10.0, smooth_cstr="squareplus", smooth_beta=2.0, **kw)
+    X, U = backend.lcone_solve(*abi_args(args, kw, Nc), smooth_alpha=10.0, solver="ecos", smooth_cstr="squareplus", smooth_beta=2.0)
+    assert np.all(np.isfinite(X)) and np.all(np.isfinite(U))
+    assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (_rel(X, Xo), _rel(U, Uo))
+
+
+@pytest.mark.parametrize("wgt,slew", [(2.5, None), (0.3, 0.5)])
+def test_squareplus_with_one_weighted_particle(co, wgt, slew):
+    """`weights` (scale_probs_cost!, main.jl:96-112) scale the particle's cost, not the hinges: (1 - eps) w J + hinges."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    args, kw = rand_problem(np.random.default_rng(85), 1, 6, 4, 2, 0.4, None, slew, None)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    Xo, Uo = co.lcone_direct_py(x0, f, fx, fu, X_prev, U_prev, wgt * Q, wgt * R, X_ref, U_ref, Nc=1, smooth_alpha=10.0, smooth_cstr="squareplus", smooth_beta=2.0,
+                                **{k: (wgt * v if k in ("reg_x", "reg_u", "slew_reg") else v) for k, v in kw.items()})
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    s = DeviceSolver(0)
+    skw = dict(slew_reg=dev(kw["slew_reg"])) if slew is not None else {}
+    X, U, st = s.lcone_solve(smooth_alpha=10.0, smooth_cstr="squareplus", smooth_beta=2.0, f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q),
+                             R=T(R), X_ref=dev(X_ref), U_ref=dev(U_ref), reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=1, x0=dev(x0), lu=dev(kw["u_l"]), uu=dev(kw["u_u"]),
+                             symmetric_cost=True, weights=dev(np.array([wgt])), **skw)
+    s.sync()
+    assert st == 0
+    assert _rel(X.cpu().numpy(), Xo) <= TOL and _rel(U.cpu().numpy(), Uo) <= TOL
+    s.close()

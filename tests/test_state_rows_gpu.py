@@ -177,3 +177,47 @@ def test_host_loop_avoids_an_obstacle_through_extra_cstrs_fns(solver):
     assert dist > rad - 1e-6, dist                    # the constrained ones do not (a half-space lies outside the disc)
     assert dist < rad + 1e-3                          # and they graze it
     assert np.all(U[:, 0] == U[0:1, 0])               # the shared control is shared
+
+
+@pytest.mark.parametrize("smooth", [None, ("logbarrier", 8.0), ("squareplus", 8.0)])
+def test_linear_cost_term_c_left_with_one_particle(smooth, oracle):
+    """`c_left` (cone_utils.jl:152-154) is added to the cone program's cost vector outside the epigraph rows.  One particle: the program
+    is min (1 - eps) J + c'z (+ smoothing) — the references shifted by Q^-1 c / (1 - eps), as the reference itself folds linear cost
+    terms (pmpc/scp_mpc.py:171-185).  A tuple may carry the cost alone (no rows)."""
+    from oracle import cone_oracle as co
+
+    N, x, u, Nc = 6, 4, 2, 1
+    rng = np.random.default_rng(9500)
+    args, kw = rand_problem(rng, 1, N, x, u, 0.8)
+    n = N * u + N * x
+    c = 0.5 * rng.standard_normal(n)
+    tup = (0, [], 0, sp.csr_matrix((0, n)), sp.csr_matrix((0, 0)), np.zeros(0), c, np.zeros(0))
+    skw = {} if smooth is None else dict(smooth_cstr=smooth[0], smooth_alpha=smooth[1])
+    Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, extra_cstrs=[tup], **skw, **kw)
+    X0, U0 = co.lcone_direct_py(*args, Nc=Nc, **skw, **kw)
+    assert _rel(Xo, X0) > 1e-3  # the term moves the answer
+    X, U = solve_host(args, kw, Nc, [tup], solver="ecos", **skw)
+    assert _rel(X, Xo) < 1e-6 and _rel(U, Uo) < 1e-6, (_rel(X, Xo), _rel(U, Uo))
+
+
+def test_cost_terms_and_cones_outside_the_supported_cases_are_refused_with_the_reason(oracle):
+    from oracle import cone_oracle as co
+    from pmpc_amd import backend
+
+    M, N, x, u, Nc = 2, 4, 3, 2, 1
+    rng = np.random.default_rng(9600)
+    args, kw = rand_problem(rng, M, N, x, u, 1.0)
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    ncu = Nc * u + M * (N - Nc) * u
+    n = ncu + M * N * x
+    call = lambda tup, **st: backend.aff_solve(f, fx, fu, x0, X_prev, U_prev, Q, R, X_ref, U_ref, 1.0, 0.1, None, None, None, None, kw["u_l"], kw["u_u"],
+                                               solver_settings=dict(Nc=Nc, extra_cstrs=[tup], solver="ecos", **st))
+    cost = (0, [], 0, sp.csr_matrix((0, n)), sp.csr_matrix((0, 0)), np.zeros(0), np.ones(n), np.zeros(0))
+    with pytest.raises(ValueError, match="one particle"):
+        call(cost)
+    row = np.zeros((1, n)); row[0, 0] = 1.0
+    Gl, Gr, hh = co.smoothen_linear_inequalities_py(sp.csr_matrix(row), np.ones(1), 5.0)
+    etup = (0, [], 1, Gl, Gr, hh, np.zeros(n), np.ones(1))
+    for st in ({}, dict(smooth_alpha=5.0), dict(smooth_alpha=5.0, smooth_cstr="squareplus")):
+        with pytest.raises(ValueError, match="exponential cones are not supported"):
+            call(etup, **st)
