@@ -30,7 +30,7 @@ def _rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
 
 
-def _scp_loop_vs_cpu(solver, prob, model, Nc, steps, cpu_solve, tol=1e-7):
+def _scp_loop_vs_cpu(solver, prob, model, Nc, steps, cpu_solve, tol=1e-7, kkt=False):
     """bench.py's calling pattern: on-device linearisation, device solve with the SCP-loop promises (same boxes,
     X_prev / U_prev = previous outputs), ping-pong buffers.  Every sub-problem is also solved on the CPU from the SAME
     linearisation (downloaded) and compared."""
@@ -56,6 +56,15 @@ def _scp_loop_vs_cpu(solver, prob, model, Nc, steps, cpu_solve, tol=1e-7):
         print(f"  SCP iteration {it + 1}: rel err X {ex:.1e} U {eu:.1e}, rounds {rounds[-1]}", flush=True)
         worst = max(worst, ex, eu)
         assert ex < tol and eu < tol, (it, ex, eu, solver.last_info)
+        if kkt:  # evidence that does not pass through either solver's algorithm: the joint QP's KKT conditions at the returned point
+            from tests.support.kkt_certificate import kkt_certificate
+
+            cert = kkt_certificate(prob["x0"], f.cpu().numpy(), fx.cpu().numpy().swapaxes(-1, -2), fu.cpu().numpy().swapaxes(-1, -2), Xa.cpu().numpy(),
+                                   Ua.cpu().numpy(), prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], prob["reg_x"], prob["reg_u"], Nc, prob["u_l"],
+                                   prob["u_u"], Xb.cpu().numpy(), Ub.cpu().numpy())
+            print(f"    KKT certificate: {cert}", flush=True)
+            assert cert["active_bounds"] > 0
+            assert max(cert["dynamics"], cert["consensus"], cert["box"], cert["stationarity"], cert["stationarity_shared"]) < 1e-9, cert
         Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
     return worst, rounds
 
@@ -83,7 +92,7 @@ def test_config_B_unicycle_scp_loop_matches_cpu(solver, oracle, M, Nc, cpu_kind)
         assert info["status"] == 0, info
         return X, U
 
-    worst, rounds = _scp_loop_vs_cpu(solver, prob, MODEL_UNICYCLE, Nc, 5, cpu)
+    worst, rounds = _scp_loop_vs_cpu(solver, prob, MODEL_UNICYCLE, Nc, 5, cpu, kkt=True)
     assert rounds[-1] >= 1  # the later sub-problems went through the warm-started active-set rounds
     print(f"config B M={M} Nc={Nc}: worst rel err {worst:.2e}, active-set rounds {rounds}")
 
@@ -106,7 +115,7 @@ def test_configs_C_D_full_size_scp_loop_matches_structured_cpu(solver, oracle, M
         assert info["status"] == 0, info
         return X, U
 
-    worst, rounds = _scp_loop_vs_cpu(solver, prob, MODEL_QUADROTOR, 1, 4, cpu)
+    worst, rounds = _scp_loop_vs_cpu(solver, prob, MODEL_QUADROTOR, 1, 4, cpu, kkt=True)
     print(f"config {'C' if M == 1024 else 'D'} M={M}: worst rel err {worst:.2e}, active-set rounds {rounds}")
 
 
@@ -213,6 +222,17 @@ def test_config_E_size_M4096_N100_thrust_cones_properties(solver):
     assert np.all(U >= prob["u_l"] - 1e-9) and np.all(U <= prob["u_u"] + 1e-9)
     Xr = _rollout_np(prob, f, fx, fu, U)
     assert np.max(np.abs(Xr - X)) < 1e-8 * max(1.0, np.max(np.abs(X)))
+    # the KKT conditions of the joint cone program at the returned point, from the ABI data alone (tests/support/kkt_certificate.py): no
+    # solver's algorithm in between — costates by the adjoint recursion, box multipliers by their signs, one fitted multiplier per active cone
+    from tests.support.kkt_certificate import kkt_certificate
+
+    cert = kkt_certificate(prob["x0"], f.cpu().numpy(), fx.cpu().numpy().swapaxes(-1, -2), fu.cpu().numpy().swapaxes(-1, -2), prob["X_prev"], prob["U_prev"],
+                           prob["Q"], prob["R"], prob["X_ref"], prob["U_ref"], prob["reg_x"], prob["reg_u"], 1, prob["u_l"], prob["u_u"], X, U,
+                           soc=dict(W=np.array([[0, 1.0, 0, 0], [0, 0, 1.0, 0]]), w0=np.zeros(2), v=np.array([0.3, 0, 0, 0]), v0=0.0), tol_act=1e-8)
+    print(f"config E size: KKT certificate {cert}", flush=True)
+    assert cert["cone_active"] > 400
+    # (the cones' Newton iteration stops at steps of 1e-6 relative, kernels_cone.hip tol_step: its stationarity residual is what that leaves)
+    assert max(cert["dynamics"], cert["consensus"], cert["box"], cert["cone"]) < 1e-9 and max(cert["stationarity"], cert["stationarity_shared"]) < 1e-8, cert
     J0 = _objective(prob, Xr, U)
     rng = np.random.default_rng(11)
     for scale in (1e-2, 1e-4):
