@@ -38,6 +38,26 @@ def riccati_flops_per_unit(x, u):
     return 4 * x ** 3 + 6 * x * x * u + 4 * x * u * u + u ** 3 / 3.0
 
 
+def pmc_sq_evidence(kernel_prefix):
+    """{counter: share of SQ_WAVE_CYCLES} of one kernel from the committed counter summary (tools/debug/pmc_sq_summary.py output), or None."""
+    f = ROOT / "profiles" / "r05_pmc_sq_D.txt"
+    if not f.exists():
+        return None
+    lines = f.read_text().splitlines()
+    for k, ln in enumerate(lines):
+        if kernel_prefix in ln:
+            for nxt in lines[k + 1:k + 4]:
+                if "of wave cycles:" in nxt:
+                    out = {}
+                    for part in nxt.split("of wave cycles:")[1].split("  "):
+                        part = part.strip()
+                        if part:
+                            name, val = part.rsplit(" ", 1)
+                            out[name] = float(val.rstrip("%")) / 100.0
+                    return out
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,14 +439,20 @@ def main():
                  "frac": ach_tf / FP64_PEAK_TFLOPS,
                  "note": "useful flops of the matrix Riccati recursion (SURVEY.md section 8d) / launch time; the 16x16x4 fp64 MFMA tiles are "
                          "padded 12 -> 16 rows, so the matrix pipe is busier than this figure by (16/12)^2 on the G and H products"}
-        limiter = {"name": "vector-instruction issue of one wave per particle walking N dependent stages",
-                   "evidence": ["fp32-storage A/B (bench.py --fp32): the launch moves 42 % fewer bytes (688 -> 400 MB) and runs 3.5 % faster "
-                                "(profiles/r03_f_bench_D_fp32.json): not bandwidth",
-                                "7 fp64 MFMAs of 64 cycles per stage = 448 of the ~2200 cycles a wave spends per stage at 4 waves per SIMD: not the matrix pipe",
-                                "ISA of k_bwd_as<12,4,1,false,true,0,double>: 375 instructions per stage in the main loop, ~300 of them VALU "
-                                "(moves, DPP / lane exchanges, selects and the lane-uniform 4x4 Cholesky + substitution); 4 waves x 375 x >= 4 cycles "
-                                "per SIMD and stage is 80 % of the measured stage period",
-                                "s_memtime stage timeline of the same kernel at 0.5 and 4 waves per SIMD: profiles/r04_stage_timeline.txt"],
+        # what bounds the dominant kernel: SQ counters of the profiled run (profiles/r05_pmc_sq_D.txt, tools/debug/pmc_sq.sh: three --pmc
+        # passes at config D) are READ here, not restated; what this run measures itself is attached next to them
+        sq = pmc_sq_evidence("k_bwd_as<12, 4, 1, false, true, 0, double>")
+        sq_fwd = pmc_sq_evidence("k_fwd_as<12, 4, false, true, false, double>")
+        rst = solver.restart_stats(reset=False)
+        limiter = {"name": "vector-instruction issue: four waves per SIMD keep its issue port busy (fp64 VALU and 64-bit lane moves at a quarter of the fp32 rate)",
+                   "evidence": {"profile": "profiles/r05_pmc_sq_D.txt (rocprofv3 --pmc, SQ_WAVE_CYCLES / SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_* per kernel, config D)",
+                                "factor_sweep_share_of_wave_cycles": sq, "forward_sweep_share_of_wave_cycles": sq_fwd,
+                                "reading": "parked at a memory wait for under a quarter of a wave's life, stalled at issue for over half; executing x 4 waves per SIMD ~ the whole "
+                                           "issue port: neither HBM latency nor bytes in flight bound the sweeps at this size, instructions per stage and swept stages do",
+                                "this_run": {"factor_sweep_avg_launch_ms": 1e3 * avg_s, "bytes_frac_of_peak": achieved / HBM_PEAK_GBS, "flops_frac_of_peak": ach_tf / FP64_PEAK_TFLOPS,
+                                             "later_rounds_factor_sweeps": rst,
+                                             "note": "later_rounds_factor_sweeps: sweeps of unsettled particles since the context was created — those restarted from a "
+                                                     "checkpoint and the stages they ran (of N per full sweep), those from the terminal cost"}},
                    "bytes_frac_of_peak": achieved / HBM_PEAK_GBS, "flops_frac_of_peak": ach_tf / FP64_PEAK_TFLOPS}
         # ---- Nc > 1 (the reference's default is Nc = N): the consensus launch class (condensing kernel + particle reduction + dense
         #      solve) is a roofline object of its own.  SURVEY.md section 8(d) expected it MFMA-bound; measured it is HBM-bound on the

@@ -20,13 +20,19 @@ __global__ void __launch_bounds__(256) k_xbox_step(XboxArgs a) {
   const int i = blockIdx.x, t = threadIdx.x, xd = a.x, n = a.N * xd;
   __shared__ double redd[256];
   __shared__ int redi[2][256];
-  // penalty of this particle: the largest diagonal cost entry of its horizon sets the scale
-  double m = 0.0;
-  for (int k = t; k < n; k += 256) m = fmax(m, fabs(a.Q[((size_t)i * n + k) * xd + (k % xd)]));
-  redd[t] = m;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if (t < w) redd[t] = fmax(redd[t], redd[t + w]);
+  // penalty of this particle: the largest diagonal cost entry of its horizon sets the scale (found by the prepare call of the attempt)
+  if (!a.finish || !a.qmax) {
+    double m = 0.0;
+    for (int k = t; k < n; k += 256) m = fmax(m, fabs(a.Q[((size_t)i * n + k) * xd + (k % xd)]));
+    redd[t] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) redd[t] = fmax(redd[t], redd[t + w]);
+      __syncthreads();
+    }
+    if (t == 0 && a.qmax) a.qmax[i] = redd[0];
+  } else {
+    if (t == 0) redd[0] = a.qmax[i];
     __syncthreads();
   }
   const double pw = a.pw ? a.pw[i] : 1.0;

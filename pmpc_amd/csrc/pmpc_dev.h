@@ -299,6 +299,8 @@ struct XboxArgs {
   const double *lo, *hi;     // (M,N,x)
   const double *Q, *pw;      // cost blocks and particle weights (or null): penalty rho_i = rho_scale pw_i (max_j,r |Q_ijrr| + reg_x)
   double reg_x, rho_scale;
+  double *qmax;              // per particle: max_j,r |Q_ijrr|, written by the prepare call (finish = 0) and read by the finish calls of the attempt —
+                             // the strided pass over the cost diagonals touches every line of Q (236 MB at config D), once per attempt instead of per round
   double *z;                 // multipliers (M,N,x), >= 0, of the side named by st
   int *st;                   // 0 free, 1 lower side held, 2 upper side held
   double *D, *g;             // outputs (M,N,x)

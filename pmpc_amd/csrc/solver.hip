@@ -154,6 +154,7 @@ struct Workspace {
   long long soc_key = -1;
   DevBuf Hadd, wu_soc;  // stage-cone extension: control Hessian blocks A'W^-2 A, gradient shift (path following) / Newton terms of the cones (active-set rounds)
   DevBuf cone_A, cone_c, cone_z, cone_rec, cone_uraw, as_open;  // stage cones inside the active-set rounds (kernels_cone.hip)
+  DevBuf xb_qmax;  // per particle: largest diagonal cost entry (penalty scale of the state rows), found once per attempt
   DevBuf xb_z, xb_st, xb_D, xb_g;  // state boxes inside the active-set rounds (kernels_xbox.hip)
   DevBuf m64[4];  // fp32-storage mode: fx, fu, Q, R widened for the paths that run the fp64 kernels
   // warm start: the early interior-point iterate (mu <= 0.5) remembered from the previous solve of the same shape
@@ -545,7 +546,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol, &w.as_ck, &w.as_jhi, &w.ck_stat, &w.Hc_grp, &w.as_T,
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol, &w.as_ck, &w.as_jhi, &w.ck_stat, &w.Hc_grp, &w.as_T, &w.xb_qmax,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
                    &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.xb_z, &w.xb_st, &w.xb_D, &w.xb_g, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
   for (DevBuf *b : all) b->release();
@@ -1421,6 +1422,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       }
       b.xb_D = w.xb_D.d(); b.xb_g = w.xb_g.d(); b.as_open = (int *)w.as_open.p;  // (the merged exchange of a sharded run carries the open rows: tail[4])
       xa.M = M; xa.N = N; xa.x = x; xa.lo = p->lx; xa.hi = p->ux; xa.Q = p->Q; xa.pw = p->weights; xa.reg_x = p->reg_x; xa.rho_scale = 1e7;  // (measured, bench.py --vmax: 1e5 .. 1e2 only add rounds)
+      w.xb_qmax.ensure((size_t)M * D8);
+      xa.qmax = w.xb_qmax.d();
       xa.z = w.xb_z.d(); xa.st = (int *)w.xb_st.p; xa.D = w.xb_D.d(); xa.g = w.xb_g.d();
       xa.cnt = (int *)w.as_cntp.p; xa.settled = (int *)w.as_settled.p; xa.open = (int *)w.as_open.p; xa.done = &ctl->done; xa.ctl = ctl;
       xa.jhi = b.as_jhi;
