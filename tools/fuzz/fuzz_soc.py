@@ -9,7 +9,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
 T = lambda a: dev(np.swapaxes(a, -1, -2))
 s = DeviceSolver(0)
-worst, fails = 0.0, 0
+worst, fails, worst_case = 0.0, 0, None
 for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 50):
     x, u = [(12, 4), (4, 2), (3, 3), (5, 3), (6, 2), (8, 4), (7, 3)][rng.integers(7)]
     M, N = int(rng.integers(1, 7)), int(rng.integers(1, 9))
@@ -39,5 +39,15 @@ for k in range(int(sys.argv[2]) if len(sys.argv) > 2 else 50):
     if not err < 1e-6:
         fails += 1
         print("FAIL", (M, N, x, u, Nc, bu, q), status, err, s.last_info["ipm_iters"])
+    if err > worst and np.isfinite(err):
+        worst_case = ((M, N, x, u, Nc, bu, q), k)
     worst = max(worst, err)
-print(f"{fails} failures, worst rel err {worst:.2e}")
+    if "--kkt" in sys.argv and status == 0 and err > 1e-9:
+        # which side is off?  The joint program's KKT conditions at BOTH points, from the data alone (tests/support/kkt_certificate.py)
+        from tests.support.kkt_certificate import kkt_certificate
+        lo, hi = (kw["u_l"], kw["u_u"]) if bu is not None else (np.full(U.shape, -np.inf), np.full(U.shape, np.inf))
+        cs = [kkt_certificate(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, kw["reg_x"], kw["reg_u"], Nc, lo, hi, Xc, Uc, soc=dict(W=W, w0=w0, v=v, v0=v0), tol_act=1e-7)
+              for Xc, Uc in ((X, U), (Xo, Uo))]
+        print(f"case {k} {(M, N, x, u, Nc, bu, q)} err {err:.1e}: stationarity device {max(cs[0]['stationarity'], cs[0]['stationarity_shared']):.1e} oracle "
+              f"{max(cs[1]['stationarity'], cs[1]['stationarity_shared']):.1e}; cone residual device {cs[0]['cone']:.1e} oracle {cs[1]['cone']:.1e}", flush=True)
+print(f"{fails} failures, worst rel err {worst:.2e}" + (f" (case {worst_case[1]}: {worst_case[0]})" if worst > 0 else ""))
