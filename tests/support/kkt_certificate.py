@@ -88,3 +88,122 @@ def kkt_certificate(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, re
     res["stationarity"] = float(viol.max()) / gscale
     res["active_bounds"] = int((at_lo | at_hi).sum())
     return res
+
+
+def smoothed_cone_certificate(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc, u_l, u_u, X, U, alpha, k=None, eps=1e-3):
+    """Optimality certificate of a returned (X, U) for the reference's DEFAULT objective with log-barrier smoothing of the control boxes
+    (PMPC.jl/src/main.jl:204-262):   min (1 + eps) sum y_i + (1 - eps) k t - (1 / alpha) sum log(alpha slack)   s.t.  J_i(z_i) <= y_i + t,  y >= 0,
+    the dynamics and the consensus of the first Nc controls — from the ABI data alone, no solver in between.
+    The epigraph multipliers are not returned by any ABI; they are DETERMINED by the point: particle i's own (non-shared) controls are stationary
+    iff  lam_i r_J + r_B = 0  with r_J the reduced gradient of J_i (adjoint recursion) and r_B the barrier's gradient — lam_i is the least-squares
+    fit, its residual the first check.  Then: lam_i in [0, 1 + eps], sum lam = (1 - eps) k, lam_i = 1 + eps above the threshold cost, 0 below it
+    (the threshold = the cost of the particles with a fractional multiplier), and stationarity of the SHARED controls under the summed gradient.
+    Returns a dict of residuals (relative) and the multipliers."""
+    M, N, x = f.shape
+    u = fu.shape[-1]
+    Ncc = N if Nc < 0 else int(Nc)
+    k = M if k is None or k < 0 else k
+    cap, K = 1.0 + eps, (1.0 - eps) * k
+    dXm = np.concatenate([np.zeros((M, 1, x)), X[:, :-1] - X_prev[:, :-1]], 1)
+    pred = f + np.einsum("mnrt,mnt->mnr", fx, dXm) + np.einsum("mnrt,mnt->mnr", fu, U - U_prev)
+    res = dict(dynamics=np.abs(X - pred).max() / max(1.0, np.abs(X).max()), consensus=(np.abs(U[:, :Ncc] - U[:1, :Ncc]).max() if Ncc else 0.0))
+    eX, eU, pX, pU = X - X_ref, U - U_ref, X - X_prev, U - U_prev
+    gx = np.einsum("mnrt,mnt->mnr", Q, eX) + reg_x * pX
+    gu = np.einsum("mnrt,mnt->mnr", R, eU) + reg_u * pU
+    J = 0.5 * (np.einsum("mnr,mnr->m", eX, np.einsum("mnrt,mnt->mnr", Q, eX)) + np.einsum("mnr,mnr->m", eU, np.einsum("mnrt,mnt->mnr", R, eU))
+               + reg_x * np.einsum("mnr,mnr->m", pX, pX) + reg_u * np.einsum("mnr,mnr->m", pU, pU))
+    nu = np.empty_like(X)
+    nu[:, N - 1] = gx[:, N - 1]
+    for j in range(N - 2, -1, -1):
+        nu[:, j] = gx[:, j] + np.einsum("mtr,mt->mr", fx[:, j + 1], nu[:, j + 1])
+    rJ = gu + np.einsum("mnrt,mnr->mnt", fu, nu)
+    lo, hi = np.broadcast_to(u_l, U.shape), np.broadcast_to(u_u, U.shape)
+    sl, sh = U - lo, hi - U
+    res["slack"] = float(min(sl.min(), sh.min()))
+    rB = (-1.0 / sl + 1.0 / sh) / alpha
+    own = slice(Ncc, N)
+    num = -np.einsum("mnr,mnr->m", rJ[:, own], rB[:, own])
+    den = np.einsum("mnr,mnr->m", rJ[:, own], rJ[:, own])
+    lam = num / np.where(den > 0.0, den, 1.0)
+    scale = np.maximum(1.0, np.abs(rB[:, own]).reshape(M, -1).max(1))
+    res["own_controls"] = float((np.abs(lam[:, None, None] * rJ[:, own] + rB[:, own]).reshape(M, -1).max(1) / scale).max())
+    res["lam_range"] = float(max(0.0, -lam.min(), lam.max() - cap))
+    res["lam_sum"] = abs(float(lam.sum()) - K) / max(1.0, K)
+    frac = (lam > 1e-6 * cap) & (lam < cap * (1 - 1e-6))
+    jscale = max(1.0, np.abs(J).max())
+    if frac.any():
+        t = float(J[frac].mean())
+        res["threshold_spread"] = float(np.abs(J[frac] - t).max()) / jscale
+    else:
+        t = 0.5 * (J[lam <= 1e-6 * cap].max(initial=-np.inf) + J[lam >= cap * (1 - 1e-6)].min(initial=np.inf))
+        res["threshold_spread"] = 0.0
+    res["complementarity"] = float(max(0.0, (J[lam <= 1e-6 * cap] - t).max(initial=0.0), (t - J[lam >= cap * (1 - 1e-6)]).max(initial=0.0))) / jscale
+    if Ncc:
+        rs = np.einsum("m,mnr->nr", lam, rJ[:, :Ncc]) + rB[0, :Ncc]  # the shared controls' box rows are particle 0's, once (lqp_utils.jl:329-330)
+        res["shared_controls"] = float(np.abs(rs).max() / max(1.0, np.abs(rB[0, :Ncc]).max(), np.abs(lam[:, None, None] * rJ[:, :Ncc]).sum(0).max()))
+    res["fractional_multipliers"] = int(frac.sum())
+    res["_lam"], res["_t"], res["_J"] = lam, t, J
+    return res
+
+
+def hard_cone_certificate(x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref, reg_x, reg_u, Nc, u_l, u_u, X, U, k=None, eps=1e-3, tol_act=1e-9, tie_tol=1e-8):
+    """The same for HARD control boxes (main.jl:204-238 without smoothing).  Here a particle's own stationarity does not name its multiplier
+    (lam_i r_J = 0 holds for any lam_i once r_J = 0), so the checks are: (1) every particle is at its conditional optimum given the shared
+    controls — reduced gradient of J_i zero inside the box, of the right sign on a bound; (2) multipliers exist: lam_i = 1 + eps strictly above
+    the threshold cost, 0 strictly below, in [0, 1 + eps] on it, summing to (1 - eps) k, with the shared controls stationary under
+    sum lam_i r_J (bounded least squares over the costs on the threshold)."""
+    from scipy.optimize import lsq_linear
+
+    M, N, x = f.shape
+    u = fu.shape[-1]
+    Ncc = N if Nc < 0 else int(Nc)
+    k = M if k is None or k < 0 else k
+    cap, K = 1.0 + eps, (1.0 - eps) * k
+    dXm = np.concatenate([np.zeros((M, 1, x)), X[:, :-1] - X_prev[:, :-1]], 1)
+    pred = f + np.einsum("mnrt,mnt->mnr", fx, dXm) + np.einsum("mnrt,mnt->mnr", fu, U - U_prev)
+    res = dict(dynamics=np.abs(X - pred).max() / max(1.0, np.abs(X).max()), consensus=(np.abs(U[:, :Ncc] - U[:1, :Ncc]).max() if Ncc else 0.0))
+    eX, eU, pX, pU = X - X_ref, U - U_ref, X - X_prev, U - U_prev
+    gx = np.einsum("mnrt,mnt->mnr", Q, eX) + reg_x * pX
+    gu = np.einsum("mnrt,mnt->mnr", R, eU) + reg_u * pU
+    J = 0.5 * (np.einsum("mnr,mnr->m", eX, np.einsum("mnrt,mnt->mnr", Q, eX)) + np.einsum("mnr,mnr->m", eU, np.einsum("mnrt,mnt->mnr", R, eU))
+               + reg_x * np.einsum("mnr,mnr->m", pX, pX) + reg_u * np.einsum("mnr,mnr->m", pU, pU))
+    nu = np.empty_like(X)
+    nu[:, N - 1] = gx[:, N - 1]
+    for j in range(N - 2, -1, -1):
+        nu[:, j] = gx[:, j] + np.einsum("mtr,mt->mr", fx[:, j + 1], nu[:, j + 1])
+    rJ = gu + np.einsum("mnrt,mnr->mnt", fu, nu)
+    lo, hi = np.broadcast_to(u_l, U.shape).copy(), np.broadcast_to(u_u, U.shape).copy()
+    lo[:, :Ncc], hi[:, :Ncc] = lo[:1, :Ncc], hi[:1, :Ncc]
+    scale_u = np.maximum(1.0, np.maximum(np.abs(lo), np.abs(hi)))
+    res["box"] = max(0.0, float(((lo - U) / scale_u).max()), float(((U - hi) / scale_u).max()))
+    at_lo, at_hi = U <= lo + tol_act * scale_u, U >= hi - tol_act * scale_u
+    gscale = max(1.0, np.abs(gu).max(), np.abs(nu).max())
+    own = slice(Ncc, N)
+    v = np.where(at_lo & at_hi, 0.0, np.where(at_lo, np.maximum(-rJ, 0.0), np.where(at_hi, np.maximum(rJ, 0.0), np.abs(rJ))))
+    res["own_controls"] = float(v[:, own].max()) / gscale
+    # multipliers: fixed off the threshold, fitted on it
+    order = np.argsort(-J)
+    n_hi = int(np.floor(K / cap + 1e-12))
+    t = float(J[order[min(n_hi, M - 1)]])  # the cost that carries the remainder
+    jscale = max(1.0, np.abs(J).max())
+    above, below = J > t + tie_tol * jscale, J < t - tie_tol * jscale
+    tied = ~(above | below)
+    lam = np.where(above, cap, 0.0)
+    rem = K - cap * above.sum()
+    res["tied"] = int(tied.sum())
+    res["remainder_feasible"] = float(max(0.0, -rem, rem - cap * tied.sum())) / max(1.0, K)
+    if Ncc:
+        rc = rJ[:, :Ncc].reshape(M, -1)  # (M, Ncc u)
+        fixed = lam @ rc
+        free_c = ~(at_lo[0, :Ncc] | at_hi[0, :Ncc]).reshape(-1)
+        wsum = 1e3 * max(1.0, np.abs(rc).max())
+        A = np.vstack([rc[tied][:, free_c].T, wsum * np.ones((1, tied.sum()))])
+        b = np.concatenate([-fixed[free_c], [wsum * rem]])
+        sol = lsq_linear(A, b, bounds=(0.0, cap), tol=1e-14, max_iter=200)
+        lam[tied] = sol.x
+        rs = lam @ rc
+        vs = np.where((at_lo[0, :Ncc] & at_hi[0, :Ncc]).reshape(-1), 0.0, np.where(at_lo[0, :Ncc].reshape(-1), np.maximum(-rs, 0.0), np.where(at_hi[0, :Ncc].reshape(-1), np.maximum(rs, 0.0), np.abs(rs))))
+        res["shared_controls"] = float(vs.max()) / (gscale * max(1.0, K))
+    res["lam_sum"] = abs(float(lam.sum()) - K) / max(1.0, K)
+    res["_lam"], res["_t"], res["_J"] = lam, t, J
+    return res

@@ -330,3 +330,70 @@ def test_consensus_horizon_beyond_N_is_refused_like_the_reference():
     assert np.all(np.isnan(X)) and np.all(np.isnan(U))
     with pytest.raises(ValueError):
         lqp_oracle.lqp_solve_py(*args, Nc=6, **kw)
+
+
+def test_config_D_size_smoothed_cone_objective_certificate(solver):
+    """The reference's DEFAULT solver path with log-barrier smoothing (c_lcone_solve, smooth_alpha = 10) at config D's size — r04 had a
+    bench line for it and no parity evidence beyond M ~ 20.  No oracle finishes 4096 x 50 x 16 variables with 4096 cones in test time;
+    instead the returned point's optimality is certified from the ABI data alone (tests/support/kkt_certificate.smoothed_cone_certificate):
+    the epigraph multipliers are determined by each particle's own stationarity, then their range, sum, sides of the threshold cost and
+    the shared controls' stationarity are checked.  Cold solve + one warm solve of the SCP loop."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem
+    from tests.support.kkt_certificate import smoothed_cone_certificate
+
+    M, N, alpha = 4096, 50, 10.0
+    prob = dyn.make_quadrotor_problem(M=M, N=N)
+    d = to_device_problem(prob)
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    for it in range(2):
+        f, fx, fu = solver.linearize(MODEL_QUADROTOR, d["x0"], Xa, Ua, d["params"])
+        _, _, status = solver.lcone_solve(smooth_alpha=alpha, f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"],
+                                          reg_x=prob["reg_x"], reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d["lu"], uu=d["uu"], X_out=Xb, U_out=Ub, symmetric_cost=True)
+        solver.sync()
+        assert status == 0, solver.last_info
+        n = lambda t_: t_.cpu().numpy()
+        cert = smoothed_cone_certificate(prob["x0"], n(f), n(fx).swapaxes(-1, -2), n(fu).swapaxes(-1, -2), n(Xa), n(Ua), prob["Q"], prob["R"], prob["X_ref"],
+                                         prob["U_ref"], prob["reg_x"], prob["reg_u"], 1, prob["u_l"], prob["u_u"], n(Xb), n(Ub), alpha)
+        print(f"  smoothed cone objective, SCP iteration {it + 1}: " + ", ".join(f"{k_} {v:.2e}" if isinstance(v, float) else f"{k_} {v}" for k_, v in cert.items() if not k_.startswith("_")),
+              flush=True)
+        assert cert["slack"] > 0.0 and cert["fractional_multipliers"] >= 1
+        assert max(cert["dynamics"], cert["consensus"]) < 1e-9
+        assert max(cert["own_controls"], cert["shared_controls"], cert["lam_range"], cert["lam_sum"], cert["threshold_spread"], cert["complementarity"]) < 1e-6, cert
+        Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
+
+
+def test_config_D_size_hard_cone_objective_certificate(solver):
+    """The reference's DEFAULT solver path (c_lcone_solve, hard boxes) at config D's size: optimality certified from the ABI data alone
+    (tests/support/kkt_certificate.hard_cone_certificate) — every particle at its conditional optimum given the shared controls, and
+    multipliers of the epigraph rows that sit on the right sides of the threshold cost, sum to (1 - eps) k and leave the shared controls
+    stationary (fitted over the costs on the threshold).  The M = 600 comparison with the cone oracle is further up."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, to_device_problem
+    from tests.support.kkt_certificate import hard_cone_certificate
+
+    M, N = 4096, 50
+    prob = dyn.make_quadrotor_problem(M=M, N=N)
+    d = to_device_problem(prob)
+    Xa, Ua = d["X_prev"].clone(), d["U_prev"].clone()
+    Xb, Ub = torch.empty_like(Xa), torch.empty_like(Ua)
+    for it in range(3):
+        f, fx, fu = solver.linearize(MODEL_QUADROTOR, d["x0"], Xa, Ua, d["params"])
+        _, _, status = solver.lcone_solve(f=f, fx=fx, fu=fu, X_prev=Xa, U_prev=Ua, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"],
+                                          reg_u=prob["reg_u"], Nc=1, x0=d["x0"], lu=d["lu"], uu=d["uu"], X_out=Xb, U_out=Ub, symmetric_cost=True,
+                                          static_cons_bounds=True, prev_is_last_solution=it > 0)
+        solver.sync()
+        assert status == 0, solver.last_info
+        n = lambda t_: t_.cpu().numpy()
+        cert = hard_cone_certificate(prob["x0"], n(f), n(fx).swapaxes(-1, -2), n(fu).swapaxes(-1, -2), n(Xa), n(Ua), prob["Q"], prob["R"], prob["X_ref"],
+                                     prob["U_ref"], prob["reg_x"], prob["reg_u"], 1, prob["u_l"], prob["u_u"], n(Xb), n(Ub))
+        print(f"  cone objective (hard boxes), SCP iteration {it + 1}: " + ", ".join(f"{k_} {v:.2e}" if isinstance(v, float) else f"{k_} {v}" for k_, v in cert.items() if not k_.startswith("_")),
+              flush=True)
+        assert max(cert["dynamics"], cert["consensus"], cert["box"]) < 1e-9
+        assert max(cert["own_controls"], cert["shared_controls"], cert["lam_sum"], cert["remainder_feasible"]) < 1e-8, cert
+        Xa, Xb, Ua, Ub = Xb, Xa, Ub, Ua
