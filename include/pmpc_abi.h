@@ -220,7 +220,7 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *                                             kernel (no per-particle block travels through HBM) whenever nothing downstream needs one particle's block
  *   as_freeze_tol    PMPC_AS_FREEZE_TOL    1e-9  stage-cone rounds with one consensus stage: a step of the free shared controls below this (relative)
  *                                             is taken as zero by every particle, and the settled particles leave the forward sweep at once (0: off)
- *   as_ckpt          PMPC_AS_CKPT          1   the factor sweeps leave their cost-to-go at stages 8, 16, 32, ..; an unsettled particle's factor sweep of a
+ *   as_ckpt          PMPC_AS_CKPT          1   the factor sweeps leave their cost-to-go at stages 4, 8, 16, 32, ..; an unsettled particle's factor sweep of a
  *                                             later round starts at the lowest of them at or above its highest changed stage (0: from the terminal cost)
  *   as_sens_min_m    PMPC_AS_SENS_MIN_M    3072  one consensus stage, at least this many particles on the rank: the forward sweep records the sensitivity
  *                                             of every stage to the shared-control step, and settled particles of the later rounds are updated elementwise

@@ -122,7 +122,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"cone_epigraph", "PMPC_CONE_EPIGRAPH", 1},    // cone objective with hard boxes: epigraph problem in the shared-control space (any tie pattern); 0: weighted-QP fixed point
     {"cond_grouped", "PMPC_COND_GROUPED", 1},      // Nc > 1: condensed Hessians summed over groups of particles inside the condensing kernel
     {"as_freeze_tol", "PMPC_AS_FREEZE_TOL", 1e-9}, // stage-cone rounds: a shared-control step below this (relative) is zero for every particle; settled ones skip the forward sweep
-    {"as_ckpt", "PMPC_AS_CKPT", 1},                // factor sweeps checkpoint their cost-to-go at stages 8, 16, 32, ..; the later rounds' sweeps restart at the lowest checkpoint above the highest changed stage
+    {"as_ckpt", "PMPC_AS_CKPT", 1},                // factor sweeps checkpoint their cost-to-go at stages 4, 8, 16, 32, ..; the later rounds' sweeps restart at the lowest checkpoint above the highest changed stage
     {"as_sens_min_m", "PMPC_AS_SENS_MIN_M", 3072}, // particles per rank from which the forward sweep records sensitivities to the shared step and settled particles of the later rounds are updated elementwise (one consensus stage; 0: never)
 };
 

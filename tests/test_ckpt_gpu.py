@@ -57,8 +57,8 @@ def test_restart_leaves_the_answers_alone_quadrotor(N, Nc, jump):
     assert r0 == r1 and r0 > 5, (r0, r1)  # several rounds per solve: there is something to restart
     assert s0["restarted"] == 0
     assert s1["restarted"] > 0, s1
-    if jump:  # changes in mid-horizon: restarts from the higher rungs (more than the 9 stages of the first one), or none possible
-        assert s1["restarted_stages"] > 9 * s1["restarted"] or s1["full"] > 0, s1
+    if jump:  # changes in mid-horizon: restarts from the higher rungs (more than the 5 stages of the first one on average), or none possible
+        assert s1["restarted_stages"] > 5 * s1["restarted"] or s1["full"] > 0, s1
     assert _compare(off, on) < 1e-10
 
 
