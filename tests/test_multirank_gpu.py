@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 _group = [1000]
 
 
-def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None):
+def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None, options=None):
     import torch
 
     from pmpc_amd import _lib
@@ -37,6 +37,8 @@ def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None):
             if world > 1:
                 assert s.lib.pmpc_comm_init_mock(s.h, rank, world, group) == 0
                 s.rank, s.world = rank, world
+            for key, val in (options or {}).items():
+                s.set_option(key, val)
             opt = {}
             if "u_l" in kw:
                 opt.update(lu=dev(kw["u_l"]), uu=dev(kw["u_u"]))
@@ -123,6 +125,26 @@ def test_sharded_binding_state_boxes_match_single_rank(world, Nc, dims, oracle):
     assert rel(X1, Xo) < 1e-7 and rel(U1, Uo) < 1e-7, (rel(X1, Xo), rel(U1, Uo))
     assert rel(Xw, X1) < 1e-9 and rel(Uw, U1) < 1e-9, (rel(Xw, X1), rel(Uw, U1))
     assert np.all(Uw[:, :Nc] == Uw[0:1, :Nc])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_rounds_with_restart_and_elementwise_update(world, oracle):
+    """The later rounds' work savers on sharded particles: factor sweeps restarted from checkpoints (as_ckpt, on by default) and settled
+    particles updated elementwise from the forward sweep's sensitivity records (as_sens_min_m forced to 1: normally on from 3072 particles per
+    rank) — the shared step every rank applies is the all-reduced one.  A cold solve whose rounds take several passes; against one rank with
+    both options off (1e-9) and the oracle."""
+    M, N, x, u, Nc = 8, 12, 12, 4, 1
+    rng = np.random.default_rng(4242)
+    args, kw = rand_problem(rng, M, N, x, u, 0.3)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    X0, U0, _ = _solve_sharded(args, kw, Nc, 1, options=dict(as_ckpt=0, as_sens_min_m=0))
+    Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, options=dict(as_sens_min_m=1))
+    assert infos[0]["active_set_rounds"] >= 3, infos[0]  # (several rounds: later ones restart sweeps and update settled particles elementwise)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    assert rel(X0, Xo) < 1e-7 and rel(U0, Uo) < 1e-7
+    assert rel(Xw, X0) < 1e-9 and rel(Uw, U0) < 1e-9, (rel(Xw, X0), rel(Uw, U0))
+    assert np.all(Uw[:, :Nc] == Uw[0:1, :Nc])
+    assert len({(i["ipm_iters"], i["active_set_rounds"], i["structured_solves"]) for i in infos}) == 1
 
 
 def test_eight_ranks_quadrotor_shape(oracle):
