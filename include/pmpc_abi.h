@@ -225,6 +225,8 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *   as_sens_min_m    PMPC_AS_SENS_MIN_M    3072  one consensus stage, at least this many particles on the rank: the forward sweep records the sensitivity
  *                                             of every stage to the shared-control step, and settled particles of the later rounds are updated elementwise
  *                                             from it instead of being swept again (0: never)
+ *   as_perm_min_m    PMPC_AS_PERM_MIN_M    2048  from that many particles per rank a later round's launches take the UNSETTLED particles first: their long sweeps
+ *                                             then spread one per SIMD instead of piling up where their indices fall (0: never)
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);

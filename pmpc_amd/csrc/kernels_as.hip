@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(64, MODE == 2 ? 2 : (MODE == 1 ? PMPC_AS_DEEP_
   constexpr long long MB = sizeof(MT);  // bytes per matrix entry
   if (a.done && *a.done) return;
   const int lane = threadIdx.x;
-  const int N = a.N, Nc = a.Nc, i = blockIdx.x;
+  // (as_perm: the round's unsettled particles first — their long sweeps then land one per SIMD instead of where their indices put them)
+  const int N = a.N, Nc = a.Nc, i = a.as_perm ? __builtin_amdgcn_readfirstlane(a.as_perm[blockIdx.x]) : (int)blockIdx.x;
   if (SKIP && a.as_settled_in[i]) {
     // nothing of this particle changed: factors, condensed Hessian H_i and conditional optimum stand; its reduced consensus
     // gradient follows the consensus step that was applied, g_i += H_i delta (exact: the QP is quadratic).  nc <= 32 here.
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
   if (a.done && *a.done) return;
   const int lane = threadIdx.x;
   const LT L(lane);
-  const int N = a.N, Nc = a.Nc, i = blockIdx.x, g = L.g, c = L.c;
+  const int N = a.N, Nc = a.Nc, i = a.as_perm ? __builtin_amdgcn_readfirstlane(a.as_perm[blockIdx.x]) : (int)blockIdx.x, g = L.g, c = L.c;
   const size_t pbase = (size_t)i * N;
   const bool gu = g < UD;
   const double *Z = a.zeros;
@@ -885,6 +886,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
             nadd_e += (vlo || vhi) ? 1 : 0;  // (outside its box and still free: the next round sweeps this particle and clamps it)
             nbad_e |= !(zt == zt) ? 1 : 0;
             gst(a.Uo + e, zt);
+            if (CONE) gst(a.as_uraw + e, zt);  // the stage's own Newton step before clamping (what the cone pass updates its multipliers with)
           } else {
             const double kn = kf[q] - dv[q];  // kff holds -du_b of the held control: its multiplier is -/+ big du_b
             const double lam = act[q] == 1 ? a.as_big * kn : -a.as_big * kn;
@@ -895,6 +897,7 @@ __global__ void __launch_bounds__(64, 4) k_fwd_as(LQArgs a) {
             gst(a.kff + e, kn);
             if (release) a.as_act[e] = 0;
             if (a.Uo != Ub) gst(a.Uo + e, ub[q]);
+            if (CONE) gst(a.as_uraw + e, ub[q] + dv[q]);
           }
         }
       }
@@ -1013,6 +1016,34 @@ __global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part
   as_ctl_block(ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol, open_part);
 }
 
+// Order of the particles for a later round's launches: the UNSETTLED ones first (ascending), then the settled ones.  A later round's sweeps
+// do long work for the unsettled particles only (restarted factor sweep, forward sweep) and next to nothing for the settled ones (g_i += H_i
+// delta; elementwise update).  Launched in index order the long waves land where their indices put them: with a quarter of 4096 particles
+// unsettled, 6 % of the SIMDs hold three or four long waves and the launch takes what a full launch takes (measured at config E: 210 of
+// 285 us with 27 % unsettled).  Workgroups are dispatched in order, so with the unsettled particles in front they spread one per SIMD.
+// One block of 1024 threads: counts, exclusive scan, scatter.
+__global__ void __launch_bounds__(1024) k_as_perm(const int *settled, int M, int *perm, const int *done) {
+  if (done && *done) return;
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x, per = (M + 1023) / 1024, lo = t * per, hi = min(M, lo + per);
+  int n = 0;
+  for (int i = lo; i < hi; i++) n += settled[i] ? 0 : 1;
+  cnt[t] = n;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
+    const int v = t >= o ? cnt[t - o] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  const int total = cnt[1023];
+  int pu = cnt[t] - n, ps = total + lo - pu;  // first slots of this thread's unsettled / settled particles
+  for (int i = lo; i < hi; i++) {
+    if (settled[i]) perm[ps++] = i;
+    else perm[pu++] = i;
+  }
+}
+
 // CONE instantiations of the two sweeps: every compiled (xdim, udim) pair with udim >= 2 (ten more kernels each)
 template <int XD, int UD>
 constexpr bool cone_dims() { return UD >= 2; }
@@ -1102,7 +1133,10 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
   const dim3 grd(a.M), blk(64);
   if (a.mat32) {
     if constexpr (f32_dims<XD, UD>()) {
-      if (a.as_uraw) {
+      if (a.as_uraw && a.as_T && a.Nc == 1) {
+        if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, false, true, float, true>), grd, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true, float, true>), grd, blk, 0, s, a);
+      } else if (a.as_uraw) {
         if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true, float>), grd, blk, 0, s, a);
         else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true, float>), grd, blk, 0, s, a);
       } else if (a.as_T && a.Nc == 1) {
@@ -1119,6 +1153,11 @@ void launch_fwd_as_t(const LQArgs &a, hipStream_t s) {
   }
   if (a.as_uraw) {
     if constexpr (cone_dims<XD, UD>()) {
+      if (a.as_T && a.Nc == 1) {  // sensitivity records + elementwise update of the settled particles, with stage cones
+        if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, false, true, double, true>), grd, blk, 0, s, a);  // (one-stage ring: registers)
+        else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true, double, true>), grd, blk, 0, s, a);
+        return;
+      }
       if (a.defect) hipLaunchKernelGGL((k_fwd_as<XD, UD, true, true, true>), grd, blk, 0, s, a);
       else hipLaunchKernelGGL((k_fwd_as<XD, UD, false, true, true>), grd, blk, 0, s, a);
       return;
@@ -1182,6 +1221,9 @@ void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int 
                    unsigned long long *mirror_seq, unsigned long long seq, hipStream_t s, double *tail, const double *viol, const int *open_part) {
   hipLaunchKernelGGL(k_as_ctl, dim3(1), dim3(1024), 0, s, ctl, cnt_part, M, fail, reduce, decide, last_of_batch, mirror, mirror_seq, seq, tail, viol,
                      open_part);
+}
+void launch_as_perm(const int *settled, int M, int *perm, const int *done, hipStream_t s) {
+  hipLaunchKernelGGL(k_as_perm, dim3(1), dim3(1024), 0, s, settled, M, perm, done);
 }
 void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s, int stall_limit) {
   hipLaunchKernelGGL(k_as_begin, dim3(1), dim3(64), 0, s, ctl, fail, max_rounds, dual_scale, stall_limit);

@@ -116,6 +116,7 @@ struct LQArgs {
   // the highest stage whose status changed (as_jhi, -1: none; the cone / state-row passes raise it to the highest stage whose
   // Newton terms changed); an unsettled particle's next factor sweep starts at the lowest checkpoint at or above that stage
   // — the recursion above it is unchanged, s follows the base point exactly: s + S (x_base_now - x_base_then).  Null = off.
+  const int *as_perm;  // later rounds: particle of workgroup b (unsettled ones first, k_as_perm); null = identity
   double *as_ck;
   int *as_jhi;
   int ck_slots;
@@ -147,7 +148,7 @@ struct LQArgs {
   const double *cone_H, *cone_g;
   double *as_uraw;
   int *as_open;    // per particle: open stage cones (zeroed by the forward sweep, counted by the cone pass)
-  double *as_T;    // forward sweep, one consensus stage: sensitivity records [M][N][64] (null: off) — see k_fwd_as<.., SENS>; solver.hip never sets it together with as_uraw
+  double *as_T;    // forward sweep, one consensus stage: sensitivity records [M][N][64] (null: off) — see k_fwd_as<.., SENS>
   // state boxes on the active-set sweeps (kernels_xbox.hip prepares them per round): a penalty on the diagonal of the stage's state
   // cost and a gradient term, per state entry (M,N,x).  Null = none (the XBOX instantiations are not launched).
   const double *xb_D, *xb_g;
@@ -253,6 +254,7 @@ void launch_bwd_as(const LQArgs &a, hipStream_t s);
 void launch_fwd_as(const LQArgs &a, hipStream_t s);
 // round control: reduce the per-particle counters into ctl->cnt (+ failure flag) and / or decide (done, status, next tolerance);
 // publishes ctl to the host-coherent mirror with sequence number `seq` when the rounds are over or the batch ends
+void launch_as_perm(const int *settled, int M, int *perm, const int *done, hipStream_t s);  // kernels_as.hip: unsettled particles first
 void launch_as_begin(AsCtl *ctl, int *fail, int max_rounds, double dual_scale, hipStream_t s, int stall_limit = 2);  // fresh control block of an attempt, *fail = 0
 // `tail`: 5 doubles {released, activated, bad, failure, open cones} (sharded runs)
 void launch_as_ctl(AsCtl *ctl, const int *cnt_part, int M, const int *fail, int reduce, int decide, int last_of_batch, AsCtl *mirror,

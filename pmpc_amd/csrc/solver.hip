@@ -124,6 +124,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"as_freeze_tol", "PMPC_AS_FREEZE_TOL", 1e-9}, // stage-cone rounds: a shared-control step below this (relative) is zero for every particle; settled ones skip the forward sweep
     {"as_ckpt", "PMPC_AS_CKPT", 1},                // factor sweeps checkpoint their cost-to-go at stages 4, 8, 16, 32, ..; the later rounds' sweeps restart at the lowest checkpoint above the highest changed stage
     {"as_sens_min_m", "PMPC_AS_SENS_MIN_M", 3072}, // particles per rank from which the forward sweep records sensitivities to the shared step and settled particles of the later rounds are updated elementwise (one consensus stage; 0: never)
+    {"as_perm_min_m", "PMPC_AS_PERM_MIN_M", 2048}, // particles per rank from which a later round's launches take the unsettled particles first (their long sweeps spread one per SIMD); 0: never
 };
 
 namespace pmpc_impl {
@@ -366,7 +367,7 @@ void pmpc_destroy(pmpc_ctx *c) {
                    &w.red_tmp, &w.Hg, &w.Lc, &w.duc, &w.xch, &w.zeros, &w.zslew, &w.zslew0, &w.zum1, &w.part_sum, &w.part_cnt,
                    &w.part_max, &w.sc, &w.fail, &w.pw, &w.Jc, &w.Jg, &w.part_dev, &w.warmU, &w.lateX, &w.lateU, &w.warm_llu, &w.warm_luu, &w.warm_llx,
                    &w.warm_lux, &w.Hadd, &w.wu_soc, &w.soc_zl, &w.soc_zu, &w.soc_zc, &w.soc_dzl, &w.soc_dzu, &w.soc_dzc, &w.soc_sl, &w.soc_su, &w.soc_sc, &w.soc_dsl,
-                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol, &w.as_ck, &w.as_jhi, &w.ck_stat, &w.Hc_grp, &w.as_T, &w.xb_qmax,
+                   &w.soc_dsu, &w.soc_dsc, &w.soc_cl, &w.soc_cu, &w.soc_cc, &w.soc_wU, &w.soc_wzl, &w.soc_wzu, &w.soc_wzc, &w.as_act, &w.as_cnt, &w.as_cntp, &w.as_settled, &w.cons_lo, &w.cons_hi, &w.as_ctl, &w.as_delta, &w.as_viol, &w.as_ck, &w.as_jhi, &w.ck_stat, &w.Hc_grp, &w.as_T, &w.xb_qmax, &w.as_perm,
                    &w.sa_f, &w.sa_fx, &w.sa_fu, &w.sa_Xp, &w.sa_Up, &w.sa_Q, &w.sa_R, &w.sa_Xr, &w.sa_Ur, &w.sa_lo, &w.sa_hi, &w.sa_Xo, &w.sa_Uo,
                    &w.sa_cl, &w.sa_ch, &w.cone_A, &w.cone_c, &w.cone_z, &w.cone_rec, &w.cone_uraw, &w.as_open, &w.xb_z, &w.xb_st, &w.xb_D, &w.xb_g, &w.m64[0], &w.m64[1], &w.m64[2], &w.m64[3]};
   for (DevBuf *b : all) b->release();
@@ -1223,7 +1224,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
     {  // sensitivity records of the forward sweep (k_fwd_as<.., SENS>): worth their stores when later rounds are expected and the sweeps are
        // issue-bound (many waves per SIMD); a small shard's rounds sit at one wave's latency whatever the settled particles do
       const int min_m = (int)c->opt[OPT_AS_SENS_MIN_M];
-      if (min_m > 0 && M >= min_m && as_skip_on && Nc == 1 && !cone && (mode != 0 || w.as_pred_rounds >= 2)) {
+      if (min_m > 0 && M >= min_m && as_skip_on && Nc == 1 && (mode != 0 || w.as_pred_rounds >= 2)) {
         w.as_T.ensure((size_t)M * N * 64 * D8);
         b.as_T = w.as_T.d();
       }
@@ -1311,6 +1312,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       ca.U = use_defect ? p->U_prev : p->U_out;
       launch_cone_step(ca, s);
     }
+    const int perm_min_m = (int)c->opt[OPT_AS_PERM_MIN_M];
     int round = 0, depth = mode == 0 ? std::max(1, std::min(w.as_pred_rounds, max_rounds)) : std::min(3, max_rounds);
     if (verbose > 1 && xbox) depth = 1;  // (the debugging dump below wants every round)
     static const bool duc_trace = getenv("PMPC_DUC_TRACE") != nullptr;
@@ -1327,6 +1329,14 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         // conditional optimum: no factor sweep for them — g_i follows the applied consensus step, g_i += H_i delta
         const bool skip = as_skip_on && r > 0 && nc <= 32;
         b.as_settled_in = skip ? (const int *)w.as_settled.p : nullptr;
+        // the unsettled particles first: their sweeps are the launch's long waves (kernels_as.hip, k_as_perm)
+        b.as_perm = nullptr;
+        if (skip && perm_min_m > 0 && M >= perm_min_m && b.as_T) {  // (with every particle sweeping the index order is the better one: memory locality)
+          ProfScope pp(c, 5);
+          w.as_perm.ensure((size_t)M * sizeof(int));
+          launch_as_perm((const int *)w.as_settled.p, M, (int *)w.as_perm.p, &ctl->done, s);
+          b.as_perm = (const int *)w.as_perm.p;
+        }
         const bool last = k == batch - 1;
         // sharded with a consensus horizon: {released, activated, bad, failure} of round r ride in round r + 1's consensus
         // all-reduce (structured_solve), the decision about round r follows it there; only the last round of a batch needs a

@@ -71,6 +71,7 @@ struct Workspace {
   DevBuf lateX, lateU;  // last interior-point iterate with mu <= 1e-10 mu_peak and small residuals (kept against a numerical breakdown at mu ~ 1e-12)
   long long warm_key = -1;
   double warm_mu = 0.0;  // barrier parameter the remembered iterate belongs to (0: the early iterate of a hard-constrained solve)
+  DevBuf as_perm;  // later rounds: particle order of the launches (unsettled first)
   DevBuf as_T;  // forward sweep's sensitivity records (one consensus stage: settled particles of the later rounds are updated elementwise)
   DevBuf as_ck, as_jhi, ck_stat;  // checkpoints of the factor sweeps' cost-to-go + highest changed stage per particle (restart of the later rounds' sweeps)
   DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta, as_viol;  // active-set iteration: status per bounded control (int), counters,
@@ -96,7 +97,7 @@ struct Workspace {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_AS_CKPT, OPT_AS_SENS_MIN_M, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_AS_CKPT, OPT_AS_SENS_MIN_M, OPT_AS_PERM_MIN_M, OPT_COUNT
 };
 }  // namespace pmpc_impl
 using namespace pmpc_impl;

@@ -139,3 +139,49 @@ def test_elementwise_update_of_settled_particles_leaves_the_answers_alone(model,
     sb.close()
     assert rounds > 6, rounds  # later rounds ran: settled particles went through the elementwise path
     assert worst < (1e-9 if f32 else 1e-12), worst
+
+
+@pytest.mark.parametrize("soc", [False, True])
+def test_unsettled_first_launch_order_and_cone_elementwise_path(soc):
+    """(1) A later round's launches take the unsettled particles first (option as_perm_min_m, k_as_perm; only with the elementwise path, where
+    the settled particles' waves are short): the workgroup -> particle map must not change a bit of the answer.  (2) The elementwise path
+    with stage cones (the raw Newton steps the cone pass needs are written elementwise too) against sweeps, lock-step on identical
+    sub-problems."""
+    import torch
+
+    from pmpc_amd import dynamics as dyn
+    from pmpc_amd.device import MODEL_QUADROTOR, DeviceSolver, to_device_problem
+
+    M, N = 160, 40
+    prob = dyn.make_quadrotor_problem(M=M, N=N, Nc=1)
+    d = to_device_problem(prob)
+    dev = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device="cuda")
+    kw = {}
+    if soc:
+        W = np.zeros((2, 4))
+        W[0, 1] = W[1, 2] = 1.0
+        kw = dict(soc_W=dev(W), soc_w0=dev(np.zeros(2)), soc_v=dev([0.3, 0, 0, 0]), soc_v0=0.0, soc_u_interior=dev([9.81, 0, 0, 0]))
+    solvers = [DeviceSolver(0) for _ in range(3)]
+    for s, (sens, perm) in zip(solvers, ((0, 0), (1, 0), (1, 1))):
+        s.set_option("as_sens_min_m", sens)
+        s.set_option("as_perm_min_m", perm)
+    Xp, Up = d["X_prev"].clone(), d["U_prev"].clone()
+    rounds = 0
+    for it in range(5):
+        f, fx, fu = solvers[0].linearize(MODEL_QUADROTOR, d["x0"], Xp, Up, d["params"])
+        solvers[0].sync()
+        outs = []
+        for s in solvers:
+            fn = s.lsoc_solve if soc else s.lqp_solve
+            X, U, status = fn(f=f, fx=fx, fu=fu, X_prev=Xp, U_prev=Up, Q=d["Q"], R=d["R"], X_ref=d["X_ref"], U_ref=d["U_ref"], reg_x=prob["reg_x"], reg_u=prob["reg_u"],
+                              Nc=1, x0=d["x0"], lu=d.get("lu"), uu=d.get("uu"), symmetric_cost=True, static_cons_bounds=True, prev_is_last_solution=it > 0, **kw)
+            s.sync()
+            assert status == 0
+            outs.append((X.cpu().numpy(), U.cpu().numpy()))
+        rounds += solvers[2].last_info["active_set_rounds"]
+        assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1], outs[2][1])  # launch order: bit for bit
+        assert _compare([outs[0]], [outs[1]]) < 1e-11                                            # elementwise path against sweeps
+        Xp, Up = torch.as_tensor(outs[0][0], device=Xp.device), torch.as_tensor(outs[0][1], device=Up.device)
+    for s in solvers:
+        s.close()
+    assert rounds > 5

@@ -16,3 +16,4 @@ run tools/fuzz/fuzz_cone.py $((b+9)) 60 300 5
 run tools/fuzz/fuzz_sharded.py $((b+10)) 400
 run tools/fuzz/fuzz_sequence.py $((b+11)) 400
 run tools/fuzz/fuzz_scp_loop.py $((b+12)) 300
+run tools/fuzz/fuzz_freeze.py $((b+13)) 100 5
