@@ -803,6 +803,199 @@ __global__ void __launch_bounds__(1024) k_cons_solve_lds(const double *Hc, doubl
   for (int e = tid; e < nc; e += nth) duc[e] = y[e];
 }
 
+// ---- register-resident variant for the systems that do not fit LDS (80 < nc <= 255: Nc = N at config D is 200) ----------------
+// The lower triangle lives in the REGISTERS of one 512-thread workgroup as 16 x 16 blocks in the accumulator layout of
+// v_mfma_f64_16x16x4_f64 (lane (c, g), register r <-> entry [g + 4r][c]; blocks dealt to the 8 waves round-robin in column-major
+// order, so the blocks still active at any panel are spread over all waves) for the whole factorisation; LDS carries the current
+// 16-column panel (raw, then solved; row-major, stride 17) and the inverses of the diagonal blocks.  k_cons_solve_blocked keeps the
+// matrix in global memory and pays a read-modify-write round trip per trailing tile and panel (0.33 ms at nc = 200, a chain of 13
+// panels).  A panel here: (A) the owners of the panel's blocks publish them, (B) one wave factors the 16 x 16 diagonal block in
+// registers (readlane broadcasts, 1/sqrt by seed + Newton) and inverts it, (C) every block of the panel becomes A L_kk^-T by 4 MFMAs
+// and is published again, (D) every trailing block takes its rank-16 update by 4 MFMAs.  The right-hand side rides along as row nc
+// of the matrix (L z = -g falls out of (C)), and L' x = z runs right-looking from the blocks with the four per-lane-group partial sums
+// added in a FIXED order: every rank that solves the same system gets the same bits.
+// Lc gets the factor in k_cons_solve_blocked's layout (its vector-only solves follow a factorisation done here).
+typedef double cv4d __attribute__((ext_vector_type(4)));
+constexpr int CONS_REG_NTH = 512, CONS_REG_NW = CONS_REG_NTH / 64;
+constexpr int CONS_REG_NCP = 256;   // padded row count of the LDS panels (16 block rows)
+constexpr int CONS_REG_LD = 17;     // row stride of the LDS panels
+__host__ __device__ inline bool cons_reg_fits(int nc) { return nc > 16 && (nc + 1 + 15) / 16 <= CONS_REG_NCP / 16; }
+constexpr size_t CONS_REG_LDS = ((size_t)2 * CONS_REG_NCP * CONS_REG_LD + (size_t)(CONS_REG_NCP / 16) * 272 + 272 + 256 + CONS_REG_NCP + 4 * CONS_REG_NCP) * sizeof(double);
+
+// (B) of k_cons_solve_reg, one wave: Cholesky factor of the 16 x 16 diagonal block (`rows`, stride CONS_REG_LD; identity beyond bs) and the
+// inverse of the factor.  All 64 lanes work on the block in the accumulator layout (lane (c, g), register r <-> entry [g + 4r][c]): per pivot
+// the scaled column goes through LDS — which leaves the factor there, Dg[p * 16 + (row & 3) * 4 + (row >> 2)] = L[row][p] — and comes back
+// as four row values + one column value per lane for the rank-one update (4 FMAs per lane); row p of the inverse (lane = its column) follows
+// in the same step from the rows already published.  The lane-per-row form with readlane broadcasts was 1 800 instructions for ONE wave
+// (5.5 us per panel, 71 of the kernel's 131 us at nc = 200).  Its own function, not inlined: next to the 96 block registers of the kernel
+// the chain went to spill code.
+__device__ __attribute__((noinline)) void cons_diag_block(const double *rows, double *Dg, double *Dinv, int bs, int *fail) {
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  double m[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = g + 4 * r;
+    m[r] = (row < bs && c <= row) ? rows[row * CONS_REG_LD + c] : ((row == c) ? 1.0 : 0.0);
+  }
+  const int vidx = (c & 3) * 4 + (c >> 2);  // where L[c][p] sits in a published column
+  double xc[16];
+  bool bad = false;
+#pragma unroll
+  for (int p = 0; p < 16; p++) {
+    double d = rl_d(m[p >> 2], p + 16 * (p & 3));
+    bad |= !(d > 0.0);
+    d = (d > 0.0) ? d : 1.0;
+    double rd = __builtin_amdgcn_rsq(d);
+    rd = fma(rd, fma(-0.5 * d * rd, rd, 0.5), rd);
+    rd = fma(rd, fma(-0.5 * d * rd, rd, 0.5), rd);
+    // (no branches in the chain: the lanes that do not hold the pivot column write to a scratch line of their own, so that the
+    //  whole factorisation is ONE basic block and the scheduler can put the inverse's dot products into the chain's stalls)
+    double *dst = (c == p) ? Dg + p * 16 + g * 4 : Dg + 272 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      m[r] = (c == p) ? m[r] * rd : m[r];  // (the pivot itself: d * rd = sqrt(d); rows above it: never read)
+      dst[r] = m[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const double vl = Dg[p * 16 + vidx], v = (c > p) ? vl : 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) m[r] = fma(-Dg[p * 16 + g * 4 + r], v, m[r]);
+    // row p of the inverse: x[p] = (e_p - sum_{k < p} L[p][k] x[k]) / L[p][p], this lane's column (the four lane groups alike)
+    double sx = (p == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < p; k++) sx = fma(-Dg[k * 16 + (p & 3) * 4 + (p >> 2)], xc[k], sx);
+    xc[p] = sx * rd;
+    Dinv[p * 17 + c] = (p >= c) ? xc[p] : 0.0;
+  }
+  if (bad && lane == 0) *fail = 2;
+}
+
+// (a uniform value the optimiser may not reason about: keeps the per-slot LDS addresses from being hoisted out of the panel loop —
+//  12 slots x 8 addresses held in registers next to the 96 of the blocks spilled)
+__device__ __forceinline__ int launder_s(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+template <int MAXQ>
+__global__ void __launch_bounds__(CONS_REG_NTH) k_cons_solve_reg(const double *Hc, double *Lc, const double *gc, double *duc, int nc, int *fail) {
+  extern __shared__ double sm[];
+  constexpr int NCP = CONS_REG_NCP, LD = CONS_REG_LD, NTH = CONS_REG_NTH, NW = CONS_REG_NW;
+  double *Praw = sm;                      // the panel as its owners hold it: Praw[row * LD + k]
+  double *P = Praw + NCP * LD;            // the panel solved against the diagonal block (the block's own rows included)
+  double *Di = P + NCP * LD;              // inverse of every diagonal block's factor, Di[p * 272 + r * 17 + c]
+  double *Dg = Di + (NCP / 16) * 272;     // the current diagonal block's factor, column by column (layout: cons_diag_block)
+  double *zs = Dg + 272 + 256;            // z, then x  (behind Dg: the 64 x 4 scratch lines of cons_diag_block)
+  double *part = zs + NCP;                // backward substitution: part[lane group][column]
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n1 = nc + 1, nb = (n1 + 15) / 16, nblk = nb * (nb + 1) / 2, npan = (nc + 15) / 16;
+  cv4d blk[MAXQ];
+  int bI[MAXQ], bJ[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; q++) {
+    const int e = q * NW + w;
+    int J = 0, st = 0;
+    while (J < nb && e >= st + nb - J) { st += nb - J; J++; }
+    bI[q] = e < nblk ? J + e - st : -1;  // (-1: no block)
+    bJ[q] = e < nblk ? J : -1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int R = 16 * bI[q] + g + 4 * r, C = 16 * bJ[q] + c;
+      double v = 0.0;
+      if (bI[q] >= 0 && C < nc) {
+        if (R < nc && C <= R) v = Hc[C + (size_t)nc * R];  // lower triangle of L from the UPPER triangle of Hc
+        else if (R == nc) v = -gc[C];
+      }
+      blk[q][r] = v;
+    }
+  }
+  for (int e = tid; e < NCP; e += NTH) zs[e] = 0.0;
+  for (int p = 0; p < npan; p++) {
+    const int kb = 16 * p, bs = min(16, nc - kb);
+    // (A) the panel's blocks -> Praw
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++)
+      if (bJ[q] == p) {
+        const int I = launder_s(bI[q]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) Praw[(16 * I + g + 4 * r) * LD + c] = blk[q][r];
+      }
+    __syncthreads();
+    // (B) diagonal block: one wave, lane l = row kb + l; then its inverse, lane l = column l, the factor read back from LDS
+    if (tid < 64) cons_diag_block(Praw + kb * LD, Dg, Di + p * 272, bs, fail);
+    __syncthreads();
+    // (C) the panel's blocks: X = A L_kk^-T (the diagonal block's own rows: the factor), published to P
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++)
+      if (bJ[q] == p) {
+        const int I = launder_s(bI[q]);
+        cv4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Praw[(16 * I + c) * LD + 4 * kk + g], Di[p * 272 + c * 17 + 4 * kk + g], acc, 0, 0, 0);
+        const int rr = nc - 16 * I;  // (the right-hand side's row inside this block row, if 0 <= rr < 16)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          if (I == p && g + 4 * r < bs) acc[r] = (c <= g + 4 * r) ? Dg[c * 16 + g * 4 + r] : 0.0;
+          P[(16 * I + g + 4 * r) * LD + c] = acc[r];
+          if (g + 4 * r == rr && c < bs) zs[kb + c] = acc[r];
+        }
+        blk[q] = acc;
+        __builtin_amdgcn_sched_barrier(0);  // (without it the loads of every slot are hoisted to the top: 256 registers and spills)
+      }
+    __syncthreads();
+    // (D) trailing blocks: rank-16 update
+#pragma unroll
+    for (int q = 0; q < MAXQ; q++)
+      if (bJ[q] > p) {
+        const int I = launder_s(bI[q]), J = launder_s(bJ[q]);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+          blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-P[(16 * I + c) * LD + 4 * kk + g], P[(16 * J + c) * LD + 4 * kk + g], blk[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    // (the next panel's (A) writes Praw, last read in (C); its (B) and (C) write Dg / Di / P after the barrier that follows (A))
+  }
+  // the factor -> global (column-major lower triangle, nc x nc)
+#pragma unroll
+  for (int q = 0; q < MAXQ; q++)
+    if (bI[q] >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int R = 16 * bI[q] + g + 4 * r, C = 16 * bJ[q] + c;
+        if (R < nc && C <= R) Lc[R + (size_t)nc * C] = blk[q][r];
+      }
+    }
+  for (int e = tid; e < npan * 272; e += NTH) Lc[(size_t)nc * nc + e] = Di[e];  // (the inverse diagonal blocks where k_cons_solve_lds keeps them: its vector-only solves may follow)
+  // L' x = z, right-looking over the block rows from the bottom
+  for (int p = npan - 1; p >= 0; p--) {
+    const int kb = 16 * p, bs = min(16, nc - kb);
+    double v = 0.0;
+    if (tid < bs) {
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (k >= tid && k < bs) v = fma(Di[p * 272 + k * 17 + tid], zs[kb + k], v);  // (L_kk^-T)[tid][k] = Linv[k][tid]
+    }
+    __syncthreads();
+    if (tid < bs) zs[kb + tid] = v;
+    __syncthreads();
+    if (kb > 0) {
+#pragma unroll
+      for (int q = 0; q < MAXQ; q++)
+        if (bI[q] == p && bJ[q] < p) {
+          double s_ = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; r++) s_ = fma(blk[q][r], zs[kb + g + 4 * r], s_);  // (rows >= nc: zs = 0)
+          part[g * NCP + 16 * launder_s(bJ[q]) + c] = s_;
+        }
+      __syncthreads();
+      for (int e = tid; e < kb; e += NTH) zs[e] -= (part[e] + part[NCP + e]) + (part[2 * NCP + e] + part[3 * NCP + e]);
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < nc; e += NTH) duc[e] = zs[e];
+}
+
 __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, const double *gc_part, int M, int nc, int with_H,
                                                      double *outH, double *outg, int solve_now, double *Lc, double *duc,
                                                      int *fail, AsCtlCall pend) {
@@ -1065,6 +1258,16 @@ void launch_reduce_particles(const double *src, double *tmp, double *dst, int M,
 
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s) {
+  static const bool reg_on = !(getenv("PMPC_CONS_REG") && atoi(getenv("PMPC_CONS_REG")) == 0);
+  if (reg_on && factor && cons_reg_fits(nc)) {
+    const int nb = (nc + 1 + 15) / 16, slots = (nb * (nb + 1) / 2 + CONS_REG_NW - 1) / CONS_REG_NW;
+    static const hipError_t attr12 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cons_solve_reg<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONS_REG_LDS);
+    static const hipError_t attr17 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cons_solve_reg<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONS_REG_LDS);
+    (void)attr12; (void)attr17;
+    if (slots <= 12) hipLaunchKernelGGL(k_cons_solve_reg<12>, dim3(1), dim3(CONS_REG_NTH), CONS_REG_LDS, s, (const double *)Hc, Lc, gc, duc, nc, fail);
+    else hipLaunchKernelGGL(k_cons_solve_reg<17>, dim3(1), dim3(CONS_REG_NTH), CONS_REG_LDS, s, (const double *)Hc, Lc, gc, duc, nc, fail);
+    return;
+  }
   // LDS-resident factor (+ inverse diagonal blocks + a 16-column scratch panel): up to nc = 80 inside 64 KB
   const int npan = (nc + 15) / 16;
   const size_t lds_full = ((size_t)nc * nc + nc + 16 * 17 + (size_t)npan * 272 + (size_t)16 * nc) * sizeof(double);
