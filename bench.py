@@ -474,15 +474,16 @@ def main():
             hbytes = float(M_loc * walk * stage_bytes + 2 * ((M_loc + 7) // 8) * (ncv * (ncv + 1) // 2) * 8)
             t_one = ms_cons * 1e-3 / solves_ps
             cons_roof = {"bound": "hbm", "kernel": "consensus launch class: k_cond_fast_grouped (off-diagonal blocks of the condensed Hessians, summed over groups of 8 particles "
-                                                   "before they leave the chip) + reduction of the group slabs + dense Cholesky (one workgroup)",
+                                                   "before they leave the chip) + reduction of the group slabs + dense Cholesky (one workgroup, the matrix register-resident as fp64 MFMA blocks)",
                          "avg_ms_per_solve": 1e3 * t_one, "solves_per_step": solves_ps, "bytes_per_solve": hbytes, "achieved": hbytes / t_one / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbytes / t_one / 1e9 / HBM_PEAK_GBS,
                          "flops": {"flop_per_solve": cond_flops, "achieved": cond_flops / t_one / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": cond_flops / t_one / 1e12 / FP64_PEAK_TFLOPS},
                          "note": "SURVEY.md section 8(d) prices full-consensus condensing as a dense (N x) x (N u) contraction per particle against the fp64 MFMA "
                                  "peak; the structured form walks the stages (O(Nc^2) small tile products, ~8 GFLOP at config D).  Neither roof binds: the "
-                                 "condensing kernel is a dependent chain of 3 fp64 MFMAs per tile and stage behind a per-stage barrier (0.31 ms), the "
-                                 "(Nc u)^2 Cholesky runs on ONE workgroup (0.35 ms in situ — a latency chain of 13 panel steps)"}
+                                 "condensing kernel is a dependent chain of 3 fp64 MFMAs per tile and stage behind a per-stage barrier (0.30 ms at config D; tiles per "
+                                 "wave, operand prefetch and an LDS-only barrier measured: CHANGELOG.md section 5.7), the (Nc u)^2 Cholesky is a chain of Nc u / 16 "
+                                 "panels on ONE workgroup (0.12 ms at config D, profiles/r05_cons_solve_micro.txt)"}
         rates = [args.steps / t_ for t_ in rep_s]
         w0, w1 = args.warmup + 1, args.warmup + args.steps
         out = {

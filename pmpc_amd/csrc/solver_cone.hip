@@ -60,23 +60,28 @@ int pmpc_lcone_solve_device(pmpc_ctx *c, const pmpc_problem *p, double smooth_al
 static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pmpc_info *info, int verbose, int smode = 0, double sbeta = 1.0, bool phase1_start = false) {
   Workspace &w = c->ws;
   hipStream_t s = c->stream;
-  const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, M = (int)p->M;
+  // Sharded particles (equal contiguous blocks, as everywhere): the device work is local — every rank sweeps its own particles —, the host
+  // side of the iteration is GLOBAL and identical on every rank: the per-particle scalars, condensed blocks and costs are gathered
+  // (all-reduce(sum) of a zero-padded table, one per Newton step + one per trial point), so every rank assembles the same (Nc u + 1)
+  // system, finds the same threshold and takes the same decisions.  Ml: particles here, M: particles in all.
+  const int x = (int)p->xdim, u = (int)p->udim, N = (int)p->N, Ml = (int)p->M, world = c->multi() ? c->world : 1, M = Ml * world;
+  const size_t off = (size_t)(c->multi() ? c->rank : 0) * Ml;
   const int Nc = p->Nc < 0 ? N : (int)std::min<long long>(p->Nc, (long long)N), nc = Nc * u;
   const bool has_xb = p->flags & PMPC_HAS_XBOUNDS, has_ub = p->flags & PMPC_HAS_UBOUNDS;
   // (several consensus stages: the condensed Hessians M (Nc u)^2 are gathered to the host every Newton step — bounded)
   // (M = 1: the epigraph row is degenerate — its multiplier is (1 - eps) k whatever t does — and the iteration is plain damped Newton on
   //  (1 - eps) J + the smoothing terms; taken for the squareplus hinge, which the interior-point iteration of the QP path does not know)
-  if (c->multi() || c->world != 1 || p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || M < (smode == 1 ? 1 : 2) ||
+  if (p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || M < (smode == 1 ? 1 : 2) ||
       !(has_xb || has_ub) || !(mu_b > 0.0) || (double)M * nc * nc > 2e7)
     return -1;
-  const size_t nx = (size_t)M * N * x, nu = (size_t)M * N * u, D8 = sizeof(double);
+  const size_t nx = (size_t)Ml * N * x, nu = (size_t)Ml * N * u, D8 = sizeof(double);
   LQArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = x; a.u = u; a.N = N; a.M = M; a.Nc = Nc; a.w = 0; a.n = x;
+  a.x = x; a.u = u; a.N = N; a.M = Ml; a.Nc = Nc; a.w = 0; a.n = x;
   a.reg_x = p->reg_x; a.reg_u = p->reg_u;
   a.f = p->f; a.fx = p->fx; a.fu = p->fu; a.Q = p->Q; a.R = p->R;
   a.X_prev = p->X_prev; a.U_prev = p->U_prev; a.X_ref = p->X_ref; a.U_ref = p->U_ref;
-  a.owner = 1; a.any_slew = 0; a.sym_cost = (p->flags & PMPC_SYMMETRIC_COST) ? 1 : 0;
+  a.owner = (!c->multi() || c->rank == 0) ? 1 : 0; a.any_slew = 0; a.sym_cost = (p->flags & PMPC_SYMMETRIC_COST) ? 1 : 0;
   if (!lq_fast_supported(a)) return -1;
   const double eps = 1e-3, cap = 1.0 + eps;
   const double kk = (p->cone_k > 0 && p->cone_k < (long long)M) ? (double)p->cone_k : (double)M, K = (1.0 - eps) * kk;
@@ -86,11 +91,15 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   w.es_xm.ensure(nx * D8); w.es_xd.ensure(nx * D8); w.es_um.ensure(nu * D8); w.es_ud.ensure(nu * D8);
   w.es_Dx.ensure(nx * D8); w.es_wx.ensure(nx * D8); w.es_Du.ensure(nu * D8); w.es_wu.ensure(nu * D8);
   w.es_Xt.ensure(nx * D8); w.es_Ut.ensure(nu * D8);
-  w.K.ensure((size_t)M * N * 64 * D8); w.Hinv.ensure(nu * u * D8);
+  w.K.ensure((size_t)Ml * N * 64 * D8); w.Hinv.ensure(nu * u * D8);
   w.kff.ensure(nu * D8); w.es_kff2.ensure(nu * D8); w.es_kff3.ensure(nu * D8);
-  w.gc_part.ensure((size_t)M * std::max(nc, 1) * D8); w.es_gc2.ensure((size_t)M * std::max(nc, 1) * D8); w.Hc_part.ensure((size_t)M * std::max(nc * nc, 1) * D8);
-  w.scratch.ensure((size_t)M * 3 * x * std::max(nc, 1) * D8);
-  w.es_dots.ensure((size_t)3 * M * D8); w.es_coef.ensure((size_t)M * D8); w.es_out2.ensure(2 * D8); w.pw.ensure((size_t)M * D8); w.Jc.ensure((size_t)M * D8);
+  w.gc_part.ensure((size_t)Ml * std::max(nc, 1) * D8); w.es_gc2.ensure((size_t)Ml * std::max(nc, 1) * D8); w.Hc_part.ensure((size_t)Ml * std::max(nc * nc, 1) * D8);
+  w.scratch.ensure((size_t)Ml * 3 * x * std::max(nc, 1) * D8);
+  w.es_dots.ensure((size_t)3 * Ml * D8); w.es_coef.ensure((size_t)Ml * D8); w.es_out2.ensure(2 * D8); w.pw.ensure((size_t)Ml * D8); w.Jc.ensure((size_t)Ml * D8);
+  // gather table of the sharded runs: [H_i | g_i (b) | g_i (a) | dots | one flag per rank] for ALL particles
+  const size_t nH = (size_t)nc * nc, tab_H = 0, tab_gb = tab_H + (size_t)M * nH, tab_ga = tab_gb + (size_t)M * nc, tab_dots = tab_ga + (size_t)M * nc, tab_rank = tab_dots + (size_t)3 * M,
+               tab_tot = tab_rank + (size_t)4 * world;
+  if (c->multi()) w.epi_gath.ensure(tab_tot * D8);
   w.part_sum.ensure(2 * PMPC_RED_BLOCKS * D8); w.part_max.ensure(2 * PMPC_RED_BLOCKS * D8);
   w.duc.ensure((size_t)std::max(nc, 1) * D8); w.fail.ensure(sizeof(int));
   if (w.es_zero.ensure((size_t)std::max(64, nc) * D8)) HIP_CHECK(hipMemsetAsync(w.es_zero.p, 0, w.es_zero.bytes, s));
@@ -98,11 +107,11 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     w.zeros.ensure(64 * D8);
     HIP_CHECK(hipMemsetAsync(w.zeros.p, 0, 64 * D8, s));
   }
-  if (w.zslew.bytes < (size_t)M * D8 || w.zum1.bytes < (size_t)M * u * D8) {
-    w.zslew.ensure((size_t)M * D8); w.zslew0.ensure((size_t)M * D8); w.zum1.ensure((size_t)M * u * D8);
-    HIP_CHECK(hipMemsetAsync(w.zslew.p, 0, (size_t)M * D8, s));
-    HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, (size_t)M * D8, s));
-    HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, (size_t)M * u * D8, s));
+  if (w.zslew.bytes < (size_t)Ml * D8 || w.zum1.bytes < (size_t)Ml * u * D8) {
+    w.zslew.ensure((size_t)Ml * D8); w.zslew0.ensure((size_t)Ml * D8); w.zum1.ensure((size_t)Ml * u * D8);
+    HIP_CHECK(hipMemsetAsync(w.zslew.p, 0, (size_t)Ml * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.zslew0.p, 0, (size_t)Ml * D8, s));
+    HIP_CHECK(hipMemsetAsync(w.zum1.p, 0, (size_t)Ml * u * D8, s));
   }
   a.slew = w.zslew.d(); a.slew0 = w.zslew0.d(); a.um1 = w.zum1.d();
   a.zeros = w.zeros.d();
@@ -134,6 +143,16 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   std::vector<double> J(M), Jt(M), lam(M, std::log((K / (double)M) / (cap - K / (double)M))), mu(M), sig(M), coef(M), Hh((size_t)M * std::max(nc * nc, 1)), gb((size_t)M * std::max(nc, 1)),
       ga((size_t)M * std::max(nc, 1)), dots((size_t)3 * M);
   double rho = 1.0, out2[2] = {0.0, 0.0};
+  std::vector<double> rk((size_t)4 * world);  // per-rank scalars as gathered
+  auto combine_out2 = [&]() {  // rk = (barrier value, smallest slack) per rank -> out2, summed / minimised in rank order
+    double v = 0.0, m_ = 1e300;
+    for (int r = 0; r < world; r++) {
+      v += rk[2 * r];
+      m_ = (rk[2 * r + 1] < m_ || rk[2 * r + 1] != rk[2 * r + 1]) ? rk[2 * r + 1] : m_;
+    }
+    out2[0] = v;
+    out2[1] = m_;
+  };
   // Entropic proximal term (exponential method of multipliers for multipliers boxed in [0, cap]): with l_i = logit(lam_i / cap)
   //   m_i(v) = cap * sigmoid(l_i + v / rho),   psi(v; l_i) = rho cap [softplus(l_i + v / rho) - softplus(l_i)],   psi'' = m (cap - m) / (rho cap) > 0:
   // every row carries a rank-one term, F is smooth (the quadratic proximal term's clipping makes its second derivative jump between 0
@@ -174,11 +193,24 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   // barrier terms + particle costs at (Xe, Ue): -> Jv, out2 = {barrier value, smallest slack}
   auto eval_at = [&](const double *Xe, const double *Ue, std::vector<double> &Jv) {
     launch_bar_prep(Xe, Ue, has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
-                    w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s, smode, sbeta);
+                    w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, a.owner, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s, smode, sbeta);
     launch_particle_cost(a, Xe, Ue, w.Jc.d(), s);
-    HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipMemcpyAsync(Jv.data(), w.Jc.p, (size_t)M * D8, hipMemcpyDeviceToHost, s));
+    if (!c->multi()) {
+      HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(Jv.data(), w.Jc.p, (size_t)M * D8, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      return;
+    }
+    // [J of every particle | (barrier value, smallest slack) of every rank]
+    const size_t tot = (size_t)M + 2 * world;
+    HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tot * D8, s));
+    HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + off, w.Jc.p, (size_t)Ml * D8, hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + M + 2 * c->rank, w.es_out2.p, 2 * D8, hipMemcpyDeviceToDevice, s));
+    allreduce(c, w.epi_gath.p, tot, ncclFloat64, ncclSum);
+    HIP_CHECK(hipMemcpyAsync(Jv.data(), w.epi_gath.p, (size_t)M * D8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + M, (size_t)2 * world * D8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    combine_out2();
   };
   // ---- starting point: the previous smoothed solution of this shape (strictly inside the same boxes), else the caller's U_prev pulled inside ----
   const long long skey = ((((((long long)x * 131 + u) * 131 + N) * 1000003 + M) * 131 + Nc) * 4 + (has_xb ? 2 : 0) + (has_ub ? 1 : 0)) * 2 + smode;
@@ -193,7 +225,8 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       HIP_CHECK(hipMemcpyAsync(w.U.p, p->U_prev, nu * D8, hipMemcpyDeviceToDevice, s));
       if (has_ub && smode == 0) launch_interior(w.U.d(), p->lu, p->uu, (long long)nu, 0.05, s);
     }
-    launch_share_cons(w.U.d(), M, N, u, Nc, s);
+    if (c->multi() && nc > 0) broadcast(c, w.U.p, (size_t)nc, ncclFloat64, 0);  // (global particle 0's shared controls)
+    launch_share_cons(w.U.d(), Ml, N, u, Nc, s);
     launch_rollout_fast(a, w.U.d(), w.X.d(), s);
     eval_at(w.X.d(), w.U.d(), J);
     if (out2[1] > 0.0 && out2[0] == out2[0]) break;
@@ -269,7 +302,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         summu += mu[i];
         coef[i] = std::max(mu[i], 1e-8);  // (cost weight of the sweeps: a particle of multiplier zero keeps a strictly convex sub-problem)
       }
-      HIP_CHECK(hipMemcpyAsync(w.pw.p, coef.data(), (size_t)M * D8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(w.pw.p, coef.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
       // right-hand side b: gradient of sum m_i J_i + barrier (the barrier arrays were written by the last eval_at at this point)
       launch_grad_prep(a, s);
@@ -288,14 +321,39 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       launch_fwd_fast(a2, s);  // -> -v_i = -K^-1 grad J_i in dX2 / dU2
       launch_cost_dots(a, w.X.d(), w.U.d(), w.dX2.d(), w.dU2.d(), w.dX.d(), w.dU.d(), w.es_dots.d(), s);
       int failflag = 0;
-      if (nc > 0) {
-        HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, (size_t)M * nc * nc * D8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(gb.data(), w.gc_part.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(ga.data(), w.es_gc2.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+      if (!c->multi()) {
+        if (nc > 0) {
+          HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, (size_t)M * nc * nc * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemcpyAsync(gb.data(), w.gc_part.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemcpyAsync(ga.data(), w.es_gc2.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+      } else {
+        // one table, one all-reduce: every rank gets every particle's condensed blocks and scalars (and every rank's failure flag)
+        HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tab_tot * D8, s));
+        if (nc > 0) {
+          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_H + off * nH, w.Hc_part.p, (size_t)Ml * nH * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_gb + off * nc, w.gc_part.p, (size_t)Ml * nc * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_ga + off * nc, w.es_gc2.p, (size_t)Ml * nc * D8, hipMemcpyDeviceToDevice, s));
+        }
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_dots + 3 * off, w.es_dots.p, (size_t)3 * Ml * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // (the flag is on the host)
+        const double ff = (double)failflag;
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_rank + 4 * c->rank, &ff, D8, hipMemcpyHostToDevice, s));
+        allreduce(c, w.epi_gath.p, tab_tot, ncclFloat64, ncclSum);
+        if (nc > 0) {
+          HIP_CHECK(hipMemcpyAsync(Hh.data(), w.epi_gath.d() + tab_H, (size_t)M * nH * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemcpyAsync(gb.data(), w.epi_gath.d() + tab_gb, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemcpyAsync(ga.data(), w.epi_gath.d() + tab_ga, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+        }
+        HIP_CHECK(hipMemcpyAsync(dots.data(), w.epi_gath.d() + tab_dots, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + tab_rank, (size_t)4 * world * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (int r = 0; r < world; r++) failflag = std::max(failflag, (int)rk[4 * r]);
       }
-      HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipStreamSynchronize(s));
       inf.structured_solves += 2;
       if (failflag) {
         if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep failed (flag %d)\n", failflag);
@@ -357,7 +415,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         coef[i] = sig[i] * e_ / (1.0 + sig[i] * kap[i]);
       }
       // total direction: feed-forward k_b + c_i k_a, shared step du_c
-      HIP_CHECK(hipMemcpyAsync(w.es_coef.p, coef.data(), (size_t)M * D8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(w.es_coef.p, coef.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
       if (nc > 0) HIP_CHECK(hipMemcpyAsync(w.duc.p, sol.data(), (size_t)nc * D8, hipMemcpyHostToDevice, s));
       launch_axpy_particle(w.kff.d(), w.es_kff2.d(), w.es_coef.d(), w.es_kff3.d(), (long long)N * u, (long long)nu, s);
       LQArgs a3 = a;
@@ -368,17 +426,38 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       launch_cost_dots(a, w.X.d(), w.U.d(), w.dX.d(), w.dU.d(), w.dX.d(), w.dU.d(), w.es_dots.d(), s);
       launch_step_to(w.X.d(), w.dX.d(), 1.0, w.es_Xt.d(), (long long)nx, s);
       launch_step_to(w.U.d(), w.dU.d(), 1.0, w.es_Ut.d(), (long long)nu, s);
-      launch_scp_residual(w.es_Xt.d(), w.X.d(), w.es_Ut.d(), w.U.d(), (long long)M * N, x, u, w.es_out2.d(), s, true);
+      launch_scp_residual(w.es_Xt.d(), w.X.d(), w.es_Ut.d(), w.U.d(), (long long)Ml * N, x, u, w.es_out2.d(), s, true);
       double stepmax = 0.0;
-      HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipMemcpyAsync(&stepmax, w.es_out2.p, D8, hipMemcpyDeviceToHost, s));
-      HIP_CHECK(hipStreamSynchronize(s));
+      if (!c->multi()) {
+        HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(&stepmax, w.es_out2.p, D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+      } else {  // [dots of every particle | largest step of every rank]
+        const size_t tot = (size_t)3 * M + world;
+        HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tot * D8, s));
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + 3 * off, w.es_dots.p, (size_t)3 * Ml * D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + 3 * M + c->rank, w.es_out2.p, D8, hipMemcpyDeviceToDevice, s));
+        allreduce(c, w.epi_gath.p, tot, ncclFloat64, ncclSum);
+        HIP_CHECK(hipMemcpyAsync(dots.data(), w.epi_gath.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + 3 * M, (size_t)world * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (int r = 0; r < world; r++) stepmax = (rk[r] > stepmax || rk[r] != rk[r]) ? rk[r] : stepmax;
+      }
       newton++;
       auto bar_at = [&](const double *Xe, const double *Ue) {  // barrier arrays + value + smallest slack at a point
         launch_bar_prep(Xe, Ue, has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
-                        w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, 1, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s, smode, sbeta);
-        HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
+                        w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, a.owner, w.part_sum.d(), w.part_max.d(), w.es_out2.d(), s, smode, sbeta);
+        if (!c->multi()) {
+          HIP_CHECK(hipMemcpyAsync(out2, w.es_out2.p, 2 * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipStreamSynchronize(s));
+          return;
+        }
+        HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, (size_t)2 * world * D8, s));
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + 2 * c->rank, w.es_out2.p, 2 * D8, hipMemcpyDeviceToDevice, s));
+        allreduce(c, w.epi_gath.p, (size_t)2 * world, ncclFloat64, ncclSum);
+        HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.p, (size_t)2 * world * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        combine_out2();
       };
       // backtracking: strictly inside the boxes, no increase of F beyond its round-off (t re-optimised at every trial point); a step
       // that is already tiny is taken in full as soon as it is feasible — F cannot resolve it
@@ -852,7 +931,7 @@ int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, pmpc_in
       st_s = lcone_smooth_body(c, p, q.barrier_mu, info, verbose, 1, sbeta);
     }
     if (st_s >= 0) return st_s;
-    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs one rank, boxes to smooth, M (Nc u)^2 <= 2e7, no fp32 storage, a compiled (xdim, udim) pair and — with slew penalties or particle weights — M = 1 (slew: symmetric costs, N >= 2, a compiled (xdim + udim, udim) pair)\n");
+    fprintf(stderr, "pmpc_hip: smooth_cstr = \"squareplus\" needs boxes to smooth, M (Nc u)^2 <= 2e7, no fp32 storage, a compiled (xdim, udim) pair and — with slew penalties or particle weights — M = 1 (slew: symmetric costs, N >= 2, a compiled (xdim + udim, udim) pair)\n");
     fill_nan_outputs(c, p);
     if (info) { memset(info, 0, sizeof(*info)); info->status = 2; }
     return 2;

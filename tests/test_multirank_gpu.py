@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 _group = [1000]
 
 
-def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None, options=None):
+def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None, options=None, smooth=None):
     import torch
 
     from pmpc_amd import _lib
@@ -39,7 +39,7 @@ def _solve_sharded(args, kw, Nc, world, repeats=1, cone=False, soc=None, options
                 s.rank, s.world = rank, world
             for key, val in (options or {}).items():
                 s.set_option(key, val)
-            opt = {}
+            opt = dict(smooth) if smooth else {}  # (smooth_alpha / smooth_cstr / smooth_beta of the cone objective)
             if "u_l" in kw:
                 opt.update(lu=dev(kw["u_l"]), uu=dev(kw["u_u"]))
             if "x_l" in kw:
@@ -195,6 +195,42 @@ def test_sharded_cone_path_with_ties_matches_single_rank(world, copies, others, 
     assert rel(X1, Xo) < 1e-6 and rel(U1, Uo) < 1e-6, (rel(X1, Xo), rel(U1, Uo))
     assert rel(Xw, X1) < 1e-8 and rel(Uw, U1) < 1e-8, (rel(Xw, X1), rel(Uw, U1))
     assert np.all(Uw[:, :Nc] == Uw[0:1, :Nc])
+
+
+@pytest.mark.parametrize("world,copies,others,Nc,alpha,seed", [(2, 3, 3, 1, 10.0, 906), (4, 5, 3, 1, 10.0, 910), (2, 3, 3, 2, 10.0, 506), (4, 3, 5, 1, 100.0, 908)])
+def test_sharded_smoothed_cone_objective_matches_single_rank_and_direct_program(world, copies, others, Nc, alpha, seed):
+    """Log-barrier smoothing of the cone objective (main.jl:246-262) on sharded particles: the Newton iteration's host side runs on gathered
+    per-particle scalars and condensed blocks, identically on every rank; `copies` identical cheapest particles (a tie on the threshold, each with
+    a fractional multiplier) spread over the ranks.  Same answer as one rank (1e-9) and as the direct cone program (1e-6); a second, warm solve too."""
+    from oracle import cone_oracle as co
+    from tests.test_cone_ties_gpu import tied_problem
+
+    args, kw = tied_problem(np.random.default_rng(seed), copies, others, 6, 4, 2, 0.4, Nc)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, smooth_alpha=alpha, **kw)
+    sm = dict(smooth_alpha=alpha)
+    X1, U1, _ = _solve_sharded(args, kw, Nc, 1, cone=True, smooth=sm)
+    Xw, Uw, infos = _solve_sharded(args, kw, Nc, world, repeats=2, cone=True, smooth=sm)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    assert rel(X1, Xo) < 1e-6 and rel(U1, Uo) < 1e-6, (rel(X1, Xo), rel(U1, Uo))
+    assert rel(Xw, X1) < 1e-9 and rel(Uw, U1) < 1e-9, (rel(Xw, X1), rel(Uw, U1))
+    assert np.all(Uw[:, :Nc] == Uw[0:1, :Nc])
+    assert len({i["ipm_iters"] for i in infos}) == 1 and all(i["fast_path"] == 1 for i in infos)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_squareplus_cone_objective_matches_single_rank_and_direct_program(world):
+    """smooth_cstr = "squareplus" (main.jl:265-279) on sharded particles: the same full-space Newton iteration with the hinge instead of the log."""
+    from oracle import cone_oracle as co
+    from tests.test_cone_ties_gpu import tied_problem
+
+    args, kw = tied_problem(np.random.default_rng(930 + world), 3, 5, 6, 4, 2, 0.4, 1)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=1, smooth_alpha=10.0, smooth_cstr="squareplus", smooth_beta=5.0, **kw)
+    sm = dict(smooth_alpha=10.0, smooth_cstr="squareplus", smooth_beta=5.0)
+    X1, U1, _ = _solve_sharded(args, kw, 1, 1, cone=True, smooth=sm)
+    Xw, Uw, _ = _solve_sharded(args, kw, 1, world, cone=True, smooth=sm)
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1.0)
+    assert rel(X1, Xo) < 1e-6 and rel(U1, Uo) < 1e-6, (rel(X1, Xo), rel(U1, Uo))
+    assert rel(Xw, X1) < 1e-9 and rel(Uw, U1) < 1e-9, (rel(Xw, X1), rel(Uw, U1))
 
 
 @pytest.mark.parametrize("Nc", [0, 1, -1])
