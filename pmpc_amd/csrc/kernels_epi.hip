@@ -90,35 +90,50 @@ __global__ void __launch_bounds__(256) k_bar_reduce(const double *part_val, cons
 // the particle's cost along d1).  One 256-thread block per particle.
 __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2,
                                                    const double *dU2, double *out) {
+  // The particle's vectors go to LDS once (with the regularisation terms taken on the way); then the cost blocks are STREAMED, one
+  // element per thread and pass in memory order:  a0 += Q[c, r] (x - x_ref)[c] d1[r],  a1 with d2[r],  a2 += Q[c, r] d1[c] d1[r].
+  // (A thread per row read its 12 doubles in a loop — 64 lanes x 96-byte stride per instruction: 186 us for the 260 MB of config D's
+  //  blocks, as long as a factor sweep; streamed: the same bytes at the rate of a copy.)
+  extern __shared__ double sv[];
   __shared__ double s0[256], s1[256], s2[256];
   const int i = blockIdx.x, tid = threadIdx.x, x = a.x, u = a.u, N = a.N;
   const size_t pb = (size_t)i * N;
+  double *xr = sv, *d1x = xr + N * x, *d2x = d1x + N * x, *ur = d2x + N * x, *d1u = ur + N * u, *d2u = d1u + N * u;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   for (int e = tid; e < N * x; e += 256) {
-    const int j = e / x, r = e - j * x;
-    const double *Qj = a.Q + (pb + j) * x * x;
-    const size_t o = (pb + j) * x;
-    double g = a.reg_x * (X[o + r] - a.X_prev[o + r]), h = a.reg_x * dX1[o + r];
-    for (int c = 0; c < x; c++) {  // (symmetric blocks on this path: row r of Q_j read as column r)
-      g += Qj[c + (size_t)x * r] * (X[o + c] - a.X_ref[o + c]);
-      h += Qj[c + (size_t)x * r] * dX1[o + c];
-    }
-    a0 += g * dX1[o + r];
-    a1 += g * dX2[o + r];
-    a2 += h * dX1[o + r];
+    const size_t o = pb * x + e;
+    const double xv = X[o], v1 = dX1[o], v2 = dX2[o], gp = a.reg_x * (xv - a.X_prev[o]);
+    xr[e] = xv - a.X_ref[o]; d1x[e] = v1; d2x[e] = v2;
+    a0 += gp * v1; a1 += gp * v2; a2 += a.reg_x * v1 * v1;
   }
   for (int e = tid; e < N * u; e += 256) {
-    const int j = e / u, r = e - j * u;
-    const double *Rj = a.R + (pb + j) * u * u;
-    const size_t o = (pb + j) * u;
-    double g = a.reg_u * (U[o + r] - a.U_prev[o + r]), h = a.reg_u * dU1[o + r];
-    for (int c = 0; c < u; c++) {
-      g += Rj[c + (size_t)u * r] * (U[o + c] - a.U_ref[o + c]);
-      h += Rj[c + (size_t)u * r] * dU1[o + c];
+    const size_t o = pb * u + e;
+    const double uv = U[o], v1 = dU1[o], v2 = dU2[o], gp = a.reg_u * (uv - a.U_prev[o]);
+    ur[e] = uv - a.U_ref[o]; d1u[e] = v1; d2u[e] = v2;
+    a0 += gp * v1; a1 += gp * v2; a2 += a.reg_u * v1 * v1;
+  }
+  __syncthreads();
+  {
+    const int xx = x * x, tot = N * xx;
+    const double *Qp = a.Q + pb * xx;
+    for (int e = tid; e < tot; e += 256) {
+      const int j = e / xx, rem = e - j * xx, r = rem / x, c = rem - r * x, b = j * x;  // (symmetric blocks on this path: row r read as column r)
+      const double q = Qp[e], t1 = d1x[b + r];
+      a0 = fma(q * xr[b + c], t1, a0);
+      a1 = fma(q * xr[b + c], d2x[b + r], a1);
+      a2 = fma(q * d1x[b + c], t1, a2);
     }
-    a0 += g * dU1[o + r];
-    a1 += g * dU2[o + r];
-    a2 += h * dU1[o + r];
+  }
+  {
+    const int uu = u * u, tot = N * uu;
+    const double *Rp = a.R + pb * uu;
+    for (int e = tid; e < tot; e += 256) {
+      const int j = e / uu, rem = e - j * uu, r = rem / u, c = rem - r * u, b = j * u;
+      const double q = Rp[e], t1 = d1u[b + r];
+      a0 = fma(q * ur[b + c], t1, a0);
+      a1 = fma(q * ur[b + c], d2u[b + r], a1);
+      a2 = fma(q * d1u[b + c], t1, a2);
+    }
   }
   s0[tid] = a0; s1[tid] = a1; s2[tid] = a2;
   __syncthreads();
@@ -178,7 +193,8 @@ void launch_bar_prep(const double *X, const double *U, const double *lx, const d
 }
 void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2, const double *dU2,
                       double *out, hipStream_t s) {
-  hipLaunchKernelGGL(k_cost_dots, dim3(a.M), dim3(256), 0, s, a, X, U, dX1, dU1, dX2, dU2, out);
+  const size_t lds = (size_t)3 * a.N * (a.x + a.u) * sizeof(double);  // (N (x + u) <= 2 300 inside the 64 KB next to the reduction arrays: N = 100 at x12 u4 is 1 600)
+  hipLaunchKernelGGL(k_cost_dots, dim3(a.M), dim3(256), lds, s, a, X, U, dX1, dU1, dX2, dU2, out);
 }
 void launch_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot, hipStream_t s) {
   hipLaunchKernelGGL(k_axpy_particle, dim3(grid_for(tot)), dim3(256), 0, s, a_, b_, coef, y, per, tot);

@@ -72,7 +72,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   // (M = 1: the epigraph row is degenerate — its multiplier is (1 - eps) k whatever t does — and the iteration is plain damped Newton on
   //  (1 - eps) J + the smoothing terms; taken for the squareplus hinge, which the interior-point iteration of the QP path does not know)
   if (p->weights || (p->flags & (PMPC_HAS_SLEW | PMPC_HAS_SLEW0 | PMPC_FORCE_GENERIC | PMPC_F32_MATRICES)) || M < (smode == 1 ? 1 : 2) ||
-      !(has_xb || has_ub) || !(mu_b > 0.0) || (double)M * nc * nc > 2e7)
+      !(has_xb || has_ub) || !(mu_b > 0.0) || (double)M * nc * nc > 2e7 || (size_t)3 * N * (x + u) * sizeof(double) > 56 * 1024 /* k_cost_dots keeps a particle's vectors in LDS */)
     return -1;
   const size_t nx = (size_t)Ml * N * x, nu = (size_t)Ml * N * u, D8 = sizeof(double);
   LQArgs a;
@@ -158,8 +158,10 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   // every row carries a rank-one term, F is smooth (the quadratic proximal term's clipping makes its second derivative jump between 0
   // and 1/rho — at config D the semismooth Newton iteration then flips a handful of rows in and out of the hinge for ever), and the
   // update l_i += v_i / rho sends the multiplier of a row below the threshold to zero geometrically.  `lam` holds the logits.
-  auto sigm = [](double w_) { return w_ >= 0.0 ? 1.0 / (1.0 + std::exp(-w_)) : std::exp(w_) / (1.0 + std::exp(w_)); };
-  auto softplus = [](double w_) { return w_ > 0.0 ? w_ + std::log1p(std::exp(-w_)) : std::log1p(std::exp(w_)); };
+  // (beyond |w| = 40 the exponential is below the last bit of 1: no libm call.  At config D all but a few dozen of the 4096 rows are
+  //  saturated at every evaluation, and the exponentials of solve_t / Fval were more than half of a Newton step's wall time)
+  auto sigm = [](double w_) { return w_ > 40.0 ? 1.0 : (w_ < -40.0 ? std::exp(w_) : (w_ >= 0.0 ? 1.0 / (1.0 + std::exp(-w_)) : std::exp(w_) / (1.0 + std::exp(w_)))); };
+  auto softplus = [](double w_) { return w_ > 40.0 ? w_ : (w_ < -40.0 ? std::exp(w_) : (w_ > 0.0 ? w_ + std::log1p(std::exp(-w_)) : std::log1p(std::exp(w_)))); };
   auto mult = [&](int i, const std::vector<double> &Jv, double t) { return cap * sigm(lam[i] + (Jv[i] - t) / rho); };
   double t_guess = std::numeric_limits<double>::quiet_NaN();
   auto solve_t = [&](const std::vector<double> &Jv) {  // sum_i m_i(J_i - t) = K  (smooth, strictly decreasing in t): safeguarded Newton
