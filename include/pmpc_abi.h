@@ -227,6 +227,10 @@ void pmpc_destroy(pmpc_ctx *ctx);
  *                                             from it instead of being swept again (0: never)
  *   as_perm_min_m    PMPC_AS_PERM_MIN_M    2048  from that many particles per rank a later round's launches take the UNSETTLED particles first: their long sweeps
  *                                             then spread one per SIMD instead of piling up where their indices fall (0: never)
+ *   cone_path        PMPC_CONE_PATH        0   cone objective with hard boxes: which body answers.  0: automatic (the order depends on what the context learnt
+ *                                             about the shape: free-particles body first where it worked before, else epigraph path, rank-based iteration,
+ *                                             free-particles body last); 1: free-particles body first; 2: epigraph path, free-particles body never; 3: the
+ *                                             rank-based weighted-QP iteration alone (two costs on the threshold at most)
  * Setting an option forgets the context's warm-start memory.  The reference has no counterpart (its solver settings travel in
  * `solver_settings`, pmpc/scp_mpc.py:45-66, and never reach the C ABI); kernel launch heuristics stay environment-only. */
 int pmpc_set_option(pmpc_ctx *ctx, const char *key, double value);

@@ -125,6 +125,7 @@ static const struct { const char *key, *env; double dflt; } kPmpcOptions[OPT_COU
     {"as_ckpt", "PMPC_AS_CKPT", 1},                // factor sweeps checkpoint their cost-to-go at stages 4, 8, 16, 32, ..; the later rounds' sweeps restart at the lowest checkpoint above the highest changed stage
     {"as_sens_min_m", "PMPC_AS_SENS_MIN_M", 3072}, // particles per rank from which the forward sweep records sensitivities to the shared step and settled particles of the later rounds are updated elementwise (one consensus stage; 0: never)
     {"as_perm_min_m", "PMPC_AS_PERM_MIN_M", 2048}, // particles per rank from which a later round's launches take the unsettled particles first (their long sweeps spread one per SIMD); 0: never
+    {"cone_path", "PMPC_CONE_PATH", 0},            // cone objective with hard boxes, which body answers: 0 automatic (what the context learnt about the shape decides the order), 1 free-particles body first, 2 epigraph path (free-particles body never), 3 rank-based weighted-QP iteration only
 };
 
 namespace pmpc_impl {

@@ -947,8 +947,12 @@ int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, pmpc_in
   // ranking iteration (measured, config B with Nc = N: 4200 it/s through the ranking, 280 through this path).
   const long long fkey = (((((((long long)M * 1000003 + (long long)p->N) * 131 + (long long)p->xdim) * 131 + (long long)p->udim) * 131 + p->Nc + 2) * 1000003 + (long long)p->cone_k + 1) * 4 +
                           ((p->flags & PMPC_HAS_XBOUNDS) ? 2 : 0) + ((p->flags & PMPC_HAS_UBOUNDS) ? 1 : 0));
-  const bool fp_applies = !(q.barrier_mu > 0.0) && c->opt[OPT_CONE_EPIGRAPH] != 0.0 && M > 1;
+  // (option cone_path: which body answers does not have to depend on what the context saw before — 1: the free-particles body first,
+  //  2: never, 3: the rank-based iteration alone; tests/test_cone_ties_gpu.py runs the same problems through each)
+  const int forced = (int)c->opt[OPT_CONE_PATH];
+  const bool fp_applies = !(q.barrier_mu > 0.0) && c->opt[OPT_CONE_EPIGRAPH] != 0.0 && M > 1 && forced != 2 && forced != 3;
   if ((p->flags & PMPC_COLD_START) || c->fp_key != fkey) { c->fp_key = fkey; c->fp_ok = -1; }
+  if (forced == 1) c->fp_ok = 1;
   if (fp_applies && c->fp_ok == 1) {
     const int st_f = lcone_free_particles_body(c, p, info, verbose);
     if (st_f >= 0) return st_f;
@@ -1024,7 +1028,7 @@ int lcone_body(pmpc_ctx *c, const pmpc_problem *p0, double smooth_alpha, pmpc_in
   // (sharded: every rank holds the multipliers of ALL particles, checks the gathered costs on the host and solves the same epigraph problem
   //  on the all-gathered quadratics: identical decisions everywhere, as for the rank-based iteration)
   const bool epi_multi = c->multi();
-  const bool epi_on = c->opt[OPT_CONE_EPIGRAPH] != 0.0 && !(q.barrier_mu > 0.0) && (double)M * ncv * ncv <= 2e7 && !(p->flags & PMPC_FORCE_GENERIC);
+  const bool epi_on = c->opt[OPT_CONE_EPIGRAPH] != 0.0 && forced != 3 && !(q.barrier_mu > 0.0) && (double)M * ncv * ncv <= 2e7 && !(p->flags & PMPC_FORCE_GENERIC);
   if (epi_on) {
     pmpc_problem qq = *p;
     qq.weights = nullptr;

@@ -97,7 +97,7 @@ struct Workspace {
 // that flips a switch) no longer depend on what the first solve of the process happened to read.
 enum PmpcOpt {
   OPT_AS_WARM, OPT_AS_SKIP, OPT_AS_DEFECT, OPT_AS_COLD_ROUNDS, OPT_POLISH_MU, OPT_WARM_START, OPT_CONE_AS, OPT_CONE_COLD_ROUNDS, OPT_XBOX_AS,
-  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_AS_CKPT, OPT_AS_SENS_MIN_M, OPT_AS_PERM_MIN_M, OPT_COUNT
+  OPT_SLEW_INCREMENT_BOXES, OPT_AS_FUSE_CTL, OPT_AS_WAVE_CONS, OPT_HOST_REUSE, OPT_WARN_SLOW_PATH, OPT_CONE_RANK_MEMORY, OPT_CONE_EPIGRAPH, OPT_COND_GROUPED, OPT_AS_FREEZE_TOL, OPT_AS_CKPT, OPT_AS_SENS_MIN_M, OPT_AS_PERM_MIN_M, OPT_CONE_PATH, OPT_COUNT
 };
 }  // namespace pmpc_impl
 using namespace pmpc_impl;

@@ -284,3 +284,47 @@ def test_squareplus_with_one_weighted_particle(co, wgt, slew):
     assert st == 0
     assert _rel(X.cpu().numpy(), Xo) <= TOL and _rel(U.cpu().numpy(), Uo) <= TOL
     s.close()
+
+
+def _device_cone_solve(args, kw, Nc, options, repeats=1):
+    """One context with the given options, `repeats` solves of the same problem (the later ones see what the context learnt); no assertion on the status."""
+    import torch
+
+    from pmpc_amd.device import DeviceSolver
+
+    x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
+    dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    T = lambda a: dev(np.swapaxes(a, -1, -2))
+    s = DeviceSolver(0)
+    for key, val in options.items():
+        s.set_option(key, val)
+    out = []
+    for _ in range(repeats):
+        X, U, status = s.lcone_solve(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref), U_ref=dev(U_ref),
+                                     reg_x=kw["reg_x"], reg_u=kw["reg_u"], Nc=Nc, symmetric_cost=True, lu=dev(kw["u_l"]), uu=dev(kw["u_u"]))
+        s.sync()
+        out.append((X.cpu().numpy(), U.cpu().numpy(), status, dict(s.last_info)))
+    s.close()
+    return out
+
+
+@pytest.mark.parametrize("copies,others,Nc,bu,seed", [(2, 4, 1, 0.4, 1231), (5, 3, 1, 0.4, 507), (4, 3, 2, 0.4, 407), (4, 3, -1, 5.0, 1250), (2, 5, -1, 5.0, 1232)])
+def test_every_body_of_the_cone_path_forced_on_the_same_problem(co, copies, others, Nc, bu, seed):
+    """Which body of `lcone_body` answers a hard-box call depends, by default, on what the context learnt about the shape (`fp_key`): option
+    `cone_path` takes that memory out — 1 free-particles body first, 2 epigraph path, 3 the rank-based iteration alone.  The same problem
+    through each, twice on one context: every body that answers (status 0) gives the direct program's optimum; a body that cannot (the
+    rank-based iteration with more than two costs on the threshold) says so with a non-zero status and NaN outputs, never with another
+    answer; the automatic order and the forced ones agree."""
+    args, kw = tied_problem(np.random.default_rng(seed), copies, others, 6, 4, 2, bu, Nc)
+    Xo, Uo = co.lcone_direct_py(*args, Nc=Nc, **kw)
+    answered = {}
+    for path in (0, 1, 2, 3):
+        for rep, (X, U, status, info) in enumerate(_device_cone_solve(args, kw, Nc, {"cone_path": path}, repeats=2)):
+            if status == 0:
+                assert _rel(X, Xo) <= TOL and _rel(U, Uo) <= TOL, (path, rep, _rel(X, Xo), _rel(U, Uo))
+                answered[path] = answered.get(path, 0) + 1
+            else:
+                assert np.all(np.isnan(X)) and np.all(np.isnan(U)), (path, rep, status)
+    assert answered.get(0) == 2 and answered.get(1) == 2 and answered.get(2) == 2, answered  # (only the rank-based iteration alone may decline)
+    if copies <= 2:
+        assert answered.get(3) == 2, answered
