@@ -1815,7 +1815,8 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         // state-row rounds switched off: mu 7.9e-10 -> 1.3e-12 -> NaN).  The last iterate with mu <= 1e-10 mu_peak and small
         // residuals is a certified near-optimal point (duality gap <= n mu): returned instead of a failed solve.
         if (late_mu >= 0.0 && mu_target == 0.0) {
-          if (verbose) printf("pmpc_hip: interior-point iteration broke down numerically at iteration %d: returning the iterate of mu %.3e\n", it, late_mu);
+          // (said on stderr whatever `verbose` is: the status is 0, and only info.mu tells this iterate from a converged one)
+          fprintf(stderr, "pmpc_hip: note: interior-point iteration broke down numerically at iteration %d; returning the kept iterate (complementarity %.3e, convergence test %.3e)\n", it, late_mu, tol * mu_peak);
           HIP_CHECK(hipMemcpyAsync(w.X.p, w.lateX.p, nx * D8, hipMemcpyDeviceToDevice, s));
           HIP_CHECK(hipMemcpyAsync(w.U.p, w.lateU.p, nu * D8, hipMemcpyDeviceToDevice, s));
           HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
@@ -1871,7 +1872,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         // out of iterations between the kept iterate (mu <= 1e-10 mu_peak, small residuals) and the convergence test: that iterate
         // is a certified near-optimal point, returned as the breakdown case above returns it — not a failed solve
         if (late_mu >= 0.0 && mu_target == 0.0) {
-          if (verbose) printf("pmpc_hip: interior-point iteration stalled above the tolerance: returning the iterate of mu %.3e\n", late_mu);
+          fprintf(stderr, "pmpc_hip: note: interior-point iteration out of iterations above its tolerance; returning the kept iterate (complementarity %.3e, convergence test %.3e)\n", late_mu, tol * mu_peak);
           HIP_CHECK(hipMemcpyAsync(w.X.p, w.lateX.p, nx * D8, hipMemcpyDeviceToDevice, s));
           HIP_CHECK(hipMemcpyAsync(w.U.p, w.lateU.p, nu * D8, hipMemcpyDeviceToDevice, s));
           inf.mu = late_mu;
