@@ -132,3 +132,27 @@ def test_host_abi_notices_in_place_changes_of_arrays_it_did_not_resend(oracle):
         Xo, Uo = oracle.lqp_solve_py(*args, Nc=1, **kw)
         X, U = backend.lqp_solve(*a)
         assert rel(X, Xo) < 1e-7 and rel(U, Uo) < 1e-7, step
+
+
+# (M, N, x, u, Nc, u-bound): the dense consensus system has Nc u unknowns — 17 .. 255 of them go through k_cons_solve_reg
+DENSE_CONS = [(3, 9, 4, 2, -1, 0.3), (3, 16, 4, 2, -1, 0.3), (3, 17, 4, 2, -1, 0.3), (2, 27, 5, 3, -1, 0.4), (3, 40, 4, 2, 33, 0.3),
+              (2, 50, 12, 4, -1, 0.4), (2, 52, 4, 2, -1, 0.3), (2, 64, 2, 1, -1, 0.5), (2, 63, 12, 4, -1, 0.5), (2, 70, 12, 4, 64, 0.5)]
+
+
+@pytest.mark.parametrize("case", DENSE_CONS, ids=[f"nc={(c[1] if c[4] < 0 else c[4]) * c[3]}-{c}" for c in DENSE_CONS])
+def test_dense_consensus_systems_of_every_panel_count(case, oracle):
+    """Several shared stages with boxes tight enough that shared controls are held (1e30 on the diagonal of the consensus system): 18 .. 256
+    unknowns — whole and ragged last panels, both instantiations of the register-resident solve (up to 12 / 17 blocks per wave), and one size
+    beyond it (256: the blocked factorisation in global memory) — against the oracle; cold and warm (the warm solve re-factors with the
+    accepted set held)."""
+    from pmpc_amd import backend
+
+    M, N, x, u, Nc, bu = case
+    args, kw = rand_problem(np.random.default_rng(7000 + N * u + M), M, N, x, u, bu)
+    Xo, Uo = oracle.lqp_solve_py(*args, Nc=Nc, **kw)
+    k = N if Nc < 0 else Nc
+    assert np.any(np.abs(np.abs(Uo[0, :k]) - bu) <= 1e-9), "no shared control on its bound: tighten the box"
+    for rep in ("cold", "warm"):
+        X, U = backend.lqp_solve(*abi_args(args, kw, Nc))
+        assert _rel(X, Xo) <= TOL and _rel(U, Uo, 1.0) <= TOL, (rep, _rel(X, Xo), _rel(U, Uo, 1.0))
+        assert np.all(U[:, :k] == U[0:1, :k])
