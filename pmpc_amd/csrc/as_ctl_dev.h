@@ -83,4 +83,28 @@ __device__ inline void as_ctl_block(AsCtl *ctl, const int *cnt_part, int M, cons
   }
 }
 
+// launch order of a later round: the unsettled particles first, index order inside both groups (one 1024-thread block; k_as_perm, or
+// behind as_ctl_block in the extra block of k_cons_small — then the round's factor sweep, which runs before that launch, still has
+// the order of the round before: any permutation is a correct one, and the unsettled set changes little from round to round)
+__device__ inline void as_perm_block(const int *settled, int M, int *perm) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x, per = (M + 1023) / 1024, lo = t * per, hi = min(M, lo + per);
+  int n = 0;
+  for (int i = lo; i < hi; i++) n += settled[i] ? 0 : 1;
+  cnt[t] = n;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
+    const int v = t >= o ? cnt[t - o] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  const int total = cnt[1023];
+  int pu = cnt[t] - n, ps = total + lo - pu;  // first slots of this thread's unsettled / settled particles
+  for (int i = lo; i < hi; i++) {
+    if (settled[i]) perm[ps++] = i;
+    else perm[pu++] = i;
+  }
+}
+
 }  // namespace

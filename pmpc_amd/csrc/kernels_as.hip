@@ -1024,24 +1024,7 @@ __global__ void __launch_bounds__(1024) k_as_ctl(AsCtl *ctl, const int *cnt_part
 // One block of 1024 threads: counts, exclusive scan, scatter.
 __global__ void __launch_bounds__(1024) k_as_perm(const int *settled, int M, int *perm, const int *done) {
   if (done && *done) return;
-  __shared__ int cnt[1024];
-  const int t = threadIdx.x, per = (M + 1023) / 1024, lo = t * per, hi = min(M, lo + per);
-  int n = 0;
-  for (int i = lo; i < hi; i++) n += settled[i] ? 0 : 1;
-  cnt[t] = n;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan
-    const int v = t >= o ? cnt[t - o] : 0;
-    __syncthreads();
-    cnt[t] += v;
-    __syncthreads();
-  }
-  const int total = cnt[1023];
-  int pu = cnt[t] - n, ps = total + lo - pu;  // first slots of this thread's unsettled / settled particles
-  for (int i = lo; i < hi; i++) {
-    if (settled[i]) perm[ps++] = i;
-    else perm[pu++] = i;
-  }
+  as_perm_block(settled, M, perm);
 }
 
 // CONE instantiations of the two sweeps: every compiled (xdim, udim) pair with udim >= 2 (ten more kernels each)

@@ -1006,6 +1006,10 @@ __global__ void __launch_bounds__(1024) k_cons_small(const double *Hc_part, cons
   const int nblk = pend.ctl ? (int)gridDim.x - 1 : (int)gridDim.x;
   if (pend.ctl && (int)blockIdx.x == nblk) {
     as_ctl_block(pend.ctl, pend.cnt_part, pend.M, pend.fail, 1, 1, 0, pend.mirror, pend.mirror_seq, pend.seq, nullptr, pend.viol, pend.open_part);
+    if (pend.perm) {  // (uniform) the launch order of this round's forward sweep, from the flags the round before left
+      __syncthreads();
+      as_perm_block(pend.settled, pend.M, pend.perm);
+    }
     return;
   }
   const int tid = threadIdx.x, e = tid & 31, pl = tid >> 5;

@@ -220,6 +220,8 @@ struct AsCtlCall {
   unsigned long long seq;
   const double *viol;
   const int *open_part;  // per-particle open stage cones (null: none)
+  const int *settled;    // with perm: the launch order of the round this call rides in (as_perm_block; null: none)
+  int *perm;
 };
 int launch_cons_partials(const double *Hc_part, const double *gc_part, int M, int nc, double *tmp, const AsCtlCall &pend,
                          hipStream_t s);  // -> number of partials

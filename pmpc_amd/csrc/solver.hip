@@ -1334,8 +1334,23 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
         b.as_perm = nullptr;
         if (skip && perm_min_m > 0 && M >= perm_min_m && b.as_T) {  // (with every particle sweeping the index order is the better one: memory locality)
           ProfScope pp(c, 5);
-          w.as_perm.ensure((size_t)M * sizeof(int));
-          launch_as_perm((const int *)w.as_settled.p, M, (int *)w.as_perm.p, &ctl->done, s);
+          if (w.as_perm.ensure((size_t)M * sizeof(int)) || w.as_perm_m != M) {  // (what the buffer holds must be a permutation of 0 .. M-1 at any time)
+            std::vector<int> id(M);
+            for (int q_ = 0; q_ < M; q_++) id[q_] = q_;
+            HIP_CHECK(hipMemcpyAsync(w.as_perm.p, id.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            w.as_perm_m = M;
+          }
+          static const bool perm_fused = !(getenv("PMPC_AS_PERM_FUSED") && atoi(getenv("PMPC_AS_PERM_FUSED")) == 0);  // (A/B switch)
+          if (c->as_pend.ctl && perm_fused) {
+            // the round control of the round before rides in this round's consensus-partials launch (between the factor and the forward
+            // sweep): the order is computed there, one launch less per round — the forward sweep gets it fresh, the factor sweep (short
+            // restarted sweeps) runs in the order of the round before
+            c->as_pend.settled = (const int *)w.as_settled.p;
+            c->as_pend.perm = (int *)w.as_perm.p;
+          } else {
+            launch_as_perm((const int *)w.as_settled.p, M, (int *)w.as_perm.p, &ctl->done, s);
+          }
           b.as_perm = (const int *)w.as_perm.p;
         }
         const bool last = k == batch - 1;
@@ -1372,7 +1387,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
           // the decision about this round rides in the next round's consensus-partials launch (structured_solve): its factor
           // sweep does not need it (settled particles leave it at once), its forward sweep sees it
           c->as_pend = AsCtlCall{ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq,
-                                 b.as_viol, open_part};
+                                 b.as_viol, open_part, nullptr, nullptr};
         } else {
           launch_as_ctl(ctl, (const int *)w.as_cntp.p, M, (const int *)w.fail.p, 1, 1, last ? 1 : 0, &c->mirror_dev->ctl, &c->mirror_dev->as_seq, c->as_seq, s,
                         nullptr, b.as_viol, open_part);

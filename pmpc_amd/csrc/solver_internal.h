@@ -71,7 +71,8 @@ struct Workspace {
   DevBuf lateX, lateU;  // last interior-point iterate with mu <= 1e-10 mu_peak and small residuals (kept against a numerical breakdown at mu ~ 1e-12)
   long long warm_key = -1;
   double warm_mu = 0.0;  // barrier parameter the remembered iterate belongs to (0: the early iterate of a hard-constrained solve)
-  DevBuf as_perm;  // later rounds: particle order of the launches (unsettled first)
+  DevBuf as_perm;  // later rounds: particle order of the launches (unsettled first); as_perm_m: the M it is a permutation for
+  int as_perm_m = -1;
   DevBuf as_T;  // forward sweep's sensitivity records (one consensus stage: settled particles of the later rounds are updated elementwise)
   DevBuf as_ck, as_jhi, ck_stat;  // checkpoints of the factor sweeps' cost-to-go + highest changed stage per particle (restart of the later rounds' sweeps)
   DevBuf as_act, as_cnt, as_cntp, as_settled, as_ctl, as_delta, as_viol;  // active-set iteration: status per bounded control (int), counters,
