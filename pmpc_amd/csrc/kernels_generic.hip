@@ -1263,11 +1263,12 @@ void launch_reduce_particles(const double *src, double *tmp, double *dst, int M,
 void launch_cons_solve(double *Hc, double *Lc, const double *gc, double *duc, int nc, bool factor, int *fail,
                        hipStream_t s) {
   static const bool reg_on = !(getenv("PMPC_CONS_REG") && atoi(getenv("PMPC_CONS_REG")) == 0);
-  if (reg_on && factor && cons_reg_fits(nc)) {
+  // (117 KB of dynamic LDS: above the 64 KB a kernel gets without asking — where the runtime refuses, the older variants below serve)
+  static const bool reg_lds_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void *>(k_cons_solve_reg<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONS_REG_LDS) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(k_cons_solve_reg<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONS_REG_LDS) == hipSuccess;
+  if (reg_on && reg_lds_ok && factor && cons_reg_fits(nc)) {
     const int nb = (nc + 1 + 15) / 16, slots = (nb * (nb + 1) / 2 + CONS_REG_NW - 1) / CONS_REG_NW;
-    static const hipError_t attr12 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cons_solve_reg<12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONS_REG_LDS);
-    static const hipError_t attr17 = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cons_solve_reg<17>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONS_REG_LDS);
-    (void)attr12; (void)attr17;
     if (slots <= 12) hipLaunchKernelGGL(k_cons_solve_reg<12>, dim3(1), dim3(CONS_REG_NTH), CONS_REG_LDS, s, (const double *)Hc, Lc, gc, duc, nc, fail);
     else hipLaunchKernelGGL(k_cons_solve_reg<17>, dim3(1), dim3(CONS_REG_NTH), CONS_REG_LDS, s, (const double *)Hc, Lc, gc, duc, nc, fail);
     return;
