@@ -266,7 +266,8 @@ dev = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, devic
 T = lambda a: dev(np.swapaxes(a, -1, -2))
 worst = 0.0
 for k, (M, N, x, u, Nc, kind) in enumerate([(8, 9, 12, 4, 1, "qp"), (6, 8, 5, 3, -1, "qp"), (8, 7, 4, 2, 3, "qp"), (8, 9, 12, 4, 0, "qp"),
-                                            (40, 6, 4, 2, 1, "cone"), (6, 7, 5, 3, 1, "soc")]):
+                                            (40, 6, 4, 2, 1, "cone"), (6, 7, 5, 3, 1, "soc"), (12, 6, 4, 2, 1, "smooth"), (10, 6, 4, 2, 2, "smooth"),
+                                            (8, 6, 4, 2, 1, "squareplus")]):
     args, kw = rand_problem(np.random.default_rng(500 + k), M, N, x, u, 0.4 if kind != "soc" else 0.6)
     x0, f, fx, fu, X_prev, U_prev, Q, R, X_ref, U_ref = args
     opt = dict(f=dev(f), fx=T(fx), fu=T(fu), X_prev=dev(X_prev), U_prev=dev(U_prev), Q=T(Q), R=T(R), X_ref=dev(X_ref),
@@ -274,10 +275,14 @@ for k, (M, N, x, u, Nc, kind) in enumerate([(8, 9, 12, 4, 1, "qp"), (6, 8, 5, 3,
     if kind == "soc":
         W = np.zeros((2, 3)); W[0, 1] = W[1, 2] = 1.0
         opt.update(soc_W=dev(W), soc_w0=dev(np.zeros(2)), soc_v=dev(np.array([0.5, 0, 0])), soc_v0=0.05, soc_u_interior=dev(np.array([0.2, 0, 0])))
+    if kind == "smooth":  # log-barrier smoothing of the cone objective: the gathers of lcone_smooth_body (all-reduce of zero-padded tables) and its broadcast
+        opt.update(smooth_alpha=10.0)
+    if kind == "squareplus":
+        opt.update(smooth_alpha=10.0, smooth_cstr="squareplus", smooth_beta=5.0)
     res = []
     for s in (plain, rccl):
         for rep in range(2):  # the second solve is warm-started and reuses the broadcast consensus bounds
-            X, U, status = getattr(s, {"qp": "lqp_solve", "cone": "lcone_solve", "soc": "lsoc_solve"}[kind])(static_cons_bounds=rep > 0, **opt)
+            X, U, status = getattr(s, {"qp": "lqp_solve", "cone": "lcone_solve", "soc": "lsoc_solve", "smooth": "lcone_solve", "squareplus": "lcone_solve"}[kind])(static_cons_bounds=rep > 0, **opt)
             s.sync()
             assert status == 0, (kind, status)
         res.append((X.cpu().numpy(), U.cpu().numpy()))
