@@ -61,6 +61,14 @@ def test_fuzz_sharded_equals_one_rank():
     assert m and int(m.group(3)) == 0 and int(m.group(2)) < 60 and float(m.group(4)) <= 1e-8, last
 
 
+def test_fuzz_sharded_smoothed_cone_objective_equals_one_rank():
+    """Log-barrier / squareplus smoothing of the cone objective on 2 .. 4 mock ranks against one rank (the Newton iteration's host side runs on
+    gathered per-particle data, identically on every rank)."""
+    last = _run("fuzz_sharded.py", 61, 120, "smooth")[-1]
+    m = re.search(r"(\d+) cases \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(3)) == 0 and int(m.group(2)) < 25 and float(m.group(4)) <= 1e-8, last
+
+
 def test_fuzz_sequence_of_unrelated_problems_on_one_context():
     last = _run("fuzz_sequence.py", 41, 150)[-1]
     m = re.search(r"(\d+) calls \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)

@@ -14,6 +14,7 @@ run tools/fuzz/fuzz_state_rows_cone.py $((b+7)) 40
 run tools/fuzz/fuzz_cone.py $((b+8)) 100 24 6
 run tools/fuzz/fuzz_cone.py $((b+9)) 60 300 5
 run tools/fuzz/fuzz_sharded.py $((b+10)) 400
+run tools/fuzz/fuzz_sharded.py $((b+14)) 200 smooth
 run tools/fuzz/fuzz_sequence.py $((b+11)) 400
 run tools/fuzz/fuzz_scp_loop.py $((b+12)) 300
 run tools/fuzz/fuzz_freeze.py $((b+13)) 100 5
