@@ -287,13 +287,16 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   double dl_prev = 1e300, dl_last = 1e300, rho_floor = 0.0;
   std::vector<double> lam_before(M), dlam_prev(M, 0.0), dlam_cur(M, 0.0);
   bool have_prev_delta = false;
+  double quad_c = 1e3;  // contraction constant of the Newton steps in their quadratic regime, |step_{n+1}| ~ quad_c |step_n|^2: the largest ratio seen in this solve
+  static const bool quad_on = !(getenv("PMPC_SM_QUAD") && atoi(getenv("PMPC_SM_QUAD")) == 0);  // (A/B switch)
   double r_prev = -1.0, rho_at_prev_delta = -1.0;
   int since_extrap = 2;
   for (int outer = 0; outer < 500 && !converged; outer++) {
     bool inner_ok = false;
     const bool last_stage = true;
-    const double step_tol = std::max(1e-9, std::min(1e-5, 1e-3 * dl_prev));  // (the inner problems are solved as sharply as the multipliers are known)
+    const double step_tol = std::max(1e-9, std::min(1e-5, 1e-3 * dl_prev));  // (the inner problems are solved as sharply as the multipliers are known; looser — 1e-1 dl, cap 1e-3 — measured: no fewer Newton steps)  // (the inner problems are solved as sharply as the multipliers are known)
     int n_damped = 0, n_cut = 0;
+    double s_prev = -1.0;  // the previous full Newton step of this inner solve
     for (int it = 0; it < 25; it++) {
       t = solve_t(J);
       Fcur = Fval(J, t, bval);
@@ -496,6 +499,16 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
                           newton, al, stepmax * al, Fcur, dF, t, (int)std::count_if(mu.begin(), mu.end(), [&](double v) { return v > 1e-6 && v < cap - 1e-6; }));
       if (al < 0.2) n_damped++;
       if (al == 1.0 && stepmax <= step_tol) { inner_ok = true; break; }
+      // Full steps in the quadratic regime: after a step s the iterate is off by ~ quad_c s^2.  Once that is a tenth of the tolerance the
+      // step that would only confirm it (1e-9 .. 1e-14 in the traces of config D: a third of all Newton steps, two factor sweeps each) is
+      // not taken.  quad_c: measured on this solve's own consecutive full steps (the largest ratio seen; 1e3 until there is one).
+      if (quad_on && al == 1.0) {
+        if (s_prev > 0.0 && s_prev < 1e-2 && stepmax < s_prev) quad_c = std::max(quad_c == 1e3 ? 1.0 : quad_c, std::min(1e6, stepmax / (s_prev * s_prev)));
+        if (stepmax <= 1e-3 && 10.0 * quad_c * stepmax * stepmax <= step_tol) { inner_ok = true; break; }
+        s_prev = stepmax;
+      } else {
+        s_prev = -1.0;
+      }
       // a hinge too narrow for this start shows at once: step after step cut to a few per cent (every Newton step crosses kinks).  Four of
       // those in a row end the attempt — the remaining twenty would be spent the same way (measured at config D: 50 such steps before the
       // width was right) — and the hinge widens from where the iterate is now
