@@ -116,7 +116,19 @@ __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, co
   {
     const int xx = x * x, tot = N * xx;
     const double *Qp = a.Q + pb * xx;
-    for (int e = tid; e < tot; e += 256) {
+    int e = tid;
+    for (; e + 768 < tot; e += 1024) {  // (four loads in flight per thread: one at a time is latency-bound)
+      const double qv[4] = {Qp[e], Qp[e + 256], Qp[e + 512], Qp[e + 768]};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ee = e + 256 * k, j = ee / xx, rem = ee - j * xx, r = rem / x, c = rem - r * x, b = j * x;
+        const double q = qv[k], t1 = d1x[b + r];
+        a0 = fma(q * xr[b + c], t1, a0);
+        a1 = fma(q * xr[b + c], d2x[b + r], a1);
+        a2 = fma(q * d1x[b + c], t1, a2);
+      }
+    }
+    for (; e < tot; e += 256) {
       const int j = e / xx, rem = e - j * xx, r = rem / x, c = rem - r * x, b = j * x;  // (symmetric blocks on this path: row r read as column r)
       const double q = Qp[e], t1 = d1x[b + r];
       a0 = fma(q * xr[b + c], t1, a0);
