@@ -377,6 +377,7 @@ void pmpc_destroy(pmpc_ctx *c) {
   for (DevBuf &b : c->stage) b.release();
   (void)hipHostFree(c->mirror);
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->sm_pinned) (void)hipHostFree(c->sm_pinned);
   c->host_flags.release();
   free(c->sc_host);
   free(c->fail_host);

@@ -140,8 +140,23 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
     return status;
   };
   // ---- host pieces ---------------------------------------------------------------------------------------------------------
-  std::vector<double> J(M), Jt(M), lam(M, std::log((K / (double)M) / (cap - K / (double)M))), mu(M), sig(M), coef(M), Hh((size_t)M * std::max(nc * nc, 1)), gb((size_t)M * std::max(nc, 1)),
-      ga((size_t)M * std::max(nc, 1)), dots((size_t)3 * M);
+  std::vector<double> J(M), Jt(M), lam(M, std::log((K / (double)M) / (cap - K / (double)M))), mu(M), sig(M);
+  // the arrays the device copies into / out of every Newton step: pinned, kept with the context
+  struct Span {
+    double *p;
+    double &operator[](size_t i) const { return p[i]; }
+    double *data() const { return p; }
+  };
+  const size_t n_H = (size_t)M * std::max(nc * nc, 1), n_g = (size_t)M * std::max(nc, 1), n_pin = n_H + 2 * n_g + (size_t)3 * M + (size_t)M;
+  if (c->sm_pinned_bytes < n_pin * D8) {
+    if (c->sm_pinned) HIP_WARN(hipHostFree(c->sm_pinned));
+    c->sm_pinned = nullptr;
+    c->sm_pinned_bytes = 0;
+    HIP_CHECK(hipHostMalloc(&c->sm_pinned, n_pin * D8, hipHostMallocDefault));
+    c->sm_pinned_bytes = n_pin * D8;
+  }
+  double *pin = (double *)c->sm_pinned;
+  const Span Hh{pin}, gb{pin + n_H}, ga{pin + n_H + n_g}, dots{pin + n_H + 2 * n_g}, coef{pin + n_H + 2 * n_g + (size_t)3 * M};
   double rho = 1.0, out2[2] = {0.0, 0.0};
   std::vector<double> rk((size_t)4 * world);  // per-rank scalars as gathered
   auto combine_out2 = [&]() {  // rk = (barrier value, smallest slack) per rank -> out2, summed / minimised in rank order

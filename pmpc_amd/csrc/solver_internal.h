@@ -149,6 +149,8 @@ struct pmpc_ctx {
   // staging for the host-pointer ABI
   DevBuf stage[19], stage_t[4];
   void *pinned = nullptr;  // host-coherent bounce buffer of the host-pointer ABI (threaded memcpy -> DMA)
+  void *sm_pinned = nullptr;  // pinned host arrays of the smoothed cone objective's Newton iteration (its per-step gathers: pageable targets cost ~0.1 ms a step)
+  size_t sm_pinned_bytes = 0;
   size_t pinned_bytes = 0;
   struct StagedChunk { void *dst; size_t bytes, off; };
   std::vector<StagedChunk> staged;  // what the bounce buffer (and the device staging buffers) hold from the previous call
