@@ -88,8 +88,10 @@ __global__ void __launch_bounds__(256) k_bar_reduce(const double *part_val, cons
 // Per particle: the cost gradient a_i = grad J_i at (X, U) (qp_utils.jl:60-162: Q (x - x_ref) + reg_x (x - x_prev), the same for the
 // controls) against two directions: out[3 i + 0] = a_i . d1, out[3 i + 1] = a_i . d2, out[3 i + 2] = d1' (grad^2 J_i) d1 (the curvature of
 // the particle's cost along d1).  One 256-thread block per particle.
+// bx / bu (null: off): out[3 i + 1] becomes  b_i . d1  instead of  a_i . d2,  b_i = pw_i a_i + (bx; bu)  the right-hand side of the particle's
+// Newton system — with d1 = -K^-1 a_i that is  a_i . (-K^-1 b_i)  by symmetry: the step for b_i itself is then not needed (one forward sweep less)
 __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2,
-                                                   const double *dU2, double *out) {
+                                                   const double *dU2, double *out, const double *bx, const double *bu) {
   // The particle's vectors go to LDS once (with the regularisation terms taken on the way); then the cost blocks are STREAMED, one
   // element per thread and pass in memory order:  a0 += Q[c, r] (x - x_ref)[c] d1[r],  a1 with d2[r],  a2 += Q[c, r] d1[c] d1[r].
   // (A thread per row read its 12 doubles in a loop — 64 lanes x 96-byte stride per instruction: 186 us for the 260 MB of config D's
@@ -98,19 +100,23 @@ __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, co
   __shared__ double s0[256], s1[256], s2[256];
   const int i = blockIdx.x, tid = threadIdx.x, x = a.x, u = a.u, N = a.N;
   const size_t pb = (size_t)i * N;
+  const bool rhs = bx != nullptr || bu != nullptr;
+  double wdot = 0.0;
   double *xr = sv, *d1x = xr + N * x, *d2x = d1x + N * x, *ur = d2x + N * x, *d1u = ur + N * u, *d2u = d1u + N * u;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   for (int e = tid; e < N * x; e += 256) {
     const size_t o = pb * x + e;
-    const double xv = X[o], v1 = dX1[o], v2 = dX2[o], gp = a.reg_x * (xv - a.X_prev[o]);
+    const double xv = X[o], v1 = dX1[o], v2 = rhs ? 0.0 : dX2[o], gp = a.reg_x * (xv - a.X_prev[o]);
     xr[e] = xv - a.X_ref[o]; d1x[e] = v1; d2x[e] = v2;
     a0 += gp * v1; a1 += gp * v2; a2 += a.reg_x * v1 * v1;
+    if (bx) wdot += bx[o] * v1;
   }
   for (int e = tid; e < N * u; e += 256) {
     const size_t o = pb * u + e;
-    const double uv = U[o], v1 = dU1[o], v2 = dU2[o], gp = a.reg_u * (uv - a.U_prev[o]);
+    const double uv = U[o], v1 = dU1[o], v2 = rhs ? 0.0 : dU2[o], gp = a.reg_u * (uv - a.U_prev[o]);
     ur[e] = uv - a.U_ref[o]; d1u[e] = v1; d2u[e] = v2;
     a0 += gp * v1; a1 += gp * v2; a2 += a.reg_u * v1 * v1;
+    if (bu) wdot += bu[o] * v1;
   }
   __syncthreads();
   {
@@ -147,13 +153,13 @@ __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, co
       a2 = fma(q * d1u[b + c], t1, a2);
     }
   }
-  s0[tid] = a0; s1[tid] = a1; s2[tid] = a2;
+  s0[tid] = a0; s1[tid] = rhs ? wdot : a1; s2[tid] = a2;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) { s0[tid] += s0[tid + o]; s1[tid] += s1[tid + o]; s2[tid] += s2[tid + o]; }
     __syncthreads();
   }
-  if (tid == 0) { out[3 * i] = s0[0]; out[3 * i + 1] = s1[0]; out[3 * i + 2] = s2[0]; }
+  if (tid == 0) { out[3 * i] = s0[0]; out[3 * i + 1] = rhs ? fma(a.pw ? a.pw[i] : 1.0, s0[0], s1[0]) : s1[0]; out[3 * i + 2] = s2[0]; }
 }
 
 // y[i, :] = a[i, :] + coef[i] * b[i, :]   (per-particle scalar; `per` entries per particle)
@@ -204,9 +210,9 @@ void launch_bar_prep(const double *X, const double *U, const double *lx, const d
   hipLaunchKernelGGL(k_bar_reduce, dim3(1), dim3(256), 0, s, (const double *)part_val, (const double *)part_min, (int)G, out2);
 }
 void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2, const double *dU2,
-                      double *out, hipStream_t s) {
+                      double *out, hipStream_t s, const double *bx, const double *bu) {
   const size_t lds = (size_t)3 * a.N * (a.x + a.u) * sizeof(double);  // (N (x + u) <= 2 300 inside the 64 KB next to the reduction arrays: N = 100 at x12 u4 is 1 600)
-  hipLaunchKernelGGL(k_cost_dots, dim3(a.M), dim3(256), lds, s, a, X, U, dX1, dU1, dX2, dU2, out);
+  hipLaunchKernelGGL(k_cost_dots, dim3(a.M), dim3(256), lds, s, a, X, U, dX1, dU1, dX2, dU2, out, bx, bu);
 }
 void launch_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot, hipStream_t s) {
   hipLaunchKernelGGL(k_axpy_particle, dim3(grid_for(tot)), dim3(256), 0, s, a_, b_, coef, y, per, tot);

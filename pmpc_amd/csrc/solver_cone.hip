@@ -328,7 +328,8 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       launch_grad_prep(a, s);
       launch_bwd_fast(a, true, s);
       if (Nc > 1) launch_cond_fast(a, s);  // off-diagonal blocks of the condensed Hessians
-      launch_fwd_fast(a, s);  // (duc = 0: the particles' own Newton steps p_b, in dX / dU)
+      // (the particles' own Newton steps p_b = -K^-1 b_i are not formed: all that is needed of them is pi_i = grad J_i . p_b = b_i . (-K^-1 grad J_i),
+      //  a dot product with the second solve's direction — one forward sweep less per Newton step)
       // right-hand side a_i = grad J_i (unweighted, no barrier shift), same Hessian
       LQArgs ag = a;
       ag.pw = nullptr; ag.wx = ag.wu = nullptr;
@@ -339,7 +340,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       a2.kff = w.es_kff2.d(); a2.gc_part = w.es_gc2.d(); a2.dX = w.dX2.d(); a2.dU = w.dU2.d();
       launch_bwd_fast(a2, true, s);
       launch_fwd_fast(a2, s);  // -> -v_i = -K^-1 grad J_i in dX2 / dU2
-      launch_cost_dots(a, w.X.d(), w.U.d(), w.dX2.d(), w.dU2.d(), w.dX.d(), w.dU.d(), w.es_dots.d(), s);
+      launch_cost_dots(a, w.X.d(), w.U.d(), w.dX2.d(), w.dU2.d(), w.dX2.d(), w.dU2.d(), w.es_dots.d(), s, a.wx, a.wu);  // (at least one of the two exists: the path needs boxes)
       int failflag = 0;
       if (!c->multi()) {
         if (nc > 0) {
