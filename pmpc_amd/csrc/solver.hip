@@ -1425,7 +1425,7 @@ static int solve_impl_body(pmpc_ctx *c, const pmpc_problem *p, pmpc_info *info, 
       if (verbose && cone) printf("pmpc_hip: active set: %d stage cones still open after round %d\n", h.open, h.round);
       if (duc_trace && nc > 0 && !a.cons_G) {
         std::vector<double> hd(nc);
-        HIP_CHECK(hipMemcpy(hd.data(), w.duc.p, nc * D8, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(hd.data(), w.as_delta.p, nc * D8, hipMemcpyDeviceToHost));  // (the step of the shared controls as APPLIED by the round's forward sweep)
         double m = 0.0;
         for (double v : hd) m = std::max(m, std::fabs(v));
         int nset = 0;
