@@ -95,7 +95,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   w.kff.ensure(nu * D8); w.es_kff2.ensure(nu * D8); w.es_kff3.ensure(nu * D8);
   w.gc_part.ensure((size_t)Ml * std::max(nc, 1) * D8); w.es_gc2.ensure((size_t)Ml * std::max(nc, 1) * D8); w.Hc_part.ensure((size_t)Ml * std::max(nc * nc, 1) * D8);
   w.scratch.ensure((size_t)Ml * 3 * x * std::max(nc, 1) * D8);
-  w.es_dots.ensure((size_t)3 * Ml * D8); w.es_coef.ensure((size_t)Ml * D8); w.es_out2.ensure(2 * D8); w.pw.ensure((size_t)Ml * D8); w.Jc.ensure((size_t)Ml * D8);
+  w.es_dots.ensure((size_t)3 * Ml * D8); w.es_coef.ensure((size_t)Ml * D8); w.es_out2.ensure(4 * D8);  // {step size | barrier value, smallest slack} + {barrier value, smallest slack} of the first trial point w.pw.ensure((size_t)Ml * D8); w.Jc.ensure((size_t)Ml * D8);
   // gather table of the sharded runs: [H_i | g_i (b) | g_i (a) | dots | one flag per rank] for ALL particles
   const size_t nH = (size_t)nc * nc, tab_H = 0, tab_gb = tab_H + (size_t)M * nH, tab_ga = tab_gb + (size_t)M * nc, tab_dots = tab_ga + (size_t)M * nc, tab_rank = tab_dots + (size_t)3 * M,
                tab_tot = tab_rank + (size_t)4 * world;
@@ -448,21 +448,30 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       launch_step_to(w.X.d(), w.dX.d(), 1.0, w.es_Xt.d(), (long long)nx, s);
       launch_step_to(w.U.d(), w.dU.d(), 1.0, w.es_Ut.d(), (long long)nu, s);
       launch_scp_residual(w.es_Xt.d(), w.X.d(), w.es_Ut.d(), w.U.d(), (long long)Ml * N, x, u, w.es_out2.d(), s, true);
-      double stepmax = 0.0;
+      // (the barrier at the FULL step — the line search's first trial, nearly always the accepted one — rides in the same read-back)
+      launch_bar_prep(w.es_Xt.d(), w.es_Ut.d(), has_xb ? p->lx : nullptr, has_xb ? p->ux : nullptr, has_ub ? p->lu : nullptr, has_ub ? p->uu : nullptr, w.es_Dx.d(), w.es_wx.d(),
+                      w.es_Du.d(), w.es_wu.d(), mu_b, (long long)nx, (long long)nu, u, N, Nc, a.owner, w.part_sum.d(), w.part_max.d(), w.es_out2.d() + 2, s, smode, sbeta);
+      double stepmax = 0.0, out_first[2] = {0.0, 0.0};
       if (!c->multi()) {
         HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(&stepmax, w.es_out2.p, D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(out_first, w.es_out2.d() + 2, 2 * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-      } else {  // [dots of every particle | largest step of every rank]
-        const size_t tot = (size_t)3 * M + world;
+      } else {  // [dots of every particle | largest step of every rank | (barrier value, smallest slack) of every rank at the full step]
+        const size_t tot = (size_t)3 * M + 3 * world;
         HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tot * D8, s));
         HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + 3 * off, w.es_dots.p, (size_t)3 * Ml * D8, hipMemcpyDeviceToDevice, s));
         HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + 3 * M + c->rank, w.es_out2.p, D8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + 3 * M + world + 2 * c->rank, w.es_out2.d() + 2, 2 * D8, hipMemcpyDeviceToDevice, s));
         allreduce(c, w.epi_gath.p, tot, ncclFloat64, ncclSum);
+        std::vector<double> rs(world);
         HIP_CHECK(hipMemcpyAsync(dots.data(), w.epi_gath.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + 3 * M, (size_t)world * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(rs.data(), w.epi_gath.d() + 3 * M, (size_t)world * D8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + 3 * M + world, (size_t)2 * world * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        for (int r = 0; r < world; r++) stepmax = (rk[r] > stepmax || rk[r] != rk[r]) ? rk[r] : stepmax;
+        for (int r = 0; r < world; r++) stepmax = (rs[r] > stepmax || rs[r] != rs[r]) ? rs[r] : stepmax;
+        combine_out2();
+        out_first[0] = out2[0]; out_first[1] = out2[1];
       }
       newton++;
       auto bar_at = [&](const double *Xe, const double *Ue) {  // barrier arrays + value + smallest slack at a point
@@ -490,7 +499,8 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
           launch_step_to(w.X.d(), w.dX.d(), al, w.es_Xt.d(), (long long)nx, s);
           launch_step_to(w.U.d(), w.dU.d(), al, w.es_Ut.d(), (long long)nu, s);
         }
-        bar_at(w.es_Xt.d(), w.es_Ut.d());
+        if (ls == 0) { out2[0] = out_first[0]; out2[1] = out_first[1]; }
+        else bar_at(w.es_Xt.d(), w.es_Ut.d());
         if (out2[1] > 0.0 && out2[0] == out2[0]) {
           if (al_feas == 0.0) al_feas = al;
           for (int i = 0; i < M; i++) Jt[i] = J[i] + al * (dots[3 * i] + 0.5 * al * dots[3 * i + 2]);
