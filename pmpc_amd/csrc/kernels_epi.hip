@@ -162,6 +162,107 @@ __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, co
   if (tid == 0) { out[3 * i] = s0[0]; out[3 * i + 1] = rhs ? fma(a.pw ? a.pw[i] : 1.0, s0[0], s1[0]) : s1[0]; out[3 * i + 2] = s2[0]; }
 }
 
+// The (Nc u + 1) system of the shared controls and t of one Newton step of the smoothed cone objective, on the device (one rank, Nc u <= 8):
+// per-particle rank-one terms folded by Sherman-Morrison exactly as lcone_smooth_body's host loop does it —
+//   A = sum_i [H_i + sp_i ga_i ga_i', -sp_i ga_i; -sp_i ga_i', sp_i],  rhs = [-sum_i (gb_i + sp_i pi_i ga_i); sum_i sp_i pi_i - (K - sum mu)],
+//   sp_i = sig_i / (1 + sig_i kap_i),  kap_i = max(0, -dots[3i]),  pi_i = dots[3i + 1]
+// — sums in a fixed order (per thread over its particles, wave shuffles, the 16 waves in turn), Gaussian elimination with partial pivoting by
+// thread 0, then coef_i = sig_i (pi_i - dt + ga_i . du) / (1 + sig_i kap_i) for every particle and the shared step du.  What it removes
+// from a Newton step: a stream synchronisation, the read-back of every (H_i, g_i) and two uploads.
+template <int NC>
+__global__ void __launch_bounds__(1024) k_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M,
+                                                      double k_minus_summu, double *coef, double *duc, int *fail) {
+  constexpr int NS = NC * (NC + 1) / 2, E = NS + 2 * NC + 2, N1 = NC + 1;
+  __shared__ double part[16][E], tot[E], sol[N1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double acc[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) acc[e] = 0.0;
+  for (int i = tid; i < M; i += 1024) {
+    const double kap = fmax(0.0, -dots[3 * i]), pi_ = dots[3 * i + 1], sg = sig[i], sp = sg / (1.0 + sg * kap);
+    const double *Hi = Hc_part + (size_t)i * NC * NC, *gai = ga + (size_t)i * NC, *gbi = gb + (size_t)i * NC;
+    double g[NC];
+#pragma unroll
+    for (int r = 0; r < NC; r++) g[r] = gai[r];
+    int e = 0;
+#pragma unroll
+    for (int q = 0; q < NC; q++)
+#pragma unroll
+      for (int r = 0; r <= q; r++) acc[e++] += Hi[r + NC * q] + sp * g[r] * g[q];  // (upper triangle of H_i)
+#pragma unroll
+    for (int r = 0; r < NC; r++) {
+      acc[NS + r] -= sp * g[r];
+      acc[NS + NC + r] -= gbi[r] + sp * pi_ * g[r];
+    }
+    acc[NS + 2 * NC] += sp;
+    acc[NS + 2 * NC + 1] += sp * pi_;
+  }
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    double v = acc[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) part[wv][e] = v;
+  }
+  __syncthreads();
+  if (tid < E) {
+    double v = 0.0;
+    for (int k = 0; k < 16; k++) v += part[k][tid];
+    tot[tid] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double A[N1][N1], b[N1];
+    int e = 0;
+    for (int q = 0; q < NC; q++)
+      for (int r = 0; r <= q; r++) { A[r][q] = tot[e]; A[q][r] = tot[e]; e++; }
+    const double cc = tot[NS + 2 * NC];
+    for (int r = 0; r < NC; r++) {
+      A[r][NC] = A[NC][r] = cc > 0.0 ? tot[NS + r] : 0.0;  // (no row strictly inside: t stays — it is re-optimised exactly at the next point)
+      b[r] = tot[NS + NC + r];
+    }
+    A[NC][NC] = cc > 0.0 ? cc : 1.0;
+    b[NC] = cc > 0.0 ? tot[NS + 2 * NC + 1] - k_minus_summu : 0.0;
+    bool bad = false;
+    for (int k = 0; k < N1; k++) {  // Gaussian elimination with partial pivoting (the matrix is positive definite)
+      int pv = k;
+      for (int r = k + 1; r < N1; r++)
+        if (fabs(A[r][k]) > fabs(A[pv][k])) pv = r;
+      if (pv != k) {
+        for (int q = 0; q < N1; q++) { const double t_ = A[k][q]; A[k][q] = A[pv][q]; A[pv][q] = t_; }
+        const double t_ = b[k]; b[k] = b[pv]; b[pv] = t_;
+      }
+      const double d = A[k][k];
+      if (!(fabs(d) > 0.0)) { bad = true; break; }
+      for (int r = k + 1; r < N1; r++) {
+        const double f_ = A[r][k] / d;
+        for (int q = k; q < N1; q++) A[r][q] -= f_ * A[k][q];
+        b[r] -= f_ * b[k];
+      }
+    }
+    if (!bad)
+      for (int k = N1 - 1; k >= 0; k--) {
+        double v = b[k];
+        for (int q = k + 1; q < N1; q++) v -= A[k][q] * sol[q];
+        sol[k] = v / A[k][k];
+      }
+    if (bad) {
+      *fail = 2;
+      for (int k = 0; k < N1; k++) sol[k] = 0.0;
+    }
+    for (int r = 0; r < NC; r++) duc[r] = sol[r];
+  }
+  __syncthreads();
+  const double dt = sol[NC];
+  for (int i = tid; i < M; i += 1024) {
+    const double kap = fmax(0.0, -dots[3 * i]), pi_ = dots[3 * i + 1], sg = sig[i];
+    double e_ = pi_ - dt;
+#pragma unroll
+    for (int r = 0; r < NC; r++) e_ += ga[(size_t)i * NC + r] * sol[r];
+    coef[i] = sg * e_ / (1.0 + sg * kap);
+  }
+}
+
 // y[i, :] = a[i, :] + coef[i] * b[i, :]   (per-particle scalar; `per` entries per particle)
 __global__ void __launch_bounds__(256) k_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot) {
   for (long long k = blockIdx.x * 256ll + threadIdx.x; k < tot; k += (long long)gridDim.x * 256) y[k] = fma(coef[k / per], b_[k], a_[k]);
@@ -213,6 +314,12 @@ void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const d
                       double *out, hipStream_t s, const double *bx, const double *bu) {
   const size_t lds = (size_t)3 * a.N * (a.x + a.u) * sizeof(double);  // (N (x + u) <= 2 300 inside the 64 KB next to the reduction arrays: N = 100 at x12 u4 is 1 600)
   hipLaunchKernelGGL(k_cost_dots, dim3(a.M), dim3(256), lds, s, a, X, U, dX1, dU1, dX2, dU2, out, bx, bu);
+}
+bool launch_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M, int nc, double k_minus_summu,
+                       double *coef, double *duc, int *fail, hipStream_t s) {
+#define X(NC) case NC: hipLaunchKernelGGL(k_epi_newton<NC>, dim3(1), dim3(1024), 0, s, Hc_part, gb, ga, dots, sig, M, k_minus_summu, coef, duc, fail); return true;
+  switch (nc) { X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) default: return false; }
+#undef X
 }
 void launch_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot, hipStream_t s) {
   hipLaunchKernelGGL(k_axpy_particle, dim3(grid_for(tot)), dim3(256), 0, s, a_, b_, coef, y, per, tot);

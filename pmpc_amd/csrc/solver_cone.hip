@@ -95,7 +95,9 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
   w.kff.ensure(nu * D8); w.es_kff2.ensure(nu * D8); w.es_kff3.ensure(nu * D8);
   w.gc_part.ensure((size_t)Ml * std::max(nc, 1) * D8); w.es_gc2.ensure((size_t)Ml * std::max(nc, 1) * D8); w.Hc_part.ensure((size_t)Ml * std::max(nc * nc, 1) * D8);
   w.scratch.ensure((size_t)Ml * 3 * x * std::max(nc, 1) * D8);
-  w.es_dots.ensure((size_t)3 * Ml * D8); w.es_coef.ensure((size_t)Ml * D8); w.es_out2.ensure(4 * D8);  // {step size | barrier value, smallest slack} + {barrier value, smallest slack} of the first trial point w.pw.ensure((size_t)Ml * D8); w.Jc.ensure((size_t)Ml * D8);
+  w.es_dots.ensure((size_t)3 * Ml * D8); w.pw.ensure((size_t)Ml * D8); w.Jc.ensure((size_t)Ml * D8);
+  w.es_coef.ensure((size_t)2 * Ml * D8);  // [coefficients | sig (input of k_epi_newton)]
+  w.es_out2.ensure(4 * D8);  // {step size | barrier value, smallest slack} + {barrier value, smallest slack} of the first trial point
   // gather table of the sharded runs: [H_i | g_i (b) | g_i (a) | dots | one flag per rank] for ALL particles
   const size_t nH = (size_t)nc * nc, tab_H = 0, tab_gb = tab_H + (size_t)M * nH, tab_ga = tab_gb + (size_t)M * nc, tab_dots = tab_ga + (size_t)M * nc, tab_rank = tab_dots + (size_t)3 * M,
                tab_tot = tab_rank + (size_t)4 * world;
@@ -323,6 +325,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         coef[i] = std::max(mu[i], 1e-8);  // (cost weight of the sweeps: a particle of multiplier zero keeps a strictly convex sub-problem)
       }
       HIP_CHECK(hipMemcpyAsync(w.pw.p, coef.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
+      if (!c->multi()) HIP_CHECK(hipMemcpyAsync(w.es_coef.d() + Ml, sig.data(), (size_t)Ml * D8, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
       // right-hand side b: gradient of sum m_i J_i + barrier (the barrier arrays were written by the last eval_at at this point)
       launch_grad_prep(a, s);
@@ -341,103 +344,112 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       launch_bwd_fast(a2, true, s);
       launch_fwd_fast(a2, s);  // -> -v_i = -K^-1 grad J_i in dX2 / dU2
       launch_cost_dots(a, w.X.d(), w.U.d(), w.dX2.d(), w.dU2.d(), w.dX2.d(), w.dU2.d(), w.es_dots.d(), s, a.wx, a.wu);  // (at least one of the two exists: the path needs boxes)
+      // the (Nc u + 1) system: on the device where it applies (one rank, 1 <= Nc u <= 8) — no read-back of the condensed blocks, no
+      // synchronisation before the direction's sweep; PMPC_SM_DEV=0: the host loop, for A/B
+      static const bool dev_env = !(getenv("PMPC_SM_DEV") && atoi(getenv("PMPC_SM_DEV")) == 0);
+      const bool dev_sys = dev_env && !c->multi() && nc >= 1 && nc <= 8;
       int failflag = 0;
-      if (!c->multi()) {
-        if (nc > 0) {
-          HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, (size_t)M * nc * nc * D8, hipMemcpyDeviceToHost, s));
-          HIP_CHECK(hipMemcpyAsync(gb.data(), w.gc_part.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
-          HIP_CHECK(hipMemcpyAsync(ga.data(), w.es_gc2.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
-        }
-        HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+      if (dev_sys) {
+        launch_epi_newton(w.Hc_part.d(), w.gc_part.d(), w.es_gc2.d(), w.es_dots.d(), w.es_coef.d() + Ml, Ml, nc, K - summu, w.es_coef.d(), w.duc.d(), (int *)w.fail.p, s);
+        inf.structured_solves += 2;
       } else {
-        // one table, one all-reduce: every rank gets every particle's condensed blocks and scalars (and every rank's failure flag)
-        HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tab_tot * D8, s));
-        if (nc > 0) {
-          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_H + off * nH, w.Hc_part.p, (size_t)Ml * nH * D8, hipMemcpyDeviceToDevice, s));
-          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_gb + off * nc, w.gc_part.p, (size_t)Ml * nc * D8, hipMemcpyDeviceToDevice, s));
-          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_ga + off * nc, w.es_gc2.p, (size_t)Ml * nc * D8, hipMemcpyDeviceToDevice, s));
-        }
-        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_dots + 3 * off, w.es_dots.p, (size_t)3 * Ml * D8, hipMemcpyDeviceToDevice, s));
-        HIP_CHECK(hipStreamSynchronize(s));  // (the flag is on the host)
-        const double ff = (double)failflag;
-        HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_rank + 4 * c->rank, &ff, D8, hipMemcpyHostToDevice, s));
-        allreduce(c, w.epi_gath.p, tab_tot, ncclFloat64, ncclSum);
-        if (nc > 0) {
-          HIP_CHECK(hipMemcpyAsync(Hh.data(), w.epi_gath.d() + tab_H, (size_t)M * nH * D8, hipMemcpyDeviceToHost, s));
-          HIP_CHECK(hipMemcpyAsync(gb.data(), w.epi_gath.d() + tab_gb, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
-          HIP_CHECK(hipMemcpyAsync(ga.data(), w.epi_gath.d() + tab_ga, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
-        }
-        HIP_CHECK(hipMemcpyAsync(dots.data(), w.epi_gath.d() + tab_dots, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + tab_rank, (size_t)4 * world * D8, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        for (int r = 0; r < world; r++) failflag = std::max(failflag, (int)rk[4 * r]);
-      }
-      inf.structured_solves += 2;
-      if (failflag) {
-        if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep failed (flag %d)\n", failflag);
-        return finish(2);
-      }
-      // (nc + 1) system of the shared controls and t
-      const int n1 = nc + 1;
-      std::vector<double> A((size_t)n1 * n1, 0.0), rhs(n1, 0.0), sol(n1, 0.0), sp(M), kap(M), pi_(M);
-      double cc = 0.0;
-      for (int i = 0; i < M; i++) {
-        kap[i] = std::max(0.0, -dots[3 * i]);
-        pi_[i] = dots[3 * i + 1];
-        sp[i] = sig[i] / (1.0 + sig[i] * kap[i]);
-        const double *Hi = &Hh[(size_t)i * nc * nc], *gbi = &gb[(size_t)i * nc], *gai = &ga[(size_t)i * nc];
-        for (int r = 0; r < nc; r++) {
-          for (int q_ = 0; q_ < nc; q_++) A[r + (size_t)n1 * q_] += Hi[(r <= q_ ? r : q_) + (size_t)nc * (r <= q_ ? q_ : r)] + sp[i] * gai[r] * gai[q_];
-          A[r + (size_t)n1 * nc] -= sp[i] * gai[r];
-          A[nc + (size_t)n1 * r] -= sp[i] * gai[r];
-          rhs[r] -= gbi[r] + sp[i] * pi_[i] * gai[r];
-        }
-        cc += sp[i];
-        rhs[nc] += sp[i] * pi_[i];
-      }
-      rhs[nc] -= K - summu;
-      A[nc + (size_t)n1 * nc] = cc > 0.0 ? cc : 1.0;  // (no row strictly inside: t stays — it is re-optimised exactly at the next point)
-      if (!(cc > 0.0)) {
-        rhs[nc] = 0.0;
-        for (int r = 0; r < nc; r++) A[r + (size_t)n1 * nc] = A[nc + (size_t)n1 * r] = 0.0;
-      }
-      {  // Gaussian elimination with partial pivoting (the matrix is positive definite; n1 = Nc u + 1)
-        std::vector<double> Mx = A;
-        sol = rhs;
-        for (int k = 0; k < n1; k++) {
-          int pv = k;
-          for (int r = k + 1; r < n1; r++)
-            if (std::fabs(Mx[r + (size_t)n1 * k]) > std::fabs(Mx[pv + (size_t)n1 * k])) pv = r;
-          if (pv != k) {
-            for (int q_ = 0; q_ < n1; q_++) std::swap(Mx[k + (size_t)n1 * q_], Mx[pv + (size_t)n1 * q_]);
-            std::swap(sol[k], sol[pv]);
+        if (!c->multi()) {
+          if (nc > 0) {
+            HIP_CHECK(hipMemcpyAsync(Hh.data(), w.Hc_part.p, (size_t)M * nc * nc * D8, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(gb.data(), w.gc_part.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(ga.data(), w.es_gc2.p, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
           }
-          const double d = Mx[k + (size_t)n1 * k];
-          if (!(std::fabs(d) > 0.0)) return finish(2);
-          for (int r = k + 1; r < n1; r++) {
-            const double fct = Mx[r + (size_t)n1 * k] / d;
-            for (int q_ = k; q_ < n1; q_++) Mx[r + (size_t)n1 * q_] -= fct * Mx[k + (size_t)n1 * q_];
-            sol[r] -= fct * sol[k];
+          HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipStreamSynchronize(s));
+        } else {
+          // one table, one all-reduce: every rank gets every particle's condensed blocks and scalars (and every rank's failure flag)
+          HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tab_tot * D8, s));
+          if (nc > 0) {
+            HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_H + off * nH, w.Hc_part.p, (size_t)Ml * nH * D8, hipMemcpyDeviceToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_gb + off * nc, w.gc_part.p, (size_t)Ml * nc * D8, hipMemcpyDeviceToDevice, s));
+            HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_ga + off * nc, w.es_gc2.p, (size_t)Ml * nc * D8, hipMemcpyDeviceToDevice, s));
+          }
+          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_dots + 3 * off, w.es_dots.p, (size_t)3 * Ml * D8, hipMemcpyDeviceToDevice, s));
+          HIP_CHECK(hipStreamSynchronize(s));  // (the flag is on the host)
+          const double ff = (double)failflag;
+          HIP_CHECK(hipMemcpyAsync(w.epi_gath.d() + tab_rank + 4 * c->rank, &ff, D8, hipMemcpyHostToDevice, s));
+          allreduce(c, w.epi_gath.p, tab_tot, ncclFloat64, ncclSum);
+          if (nc > 0) {
+            HIP_CHECK(hipMemcpyAsync(Hh.data(), w.epi_gath.d() + tab_H, (size_t)M * nH * D8, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(gb.data(), w.epi_gath.d() + tab_gb, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(ga.data(), w.epi_gath.d() + tab_ga, (size_t)M * nc * D8, hipMemcpyDeviceToHost, s));
+          }
+          HIP_CHECK(hipMemcpyAsync(dots.data(), w.epi_gath.d() + tab_dots, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + tab_rank, (size_t)4 * world * D8, hipMemcpyDeviceToHost, s));
+          HIP_CHECK(hipStreamSynchronize(s));
+          for (int r = 0; r < world; r++) failflag = std::max(failflag, (int)rk[4 * r]);
+        }
+        inf.structured_solves += 2;
+        if (failflag) {
+          if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep failed (flag %d)\n", failflag);
+          return finish(2);
+        }
+        // (nc + 1) system of the shared controls and t
+        const int n1 = nc + 1;
+        std::vector<double> A((size_t)n1 * n1, 0.0), rhs(n1, 0.0), sol(n1, 0.0), sp(M), kap(M), pi_(M);
+        double cc = 0.0;
+        for (int i = 0; i < M; i++) {
+          kap[i] = std::max(0.0, -dots[3 * i]);
+          pi_[i] = dots[3 * i + 1];
+          sp[i] = sig[i] / (1.0 + sig[i] * kap[i]);
+          const double *Hi = &Hh[(size_t)i * nc * nc], *gbi = &gb[(size_t)i * nc], *gai = &ga[(size_t)i * nc];
+          for (int r = 0; r < nc; r++) {
+            for (int q_ = 0; q_ < nc; q_++) A[r + (size_t)n1 * q_] += Hi[(r <= q_ ? r : q_) + (size_t)nc * (r <= q_ ? q_ : r)] + sp[i] * gai[r] * gai[q_];
+            A[r + (size_t)n1 * nc] -= sp[i] * gai[r];
+            A[nc + (size_t)n1 * r] -= sp[i] * gai[r];
+            rhs[r] -= gbi[r] + sp[i] * pi_[i] * gai[r];
+          }
+          cc += sp[i];
+          rhs[nc] += sp[i] * pi_[i];
+        }
+        rhs[nc] -= K - summu;
+        A[nc + (size_t)n1 * nc] = cc > 0.0 ? cc : 1.0;  // (no row strictly inside: t stays — it is re-optimised exactly at the next point)
+        if (!(cc > 0.0)) {
+          rhs[nc] = 0.0;
+          for (int r = 0; r < nc; r++) A[r + (size_t)n1 * nc] = A[nc + (size_t)n1 * r] = 0.0;
+        }
+        {  // Gaussian elimination with partial pivoting (the matrix is positive definite; n1 = Nc u + 1)
+          std::vector<double> Mx = A;
+          sol = rhs;
+          for (int k = 0; k < n1; k++) {
+            int pv = k;
+            for (int r = k + 1; r < n1; r++)
+              if (std::fabs(Mx[r + (size_t)n1 * k]) > std::fabs(Mx[pv + (size_t)n1 * k])) pv = r;
+            if (pv != k) {
+              for (int q_ = 0; q_ < n1; q_++) std::swap(Mx[k + (size_t)n1 * q_], Mx[pv + (size_t)n1 * q_]);
+              std::swap(sol[k], sol[pv]);
+            }
+            const double d = Mx[k + (size_t)n1 * k];
+            if (!(std::fabs(d) > 0.0)) return finish(2);
+            for (int r = k + 1; r < n1; r++) {
+              const double fct = Mx[r + (size_t)n1 * k] / d;
+              for (int q_ = k; q_ < n1; q_++) Mx[r + (size_t)n1 * q_] -= fct * Mx[k + (size_t)n1 * q_];
+              sol[r] -= fct * sol[k];
+            }
+          }
+          for (int k = n1 - 1; k >= 0; k--) {
+            double v = sol[k];
+            for (int q_ = k + 1; q_ < n1; q_++) v -= Mx[k + (size_t)n1 * q_] * sol[q_];
+            sol[k] = v / Mx[k + (size_t)n1 * k];
           }
         }
-        for (int k = n1 - 1; k >= 0; k--) {
-          double v = sol[k];
-          for (int q_ = k + 1; q_ < n1; q_++) v -= Mx[k + (size_t)n1 * q_] * sol[q_];
-          sol[k] = v / Mx[k + (size_t)n1 * k];
+        const double dt = sol[nc];
+        for (int i = 0; i < M; i++) {
+          double e_ = pi_[i] - dt;
+          for (int r = 0; r < nc; r++) e_ += ga[(size_t)i * nc + r] * sol[r];
+          coef[i] = sig[i] * e_ / (1.0 + sig[i] * kap[i]);
         }
+        // total direction: feed-forward k_b + c_i k_a, shared step du_c
+        HIP_CHECK(hipMemcpyAsync(w.es_coef.p, coef.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
+        if (nc > 0) HIP_CHECK(hipMemcpyAsync(w.duc.p, sol.data(), (size_t)nc * D8, hipMemcpyHostToDevice, s));
       }
-      const double dt = sol[nc];
-      for (int i = 0; i < M; i++) {
-        double e_ = pi_[i] - dt;
-        for (int r = 0; r < nc; r++) e_ += ga[(size_t)i * nc + r] * sol[r];
-        coef[i] = sig[i] * e_ / (1.0 + sig[i] * kap[i]);
-      }
-      // total direction: feed-forward k_b + c_i k_a, shared step du_c
-      HIP_CHECK(hipMemcpyAsync(w.es_coef.p, coef.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
-      if (nc > 0) HIP_CHECK(hipMemcpyAsync(w.duc.p, sol.data(), (size_t)nc * D8, hipMemcpyHostToDevice, s));
       launch_axpy_particle(w.kff.d(), w.es_kff2.d(), w.es_coef.d(), w.es_kff3.d(), (long long)N * u, (long long)nu, s);
       LQArgs a3 = a;
       a3.kff = w.es_kff3.d(); a3.duc = nc > 0 ? w.duc.d() : w.es_zero.d();
@@ -456,7 +468,12 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         HIP_CHECK(hipMemcpyAsync(dots.data(), w.es_dots.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(&stepmax, w.es_out2.p, D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(out_first, w.es_out2.d() + 2, 2 * D8, hipMemcpyDeviceToHost, s));
+        if (dev_sys) HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        if (dev_sys && failflag) {
+          if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep or the Newton system failed (flag %d)\n", failflag);
+          return finish(2);
+        }
       } else {  // [dots of every particle | largest step of every rank | (barrier value, smallest slack) of every rank at the full step]
         const size_t tot = (size_t)3 * M + 3 * world;
         HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tot * D8, s));
