@@ -169,13 +169,21 @@ __global__ void __launch_bounds__(256) k_cost_dots(LQArgs a, const double *X, co
 // — sums in a fixed order (per thread over its particles, wave shuffles, the 16 waves in turn), Gaussian elimination with partial pivoting by
 // thread 0, then coef_i = sig_i (pi_i - dt + ga_i . du) / (1 + sig_i kap_i) for every particle and the shared step du.  What it removes
 // from a Newton step: a stream synchronisation, the read-back of every (H_i, g_i) and two uploads.
-template <int NC>
+// MODE 0: sums, solve and coefficients in one launch (one rank).  Sharded: MODE 1 leaves this rank's sums in `xch` (E doubles + its failure
+// flag), the caller all-reduces them, MODE 2 solves from `xch` and writes the coefficients of this rank's particles — the exchange is E + 1
+// doubles per Newton step instead of every particle's condensed blocks.
+template <int NC, int MODE>
 __global__ void __launch_bounds__(1024) k_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M,
-                                                      double k_minus_summu, double *coef, double *duc, int *fail) {
+                                                      double k_minus_summu, double *coef, double *duc, int *fail, double *xch) {
   constexpr int NS = NC * (NC + 1) / 2, E = NS + 2 * NC + 2, N1 = NC + 1;
   __shared__ double part[16][E], tot[E], sol[N1];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double acc[E];
+  if (MODE == 2) {
+    if (tid < E) tot[tid] = xch[tid];
+    if (tid == 0 && xch[E] != 0.0) *fail = 2;  // (a rank's factor sweep failed: every rank gives up alike)
+    __syncthreads();
+  } else {
 #pragma unroll
   for (int e = 0; e < E; e++) acc[e] = 0.0;
   for (int i = tid; i < M; i += 1024) {
@@ -209,8 +217,14 @@ __global__ void __launch_bounds__(1024) k_epi_newton(const double *Hc_part, cons
     double v = 0.0;
     for (int k = 0; k < 16; k++) v += part[k][tid];
     tot[tid] = v;
+    if (MODE == 1) xch[tid] = v;
+  }
+  if (MODE == 1) {
+    if (tid == 0) xch[E] = (double)*fail;
+    return;
   }
   __syncthreads();
+  }
   if (tid == 0) {
     double A[N1][N1], b[N1];
     int e = 0;
@@ -315,10 +329,16 @@ void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const d
   const size_t lds = (size_t)3 * a.N * (a.x + a.u) * sizeof(double);  // (N (x + u) <= 2 300 inside the 64 KB next to the reduction arrays: N = 100 at x12 u4 is 1 600)
   hipLaunchKernelGGL(k_cost_dots, dim3(a.M), dim3(256), lds, s, a, X, U, dX1, dU1, dX2, dU2, out, bx, bu);
 }
-bool launch_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M, int nc, double k_minus_summu,
-                       double *coef, double *duc, int *fail, hipStream_t s) {
-#define X(NC) case NC: hipLaunchKernelGGL(k_epi_newton<NC>, dim3(1), dim3(1024), 0, s, Hc_part, gb, ga, dots, sig, M, k_minus_summu, coef, duc, fail); return true;
-  switch (nc) { X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) default: return false; }
+// mode 0: everything (one rank); 1: this rank's sums -> xch (returns their count, fail flag included, for the all-reduce); 2: solve from xch
+int launch_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M, int nc, double k_minus_summu,
+                      double *coef, double *duc, int *fail, hipStream_t s, int mode, double *xch) {
+#define X(NC)                                                                                                                                            \
+  case NC:                                                                                                                                               \
+    if (mode == 0) hipLaunchKernelGGL((k_epi_newton<NC, 0>), dim3(1), dim3(1024), 0, s, Hc_part, gb, ga, dots, sig, M, k_minus_summu, coef, duc, fail, xch);       \
+    else if (mode == 1) hipLaunchKernelGGL((k_epi_newton<NC, 1>), dim3(1), dim3(1024), 0, s, Hc_part, gb, ga, dots, sig, M, k_minus_summu, coef, duc, fail, xch);  \
+    else hipLaunchKernelGGL((k_epi_newton<NC, 2>), dim3(1), dim3(1024), 0, s, Hc_part, gb, ga, dots, sig, M, k_minus_summu, coef, duc, fail, xch);                 \
+    return NC * (NC + 1) / 2 + 2 * NC + 2 + 1;
+  switch (nc) { X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) default: return 0; }
 #undef X
 }
 void launch_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot, hipStream_t s) {

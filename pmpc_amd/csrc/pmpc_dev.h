@@ -382,8 +382,8 @@ void launch_bar_prep(const double *X, const double *U, const double *lx, const d
                      double *out2, hipStream_t s, int mode = 0, double beta = 1.0);  // out2 = {barrier value, smallest slack}; mode 1: squareplus hinge (mu = 1/alpha)
 void launch_cost_dots(const LQArgs &a, const double *X, const double *U, const double *dX1, const double *dU1, const double *dX2, const double *dU2,
                       double *out, hipStream_t s, const double *bx = nullptr, const double *bu = nullptr);  // per particle {grad J . d1, grad J . d2, d1' hess J d1}
-bool launch_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M, int nc, double k_minus_summu,
-                       double *coef, double *duc, int *fail, hipStream_t s);  // (Nc u + 1) system of the smoothed cone objective's Newton step (false: Nc u > 8)
+int launch_epi_newton(const double *Hc_part, const double *gb, const double *ga, const double *dots, const double *sig, int M, int nc, double k_minus_summu,
+                      double *coef, double *duc, int *fail, hipStream_t s, int mode = 0, double *xch = nullptr);  // (Nc u + 1) system of the smoothed cone objective's Newton step (0: Nc u > 8)
 void launch_axpy_particle(const double *a_, const double *b_, const double *coef, double *y, long long per, long long tot, hipStream_t s);
 void launch_step_to(const double *a_, const double *b_, double alpha, double *y, long long tot, hipStream_t s);
 void launch_interior(double *U, const double *lo, const double *hi, long long tot, double frac, hipStream_t s);

@@ -325,7 +325,7 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         coef[i] = std::max(mu[i], 1e-8);  // (cost weight of the sweeps: a particle of multiplier zero keeps a strictly convex sub-problem)
       }
       HIP_CHECK(hipMemcpyAsync(w.pw.p, coef.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
-      if (!c->multi()) HIP_CHECK(hipMemcpyAsync(w.es_coef.d() + Ml, sig.data(), (size_t)Ml * D8, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipMemcpyAsync(w.es_coef.d() + Ml, sig.data() + off, (size_t)Ml * D8, hipMemcpyHostToDevice, s));
       HIP_CHECK(hipMemsetAsync(w.fail.p, 0, sizeof(int), s));
       // right-hand side b: gradient of sum m_i J_i + barrier (the barrier arrays were written by the last eval_at at this point)
       launch_grad_prep(a, s);
@@ -344,13 +344,22 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
       launch_bwd_fast(a2, true, s);
       launch_fwd_fast(a2, s);  // -> -v_i = -K^-1 grad J_i in dX2 / dU2
       launch_cost_dots(a, w.X.d(), w.U.d(), w.dX2.d(), w.dU2.d(), w.dX2.d(), w.dU2.d(), w.es_dots.d(), s, a.wx, a.wu);  // (at least one of the two exists: the path needs boxes)
-      // the (Nc u + 1) system: on the device where it applies (one rank, 1 <= Nc u <= 8) — no read-back of the condensed blocks, no
-      // synchronisation before the direction's sweep; PMPC_SM_DEV=0: the host loop, for A/B
+      // the (Nc u + 1) system: on the device where it applies (1 <= Nc u <= 8) — no read-back of the condensed blocks, no synchronisation
+      // before the direction's sweep; sharded: every rank sums its own particles' terms, ONE all-reduce of those sums (<= 55 doubles,
+      // the failure flags among them) instead of the table of every particle's blocks.  PMPC_SM_DEV=0: the host loop, for A/B
       static const bool dev_env = !(getenv("PMPC_SM_DEV") && atoi(getenv("PMPC_SM_DEV")) == 0);
-      const bool dev_sys = dev_env && !c->multi() && nc >= 1 && nc <= 8;
+      const bool dev_sys = dev_env && nc >= 1 && nc <= 8;
       int failflag = 0;
       if (dev_sys) {
-        launch_epi_newton(w.Hc_part.d(), w.gc_part.d(), w.es_gc2.d(), w.es_dots.d(), w.es_coef.d() + Ml, Ml, nc, K - summu, w.es_coef.d(), w.duc.d(), (int *)w.fail.p, s);
+        if (!c->multi()) {
+          launch_epi_newton(w.Hc_part.d(), w.gc_part.d(), w.es_gc2.d(), w.es_dots.d(), w.es_coef.d() + Ml, Ml, nc, K - summu, w.es_coef.d(), w.duc.d(), (int *)w.fail.p, s);
+        } else {
+          const int n_x = launch_epi_newton(w.Hc_part.d(), w.gc_part.d(), w.es_gc2.d(), w.es_dots.d(), w.es_coef.d() + Ml, Ml, nc, K - summu, w.es_coef.d(), w.duc.d(),
+                                            (int *)w.fail.p, s, 1, w.epi_gath.d());
+          allreduce(c, w.epi_gath.p, (size_t)n_x, ncclFloat64, ncclSum);
+          launch_epi_newton(w.Hc_part.d(), w.gc_part.d(), w.es_gc2.d(), w.es_dots.d(), w.es_coef.d() + Ml, Ml, nc, K - summu, w.es_coef.d(), w.duc.d(), (int *)w.fail.p, s, 2,
+                            w.epi_gath.d());
+        }
         inf.structured_solves += 2;
       } else {
         if (!c->multi()) {
@@ -470,10 +479,6 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         HIP_CHECK(hipMemcpyAsync(out_first, w.es_out2.d() + 2, 2 * D8, hipMemcpyDeviceToHost, s));
         if (dev_sys) HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
-        if (dev_sys && failflag) {
-          if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep or the Newton system failed (flag %d)\n", failflag);
-          return finish(2);
-        }
       } else {  // [dots of every particle | largest step of every rank | (barrier value, smallest slack) of every rank at the full step]
         const size_t tot = (size_t)3 * M + 3 * world;
         HIP_CHECK(hipMemsetAsync(w.epi_gath.p, 0, tot * D8, s));
@@ -485,10 +490,15 @@ static int lcone_smooth_body(pmpc_ctx *c, const pmpc_problem *p, double mu_b, pm
         HIP_CHECK(hipMemcpyAsync(dots.data(), w.epi_gath.p, (size_t)3 * M * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(rs.data(), w.epi_gath.d() + 3 * M, (size_t)world * D8, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(rk.data(), w.epi_gath.d() + 3 * M + world, (size_t)2 * world * D8, hipMemcpyDeviceToHost, s));
+        if (dev_sys) HIP_CHECK(hipMemcpyAsync(&failflag, w.fail.p, sizeof(int), hipMemcpyDeviceToHost, s));  // (the same on every rank: the flags were summed)
         HIP_CHECK(hipStreamSynchronize(s));
         for (int r = 0; r < world; r++) stepmax = (rs[r] > stepmax || rs[r] != rs[r]) ? rs[r] : stepmax;
         combine_out2();
         out_first[0] = out2[0]; out_first[1] = out2[1];
+      }
+      if (dev_sys && failflag) {
+        if (verbose) printf("pmpc_hip: smoothed cone objective: a factor sweep or the Newton system failed (flag %d)\n", failflag);
+        return finish(2);
       }
       newton++;
       auto bar_at = [&](const double *Xe, const double *Ue) {  // barrier arrays + value + smallest slack at a point
