@@ -518,3 +518,18 @@ def test_state_rows_restated_as_auxiliary_states_are_the_same_problem(oracle):
     bad = np.zeros((1, n)); bad[0, xcol(0, 0, 0)] = 1.0; bad[0, ucol(0, 3, 0)] = 1.0
     with pytest.raises(ValueError, match="couples state stage"):
         stage_rows_from_extra_cstrs([(1, [], 0, bad, np.zeros((1, 0)), np.ones(1), np.zeros(n), np.zeros(0))], M, N, x, u, Nc)
+
+
+def test_every_context_option_is_documented_where_a_maintainer_looks():
+    """The option table of the library (pmpc_set_option / the environment variables that set the defaults) against include/pmpc_abi.h and
+    INTEGRATION.md: an option added to the table and not to the documents fails here, not in a reader's hands."""
+    import re
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    table = (root / "pmpc_amd" / "csrc" / "solver.hip").read_text()
+    opts = re.findall(r'\{"([a-z_0-9]+)", "(PMPC_[A-Z_0-9]+)", [^}]+\}', table)
+    assert len(opts) >= 20, opts
+    header, integ = (root / "include" / "pmpc_abi.h").read_text(), (root / "INTEGRATION.md").read_text()
+    missing = [(n, e) for n, e in opts if n not in header or e not in header or (e not in integ and n not in integ)]
+    assert not missing, missing
