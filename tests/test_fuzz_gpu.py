@@ -69,6 +69,13 @@ def test_fuzz_sharded_smoothed_cone_objective_equals_one_rank():
     assert m and int(m.group(3)) == 0 and int(m.group(2)) < 25 and float(m.group(4)) <= 1e-8, last
 
 
+def test_fuzz_dense_consensus_systems():
+    """17 .. 256 shared unknowns (the register-resident consensus factorisation and, at 256, the blocked one), held shared controls, cold and warm."""
+    last = _run("fuzz_dense_cons.py", 71, 60)[-1]
+    m = re.search(r"(\d+) cases \((\d+) with a shared control on its bound\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)
+    assert m and int(m.group(3)) == 0 and int(m.group(2)) >= 30 and float(m.group(4)) <= 1e-7, last
+
+
 def test_fuzz_sequence_of_unrelated_problems_on_one_context():
     last = _run("fuzz_sequence.py", 41, 150)[-1]
     m = re.search(r"(\d+) calls \((\d+) skipped\), (\d+) failures, worst rel err ([0-9.e+-]+)", last)

@@ -18,3 +18,4 @@ run tools/fuzz/fuzz_sharded.py $((b+14)) 200 smooth
 run tools/fuzz/fuzz_sequence.py $((b+11)) 400
 run tools/fuzz/fuzz_scp_loop.py $((b+12)) 300
 run tools/fuzz/fuzz_freeze.py $((b+13)) 100 5
+run tools/fuzz/fuzz_dense_cons.py $((b+15)) 150
